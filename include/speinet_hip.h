@@ -1,0 +1,122 @@
+/*
+ * speinet_hip.h — C-ABI of the MI355X (gfx950) kernels behind SPEINet's per-sequence forward pass.
+ *
+ * The reference (yangt1013/SPEINet) is pure PyTorch: it has no FFI for this path, so this header *defines*
+ * the boundary underneath the drop-in Python class (last row).  Each entry point names the
+ * reference code it replaces (file:line relative to the reference tree).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocates; the library never
+ *     allocates, frees or synchronises), every call is asynchronous on `stream`;
+ *   - feature maps are NHWC fp32 ("pixel rows": [H][W][C], C contiguous) with an explicit row stride `ld*`
+ *     in floats so channel-concatenated buffers are addressed in place; frames are NCHW fp32 planes;
+ *   - packed weights are [tap][Cout][Cin] fp32 (speinet_amd/pack.py builds them once per checkpoint);
+ *   - return 0 on success, <0 on error: -1 bad argument / unsupported shape, -2 launch failure; the text
+ *     is available from spei_last_error() (thread local).
+ */
+#ifndef SPEINET_HIP_H
+#define SPEINET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* spei_stream_t; /* hipStream_t */
+
+#define SPEI_ACT_NONE 0
+#define SPEI_ACT_RELU 1
+#define SPEI_ACT_GELU 2 /* exact erf GELU (nn.GELU default, reference model/swinir.py:14-19) */
+
+#define SPEI_CONV 0
+#define SPEI_CONV_TRANSPOSED 1 /* ConvTranspose2d(k, stride, pad=k/2, output_padding=stride-1) */
+
+int spei_version(void);
+const char* spei_last_error(void);
+const char* spei_arch(void); /* "gfx950" */
+
+/* K15 — routing test `torch.all(x[:,3]==0)` (model/speinet.py:70-73).  flag[0] := 1 if any element != 0. */
+int spei_any_nonzero(const float* x, int64_t n, int32_t* flag, spei_stream_t stream);
+
+/* K1 — r_l_per_channel(img, box5/25, iters, lam) (model/rcl.py:22-51).  img/out: [C][H][W]; scratch same size. */
+int spei_rl_prior(const float* img, float* out, float* scratch, int C, int H, int W, int iters, float lam,
+                  spei_stream_t stream);
+
+/* K2 head — first conv 5x5 pad 2, Cin=3 NCHW planes -> NHWC [H][W][Cout], +bias, ReLU
+ * (model/recons_video_ori.py:28-32).  w: [25][Cout][3] packed, Cout == 32. */
+int spei_conv5_in(const float* img_chw, const float* w, const float* bias, float* out_hwc, int H, int W,
+                  int Cout, spei_stream_t stream);
+
+/* K2 tail — last conv 5x5 pad 2, NHWC [H][W][32] -> NCHW [3][H][W], +bias, no activation
+ * (model/recons_video_ori.py:75-77).  w: [25][3][Cin] packed. */
+int spei_conv5_out(const float* in_hwc, int ldi, const float* w, const float* bias, float* out_chw, int H,
+                   int W, int Cin, spei_stream_t stream);
+
+/* K2/K4/K5/K6/K9 — implicit-GEMM convolution / linear on f32 MFMA:
+ *   out[m][n] = epi( sum_t sum_k A[src(m,t)][k] * w[t][n][k] ),  m = oy*Wout+ox, k over cat(a0[:, :k0], a1[:, :k1])
+ *   epi(v) = (act(v + bias[n])) * rowscale[m] + residual[m][n]      (rowscale / residual optional)
+ * Replaces nn.Conv2d / nn.ConvTranspose2d / nn.Linear call sites: model/block.py:26-47, model/swinir.py:18-29,
+ * 105-108,467,667,716,742, model/speinet.py:55-66,93-119, model/recons_video_ori.py:44-71.
+ * Constraints: k0, k1 multiples of 32; N multiple of 32; lda*, ldo, ldr multiples of 4. */
+int spei_igemm_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const float* w,
+                   const float* bias, float* out, int ldo, const float* residual, int ldr,
+                   const float* rowscale, int Hin, int Win, int Hout, int Wout, int N, int ksize, int stride,
+                   int pad, int mode, int act, spei_stream_t stream);
+
+/* K3 — ResBlock gates (model/block.py:8-24 SE, 71-96 ZPool+AttentionGate1/2, 108-124 TripletAttention).
+ * x1: conv2 output [H][W][C].  Workspace `ws` floats: spei_gate_ws_floats(H,W,C).
+ * Produces s[C], g1[H][C], g2[W][C] such that ResBlock = x + x1*s + (x1*g1 + x1*g2).
+ * gate params (packed by speinet_amd/pack.py): se_w1[C/4][C], se_b1[C/4], se_w2[C][C/4], se_b2[C],
+ * cw_w[2][7][7], cw_bn[2] = {scale, shift}, hc_w[2][5][5], hc_bn[2]. */
+int64_t spei_gate_ws_floats(int H, int W, int C);
+int spei_resblock_gates(const float* x1, int H, int W, int C, const float* se_w1, const float* se_b1,
+                        const float* se_w2, const float* se_b2, const float* cw_w, const float* cw_bn,
+                        const float* hc_w, const float* hc_bn, float* s, float* g1, float* g2, float* ws,
+                        spei_stream_t stream);
+/* out = x + x1*s + (x1*g1 + x1*g2) [+ extra]   (model/block.py:136-140; `extra` fuses speinet.py:84,132) */
+int spei_resblock_apply(const float* x, const float* x1, const float* s, const float* g1, const float* g2,
+                        const float* extra, float* out, int ldo, int H, int W, int C, spei_stream_t stream);
+
+/* K7 — LayerNorm over C=256, eps 1e-5 (model/swinir.py:244-245,279,528-529,776).  gamma/beta may be NULL
+ * (affine folded into the following linear by pack.py). */
+int spei_layernorm256(const float* x, float* y, const float* gamma, const float* beta, int64_t M,
+                      spei_stream_t stream);
+
+/* K8 — window attention core: cyclic shift, 5x5 partition, softmax(q k^T + relbias + shift mask) v, reverse
+ * (model/swinir.py:115-149, 215-236, 250-275).  q [H*W][256] (scale folded), kv [H*W][512] (K then V, head major),
+ * relbias [8][25][25] pre-gathered, out [H*W][256]; heads = 8, head_dim = 32, window 5. */
+int spei_window_attention(const float* q, const float* kv, const float* relbias, float* out, int H, int W,
+                          int shift, spei_stream_t stream);
+
+/* K10 — 1 / max(||unfold3x3(f)[p]||_2, 1e-12) per position (F.normalize, model/SearchTransfer.py:30-31). */
+int spei_patch_invnorm(const float* f, int ldf, float* inv, int H, int W, int C, spei_stream_t stream);
+
+/* K11 — fused correlation + max/argmax over the reference index j (model/SearchTransfer.py:33-34, 68-69):
+ *   S[i] = max_j <P_ref[j], P_lr[i]> * inv_ref[j] * inv_lr[i],  arg[i] = lowest maximising j.
+ * R is never materialised.  Workspace floats: spei_corr_ws_floats(Hl*Wl).  C must be 128. */
+int64_t spei_corr_ws_floats(int64_t n_lr);
+int spei_corr_argmax(const float* lr, int ldl, const float* ref, int ldr, const float* inv_lr,
+                     const float* inv_ref, int Hl, int Wl, int Hr, int Wr, int C, float* S, int32_t* arg,
+                     float* ws, spei_stream_t stream);
+
+/* K12 — gather the best-matching reference patch and overlap-add (unfold -> bis -> fold / 9,
+ * model/SearchTransfer.py:36-46).  scale s in {1,2,4}: patch 3s, stride s, pad s. */
+int spei_gather_fold(const float* ref, int ldr, const int32_t* arg, float* out, int ldo, int H3, int W3,
+                     int Hr3, int Wr3, int C, int s, spei_stream_t stream);
+
+/* SelfTransfer's reference map x.transpose(2,3).flip(2) (model/SearchTransfer.py:60): [H][W][C] -> [W][H][C]. */
+int spei_rot90(const float* in, int ldi, float* out, int H, int W, int C, spei_stream_t stream);
+
+/* K13 — F.interpolate(mode='bicubic', align_corners=False), A=-0.75, scale s in {2,4}
+ * (model/speinet.py:96,99,108,111,113; model/SearchTransfer.py:73,75). */
+int spei_upsample_bicubic(const float* in, int ldi, float* out, int ldo, int H, int W, int C, int s,
+                          spei_stream_t stream);
+
+/* K14 — out = a + b over n floats. */
+int spei_add(const float* a, const float* b, float* out, int64_t n, spei_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

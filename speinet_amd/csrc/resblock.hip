@@ -1,0 +1,256 @@
+// K3 — ResBlock epilogue: SE + TripletAttention gates and the gated residual sum
+// (reference model/block.py:8-24, 71-96, 108-140).  x1 is conv2's output, NHWC [H][W][C].
+//
+//   s[c]      = sigmoid(W2 relu(W1 mean_hw(x1) + b1) + b2)
+//   g1[h][c]  = BN(conv7x7([max_w x1, mean_w x1]))   on the (H, C) plane, zero pad 3, no sigmoid
+//   g2[w][c]  = BN(conv5x5([max_h x1, mean_h x1]))   on the (C, W) plane, zero pad 2, no sigmoid
+//   out       = x + (x1*s + (x1*g1 + x1*g2))
+//
+// Three global reductions force a grid-wide dependency, so the gates take three small launches
+// (stats -> reduce+SE -> gate maps) and the application one elementwise launch.  All partial sums are
+// combined in a fixed order: results are bitwise reproducible run to run.
+#include "common.h"
+
+namespace {
+
+constexpr int COL_TW = 64;     // columns per column-stat block
+constexpr int COL_STRIPS = 16; // row strips for the column partials
+
+// workspace layout (floats)
+struct GateWs {
+    float* rowmax;   // [H][C]
+    float* rowmean;  // [H][C]
+    float* colpmax;  // [S][W][C]
+    float* colpsum;  // [S][W][C]
+    float* colmax;   // [W][C]
+    float* colmean;  // [W][C]
+};
+__host__ __device__ inline GateWs carve(float* ws, int H, int W, int C) {
+    GateWs g;
+    g.rowmax = ws;
+    g.rowmean = g.rowmax + (size_t)H * C;
+    g.colpmax = g.rowmean + (size_t)H * C;
+    g.colpsum = g.colpmax + (size_t)COL_STRIPS * W * C;
+    g.colmax = g.colpsum + (size_t)COL_STRIPS * W * C;
+    g.colmean = g.colmax + (size_t)W * C;
+    return g;
+}
+
+// ---- launch 1: row stats (blocks [0,H)) and column partials (blocks [H, H + ctiles*S)) --------------
+template <int C>
+__global__ __launch_bounds__(256) void gate_stats_kernel(const float* __restrict__ x1, int H, int W, GateWs g) {
+    constexpr int G = 256 / C;      // column groups per block
+    __shared__ float smax[256], ssum[256];
+    const int c = threadIdx.x % C, grp = threadIdx.x / C;
+    if ((int)blockIdx.x < H) {
+        const int y = blockIdx.x;
+        const float* row = x1 + (size_t)y * W * C;
+        float mx = -INFINITY, sm = 0.f;
+        for (int x = grp; x < W; x += G) {
+            const float v = row[(size_t)x * C + c];
+            mx = fmaxf(mx, v);
+            sm += v;
+        }
+        smax[threadIdx.x] = mx;
+        ssum[threadIdx.x] = sm;
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int k = 1; k < G; ++k) {
+                mx = fmaxf(mx, smax[k * C + c]);
+                sm += ssum[k * C + c];
+            }
+            g.rowmax[(size_t)y * C + c] = mx;
+            g.rowmean[(size_t)y * C + c] = sm / (float)W;
+        }
+    } else {
+        const int b = blockIdx.x - H;
+        const int ctiles = (W + COL_TW - 1) / COL_TW;
+        const int tile = b % ctiles, strip = b / ctiles;
+        const int rows = (H + COL_STRIPS - 1) / COL_STRIPS;
+        const int ya = strip * rows, yb = min(H, ya + rows);
+        for (int xo = grp; xo < COL_TW; xo += G) {
+            const int x = tile * COL_TW + xo;
+            if (x >= W) break;
+            float mx = -INFINITY, sm = 0.f;
+            for (int y = ya; y < yb; ++y) {
+                const float v = x1[((size_t)y * W + x) * C + c];
+                mx = fmaxf(mx, v);
+                sm += v;
+            }
+            g.colpmax[((size_t)strip * W + x) * C + c] = mx;
+            g.colpsum[((size_t)strip * W + x) * C + c] = sm;
+        }
+    }
+}
+
+// ---- launch 2: block 0 = SE vector; other blocks = reduce column partials over the strips ----------
+__global__ __launch_bounds__(256) void gate_reduce_kernel(int H, int W, int C, GateWs g, const float* __restrict__ w1,
+                                                          const float* __restrict__ b1, const float* __restrict__ w2,
+                                                          const float* __restrict__ b2, float* __restrict__ s) {
+    if (blockIdx.x == 0) {
+        __shared__ float mean[128], hid[32], part[256];
+        const int G = 256 / C;
+        const int c = threadIdx.x % C, grp = threadIdx.x / C;
+        float sm = 0.f;
+        for (int y = grp; y < H; y += G) sm += g.rowmean[(size_t)y * C + c];
+        part[threadIdx.x] = sm;
+        __syncthreads();
+        if (grp == 0) {
+            for (int k = 1; k < G; ++k) sm += part[k * C + c];
+            mean[c] = sm / (float)H;
+        }
+        __syncthreads();
+        const int mid = C / 4;
+        if ((int)threadIdx.x < mid) {
+            float a = b1[threadIdx.x];
+            for (int k = 0; k < C; ++k) a = fmaf(w1[threadIdx.x * C + k], mean[k], a);
+            hid[threadIdx.x] = fmaxf(a, 0.f);
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < C) {
+            float a = b2[threadIdx.x];
+            for (int k = 0; k < mid; ++k) a = fmaf(w2[threadIdx.x * mid + k], hid[k], a);
+            s[threadIdx.x] = 1.0f / (1.0f + expf(-a));
+        }
+    } else {
+        const int64_t i = (int64_t)(blockIdx.x - 1) * 256 + threadIdx.x;
+        if (i < (int64_t)W * C) {
+            float mx = -INFINITY, sm = 0.f;
+            const int rows = (H + COL_STRIPS - 1) / COL_STRIPS;
+            for (int k = 0; k < COL_STRIPS; ++k) {
+                if (k * rows >= H) break;
+                mx = fmaxf(mx, g.colpmax[(size_t)k * W * C + i]);
+                sm += g.colpsum[(size_t)k * W * C + i];
+            }
+            g.colmax[i] = mx;
+            g.colmean[i] = sm / (float)H;
+        }
+    }
+}
+
+// ---- launch 3: the two 2->1 channel convolutions + eval BatchNorm(1) ------------------------------
+__global__ __launch_bounds__(256) void gate_maps_kernel(int H, int W, int C, GateWs g, const float* __restrict__ cw_w,
+                                                        const float* __restrict__ cw_bn, const float* __restrict__ hc_w,
+                                                        const float* __restrict__ hc_bn, float* __restrict__ g1,
+                                                        float* __restrict__ g2) {
+    __shared__ float wk[98];
+    const int64_t n1 = (int64_t)H * C;
+    const int nb1 = (int)((n1 + 255) / 256);
+    if ((int)blockIdx.x < nb1) {
+        if (threadIdx.x < 98) wk[threadIdx.x] = cw_w[threadIdx.x];
+        __syncthreads();
+        const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (i >= n1) return;
+        const int c = (int)(i % C), y = (int)(i / C);
+        float acc = 0.f;
+        // conv "height" axis = H, "width" axis = C  (x.permute(0,3,2,1) -> [B,W,H,C], ZPool over dim 1)
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const float* z = ch == 0 ? g.rowmax : g.rowmean;
+            for (int dy = 0; dy < 7; ++dy) {
+                const int yy = y + dy - 3;
+                if (yy < 0 || yy >= H) continue;
+                for (int dc = 0; dc < 7; ++dc) {
+                    const int cc = c + dc - 3;
+                    if (cc < 0 || cc >= C) continue;
+                    acc = fmaf(wk[ch * 49 + dy * 7 + dc], z[(size_t)yy * C + cc], acc);
+                }
+            }
+        }
+        g1[i] = fmaf(acc, cw_bn[0], cw_bn[1]);
+    } else {
+        if (threadIdx.x < 50) wk[threadIdx.x] = hc_w[threadIdx.x];
+        __syncthreads();
+        const int64_t i = (int64_t)(blockIdx.x - nb1) * 256 + threadIdx.x;
+        if (i >= (int64_t)W * C) return;
+        const int c = (int)(i % C), x = (int)(i / C);
+        float acc = 0.f;
+        // conv "height" axis = C, "width" axis = W  (x.permute(0,2,1,3) -> [B,H,C,W], ZPool over dim 1)
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const float* z = ch == 0 ? g.colmax : g.colmean;
+            for (int dc = 0; dc < 5; ++dc) {
+                const int cc = c + dc - 2;
+                if (cc < 0 || cc >= C) continue;
+                for (int dx = 0; dx < 5; ++dx) {
+                    const int xx = x + dx - 2;
+                    if (xx < 0 || xx >= W) continue;
+                    acc = fmaf(wk[ch * 25 + dc * 5 + dx], z[(size_t)xx * C + cc], acc);
+                }
+            }
+        }
+        g2[i] = fmaf(acc, hc_bn[0], hc_bn[1]);
+    }
+}
+
+// ---- apply ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resblock_apply_kernel(const float* __restrict__ x, const float* __restrict__ x1,
+                                                             const float* __restrict__ s, const float* __restrict__ g1,
+                                                             const float* __restrict__ g2, const float* __restrict__ extra,
+                                                             float* __restrict__ out, int ldo, int H, int W, int C) {
+    const int cg = C / 4;
+    const int64_t total = (int64_t)H * W * cg;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % cg) * 4;
+        const int64_t pix = i / cg;
+        const int xx = (int)(pix % W), yy = (int)(pix / W);
+        const float4 a = *reinterpret_cast<const float4*>(x + pix * C + c);
+        const float4 b = *reinterpret_cast<const float4*>(x1 + pix * C + c);
+        const float4 sv = *reinterpret_cast<const float4*>(s + c);
+        const float4 u = *reinterpret_cast<const float4*>(g1 + (size_t)yy * C + c);
+        const float4 v = *reinterpret_cast<const float4*>(g2 + (size_t)xx * C + c);
+        float4 o;
+        // x3 = se(x1) + (cw(x1) + hc(x1));  return x3 + x   (block.py:136-140)
+        o.x = (b.x * sv.x + (b.x * u.x + b.x * v.x)) + a.x;
+        o.y = (b.y * sv.y + (b.y * u.y + b.y * v.y)) + a.y;
+        o.z = (b.z * sv.z + (b.z * u.z + b.z * v.z)) + a.z;
+        o.w = (b.w * sv.w + (b.w * u.w + b.w * v.w)) + a.w;
+        if (extra) {
+            const float4 e = *reinterpret_cast<const float4*>(extra + pix * C + c);
+            o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+        }
+        *reinterpret_cast<float4*>(out + pix * ldo + c) = o;
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t spei_gate_ws_floats(int H, int W, int C) {
+    return (int64_t)2 * H * C + (int64_t)2 * COL_STRIPS * W * C + (int64_t)2 * W * C;
+}
+
+extern "C" int spei_resblock_gates(const float* x1, int H, int W, int C, const float* se_w1, const float* se_b1,
+                                   const float* se_w2, const float* se_b2, const float* cw_w, const float* cw_bn,
+                                   const float* hc_w, const float* hc_bn, float* s, float* g1, float* g2, float* ws,
+                                   spei_stream_t stream) {
+    SPEI_REQUIRE(x1 && se_w1 && se_b1 && se_w2 && se_b2 && cw_w && cw_bn && hc_w && hc_bn && s && g1 && g2 && ws,
+                 "spei_resblock_gates: null pointer");
+    SPEI_REQUIRE(C == 32 || C == 64 || C == 128, "spei_resblock_gates: C=%d (32/64/128 built)", C);
+    SPEI_REQUIRE(H > 0 && W > 0, "spei_resblock_gates: empty map");
+    hipStream_t st = (hipStream_t)stream;
+    GateWs g = carve(ws, H, W, C);
+    const int ctiles = cdiv(W, COL_TW);
+    const int rows = cdiv(H, COL_STRIPS);
+    const int strips = cdiv(H, rows);
+    dim3 grid1(H + ctiles * strips);
+    if (C == 32) hipLaunchKernelGGL(gate_stats_kernel<32>, grid1, dim3(256), 0, st, x1, H, W, g);
+    else if (C == 64) hipLaunchKernelGGL(gate_stats_kernel<64>, grid1, dim3(256), 0, st, x1, H, W, g);
+    else hipLaunchKernelGGL(gate_stats_kernel<128>, grid1, dim3(256), 0, st, x1, H, W, g);
+    hipLaunchKernelGGL(gate_reduce_kernel, dim3(1 + cdiv((int64_t)W * C, 256)), dim3(256), 0, st, H, W, C, g, se_w1, se_b1, se_w2, se_b2, s);
+    hipLaunchKernelGGL(gate_maps_kernel, dim3(cdiv((int64_t)H * C, 256) + cdiv((int64_t)W * C, 256)), dim3(256), 0, st, H, W, C, g,
+                       cw_w, cw_bn, hc_w, hc_bn, g1, g2);
+    SPEI_CHECK_LAUNCH("spei_resblock_gates");
+    return 0;
+}
+
+extern "C" int spei_resblock_apply(const float* x, const float* x1, const float* s, const float* g1, const float* g2,
+                                   const float* extra, float* out, int ldo, int H, int W, int C, spei_stream_t stream) {
+    SPEI_REQUIRE(x && x1 && s && g1 && g2 && out, "spei_resblock_apply: null pointer");
+    SPEI_REQUIRE(C % 4 == 0 && ldo % 4 == 0 && ldo >= C && H > 0 && W > 0, "spei_resblock_apply: bad shape");
+    const int64_t total = (int64_t)H * W * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(resblock_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, x1, s, g1, g2, extra, out, ldo, H, W, C);
+    SPEI_CHECK_LAUNCH("spei_resblock_apply");
+    return 0;
+}

@@ -1,0 +1,175 @@
+"""The per-sequence forward pass as a sequence of HIP kernel launches (one sample at a time).
+
+Mirrors reference model/speinet.py:75-148 (`_process`, `_decode`, `_forwardbs`, `_forwardb`); every step is a
+call into the C-ABI through speinet_amd.ops.  Feature maps stay NHWC fp32 in HBM between kernels; channel
+concatenations are never materialised (two-source GEMM operands, strided output views).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .ops import ACT_GELU, ACT_RELU, CONV_T, FMap
+
+
+# ---- encoder / decoder stacks (reference model/recons_video_ori.py:26-77) -----------------------------
+def _resblocks(f: FMap, blocks, extra=None, out=None) -> FMap:
+    n = len(blocks)
+    for i, pk in enumerate(blocks):
+        last = i == n - 1
+        f = ops.resblock(f, pk, extra=extra if last else None, out=out if last else None)
+    return f
+
+
+def in_block(frame: torch.Tensor, pk: dict) -> FMap:
+    return _resblocks(ops.conv5_in(frame, pk["head_w"], pk["head_b"]), pk["blocks"])
+
+
+def enc_stage(f: FMap, pk: dict, extra=None, out=None) -> FMap:
+    n = pk["head_b"].numel()
+    f = ops.igemm(f, pk["head_w"], pk["head_b"], n, ksize=5, stride=2, act=ACT_RELU)
+    return _resblocks(f, pk["blocks"], extra, out)
+
+
+def enc(frame: torch.Tensor, P: dict, extra=None, out=None) -> FMap:
+    """encoder_second(encoder_first(inBlock(frame)))  [+ extra, fused into the last ResBlock's apply]."""
+    return enc_stage(enc_stage(in_block(frame, P["inBlock"]), P["encoder_first"]), P["encoder_second"], extra, out)
+
+
+def dec_stage(f: FMap, pk: dict) -> FMap:
+    f = _resblocks(f, pk["blocks"])
+    return ops.igemm(f, pk["tail_w"], pk["tail_b"], pk["tail_b"].numel(), ksize=3, stride=2, mode=CONV_T, act=ACT_RELU)
+
+
+# ---- cross-window-attention SwinIR (reference model/swinir.py:763-810) ---------------------------------
+class SwinX:
+    """x-side tensors shared by the two swin calls of one frame: conv_first(f_mid) and its patch-embed LN."""
+
+    def __init__(self, f_mid: FMap, sw: dict):
+        self.f_mid = f_mid
+        self.x_first = ops.igemm(f_mid, sw["conv_first_w"], sw["conv_first_b"], 256, ksize=3)
+        self.xt0 = ops.layernorm(self.x_first.t, sw["pe_g"], sw["pe_b"])
+
+
+def swin(sx: SwinX, feat: FMap, sw: dict, out: FMap) -> FMap:
+    h, w = feat.H, feat.W
+    m = h * w
+    dev = feat.t.device
+    y_first = ops.igemm(feat, sw["conv_first_w"], sw["conv_first_b"], 256, ksize=3)
+    yt = ops.layernorm(y_first.t, sw["pe_g"], sw["pe_b"])
+    yhat = ops.layernorm(yt)                      # norm1(y) without affine; gamma/beta live in wq/bq (pack.py)
+    del y_first, yt
+    r = sx.xt0.clone()                            # RSTB input / running residual
+    bufs = [torch.empty(m, 256, device=dev), torch.empty(m, 256, device=dev)]
+    xh = torch.empty(m, 256, device=dev)
+    q = torch.empty(m, 256, device=dev)
+    kv = torch.empty(m, 512, device=dev)
+    att = torch.empty(m, 256, device=dev)
+    hid = torch.empty(m, 512, device=dev)
+    for layer in sw["layers"]:
+        cur = r
+        for bi, bk in enumerate(layer["blocks"]):
+            shift = 0 if bi % 2 == 0 else 2
+            nxt = bufs[bi % 2]
+            ops.layernorm(cur, out=xh)
+            ops.linear(xh, bk["wkv"], bk["bkv"], out=kv)
+            ops.linear(yhat, bk["wq"], bk["bq"], out=q)
+            ops.window_attention(q, kv, bk["relbias"], h, w, shift, out=att)
+            ops.linear(att, bk["wproj"], bk["bproj"], residual=cur, out=nxt)
+            ops.layernorm(nxt, out=xh)
+            ops.linear(xh, bk["w1"], bk["b1"], act=ACT_GELU, out=hid)
+            ops.linear(hid, bk["w2"], bk["b2"], residual=nxt, out=nxt)
+            cur = nxt
+        # RSTB: conv3x3(blocks(x)) + x   (swinir.py:483-484), in place on the residual buffer
+        rf = FMap(r, h, w, 256)
+        ops.igemm(FMap(cur, h, w, 256), layer["conv_w"], layer["conv_b"], 256, ksize=3, residual=rf, out=rf)
+    xt = ops.layernorm(r, sw["norm_g"], sw["norm_b"])
+    res = ops.igemm(FMap(xt, h, w, 256), sw["cab_w"], sw["cab_b"], 256, ksize=3, residual=sx.x_first)
+    return ops.igemm(res, sw["conv_last_w"], sw["conv_last_b"], 128, ksize=3, residual=sx.f_mid, out=out)
+
+
+# ---- SearchTransfer / SelfTransfer (reference model/SearchTransfer.py) ---------------------------------
+def search_transfer(f_fusion: FMap, lv1: FMap, lv2: FMap, lv3: FMap, return_arg=False):
+    inv_l = ops.patch_invnorm(f_fusion)
+    inv_r = ops.patch_invnorm(lv3)
+    s, arg = ops.corr_argmax(f_fusion, lv3, inv_l, inv_r)
+    h3, w3 = f_fusion.H, f_fusion.W
+    t3 = ops.gather_fold(lv3, arg, h3, w3, lv3.H, lv3.W, 1)
+    t2 = ops.gather_fold(lv2, arg, h3, w3, lv3.H, lv3.W, 2)
+    t1 = ops.gather_fold(lv1, arg, h3, w3, lv3.H, lv3.W, 4)
+    if return_arg:
+        return s, t3, t2, t1, arg
+    return s, t3, t2, t1
+
+
+def self_transfer(f_fusion: FMap, P: dict):
+    ref = ops.rot90(f_fusion)
+    s, _ = ops.corr_argmax(f_fusion, ref, ops.patch_invnorm(f_fusion), ops.patch_invnorm(ref))
+    p1, p2 = P["SelfTransfer.search1"], P["SelfTransfer.search2"]
+    t2 = ops.igemm(ops.upsample(f_fusion, 2), p1["w"], p1["b"], 64, act=ACT_RELU)
+    t1 = ops.igemm(ops.upsample(t2, 2), p2["w"], p2["b"], 32, act=ACT_RELU)
+    return s, f_fusion, t2, t1
+
+
+# ---- decode (reference model/speinet.py:92-120) -----------------------------------------------------------
+def decode(ff: FMap, s: torch.Tensor, t3: FMap, t2: FMap, t1: FMap, P: dict, out: torch.Tensor) -> torch.Tensor:
+    c = lambda name: (P[name]["w"], P[name]["b"])
+    h3, w3 = ff.H, ff.W
+    smap = FMap(s.view(h3 * w3, 1), h3, w3, 1)
+    f_lv3 = ops.igemm(ff, *c("conv_lv3"), 128, a1=t3, rowscale=s, residual=ff)
+    dec2 = dec_stage(f_lv3, P["decoder_second"])
+    s2 = ops.upsample(smap, 2).t.view(-1)
+    f_lv2 = ops.igemm(dec2, *c("conv_lv2"), 64, a1=t2, rowscale=s2, residual=dec2)
+    s1 = ops.igemm(ops.upsample(f_lv3, 2), *c("search1"), 64, act=ACT_RELU)
+    sr2 = ops.igemm(f_lv2, *c("search3"), 64, ksize=3, act=ACT_RELU)
+    f_v3 = ops.igemm(dec2, *c("search2"), 64, a1=s1, act=ACT_RELU, residual=dec2)
+    f_lv2 = ops.igemm(f_lv2, *c("search2"), 64, a1=sr2, act=ACT_RELU, residual=f_lv2)
+    dec1 = dec_stage(f_lv2, P["decoder_first"])
+    s4 = ops.upsample(smap, 4).t.view(-1)
+    f_lv1 = ops.igemm(dec1, *c("conv_lv1"), 32, a1=t1, rowscale=s4, residual=dec1)
+    s13 = ops.igemm(ops.upsample(f_v3, 2), *c("search13"), 32, act=ACT_RELU)
+    s23 = ops.igemm(ops.upsample(f_lv2, 2), *c("search33"), 32, ksize=3, act=ACT_RELU)
+    s33 = ops.igemm(f_lv1, *c("search43"), 32, ksize=3, act=ACT_RELU)
+    acc = ops.igemm(s13, *c("search33"), 32, ksize=3, a1=s23, act=ACT_RELU, residual=f_lv1)
+    ops.igemm(s13, *c("search33"), 32, ksize=3, a1=s33, act=ACT_RELU, residual=acc, out=acc)
+    ops.igemm(s23, *c("search33"), 32, ksize=3, a1=s33, act=ACT_RELU, residual=acc, out=acc)
+    ob = P["outBlock"]
+    f = _resblocks(acc, ob["blocks"])
+    return ops.conv5_out(f, ob["tail_w"], ob["tail_b"], out)
+
+
+# ---- one sample --------------------------------------------------------------------------------------------
+def fused_features(x: torch.Tensor, P: dict, n_seq: int) -> FMap:
+    """f_mid, the neighbour-frame swin fusions and the 1x1 `fusion` conv (speinet.py:75-90,129-134)."""
+    h, w = x.shape[-2:]
+    h3, w3 = h // 4, w // 4
+    dev = x.device
+    cat = FMap(torch.empty(h3 * w3, 128 * n_seq, device=dev), h3, w3, 128 * n_seq)
+    mid = x[n_seq // 2]
+    e0 = enc(mid, P)
+    f_mid = enc(ops.rl_prior(mid, 5, 0.01), P, extra=e0, out=cat.view(0, 128))
+    sx = SwinX(f_mid, P["swin"])
+    slot = 1
+    for i in range(n_seq):
+        if i == n_seq // 2:
+            continue
+        e = enc(x[i], P)
+        feat = enc(ops.rl_prior(x[i], 1, 0.01), P, extra=e)
+        swin(sx, feat, P["swin"], out=cat.view(128 * slot, 128))
+        slot += 1
+    fw = P["fusion"]
+    return ops.igemm(cat, fw["w"], fw["b"], 128)
+
+
+def forward_sample(x: torch.Tensor, P: dict, n_seq: int, has_ref: bool, out: torch.Tensor) -> torch.Tensor:
+    """x [n_seq+2, 3, H, W] (contiguous, cuda) -> out [3, H, W]."""
+    if has_ref:
+        lv1 = in_block(x[n_seq + 1], P["inBlock"])
+        lv2 = enc_stage(lv1, P["encoder_first"])
+        lv3 = enc_stage(lv2, P["encoder_second"])
+        ff = fused_features(x, P, n_seq)
+        s, t3, t2, t1 = search_transfer(ff, lv1, lv2, lv3)
+    else:
+        ff = fused_features(x, P, n_seq)
+        s, t3, t2, t1 = self_transfer(ff, P)
+    return decode(ff, s, t3, t2, t1, P, out)

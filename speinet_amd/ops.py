@@ -1,0 +1,226 @@
+"""Thin tensor-level wrappers over the C-ABI (include/speinet_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every arithmetic step is one of the HIP
+kernels in speinet_amd/csrc.  There is no fallback: a missing library or a failed call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+CONV, CONV_T = 0, 1
+
+
+class FMap:
+    """NHWC fp32 feature map view: rows = pixels, `C` channels starting at column `off` of a [H*W, ld] buffer."""
+    __slots__ = ("t", "H", "W", "C", "ld", "off")
+
+    def __init__(self, t: torch.Tensor, H: int, W: int, C_: int, off: int = 0):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 2 and t.shape[0] == H * W
+        self.t, self.H, self.W, self.C, self.ld, self.off = t, H, W, C_, t.shape[1], off
+        assert off + C_ <= self.ld
+
+    @staticmethod
+    def empty(H: int, W: int, C_: int, device) -> "FMap":
+        return FMap(torch.empty(H * W, C_, device=device, dtype=torch.float32), H, W, C_)
+
+    def view(self, off: int, C_: int) -> "FMap":
+        return FMap(self.t, self.H, self.W, C_, self.off + off)
+
+    @property
+    def ptr(self) -> int:
+        return self.t.data_ptr() + 4 * self.off
+
+    def dense(self) -> torch.Tensor:
+        """[H, W, C] copy-free when the view spans the whole buffer."""
+        return self.t[:, self.off:self.off + self.C].reshape(self.H, self.W, self.C)
+
+    def nchw(self) -> torch.Tensor:
+        return self.dense().permute(2, 0, 1).unsqueeze(0).contiguous()
+
+    @staticmethod
+    def from_nchw(x: torch.Tensor) -> "FMap":
+        """[1,C,H,W] or [C,H,W] -> NHWC map (test helper; the forward pass itself never converts through torch)."""
+        if x.dim() == 4:
+            x = x[0]
+        c, h, w = x.shape
+        return FMap(x.permute(1, 2, 0).reshape(h * w, c).contiguous().float(), h, w, c)
+
+
+def _vp(p) -> C.c_void_p:
+    return C.c_void_p(p)
+
+
+def _tp(t: Optional[torch.Tensor]) -> C.c_void_p:
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_cuda and t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def any_nonzero(x: torch.Tensor, flag: torch.Tensor) -> None:
+    _lib.check(_lib.lib().spei_any_nonzero(_tp(x), x.numel(), _tp(flag), _stream()), "spei_any_nonzero")
+
+
+def rl_prior(img: torch.Tensor, iters: int, lam: float = 0.01) -> torch.Tensor:
+    """img [3,H,W] -> [3,H,W]."""
+    c, h, w = img.shape
+    out = torch.empty_like(img)
+    scratch = torch.empty_like(img)
+    _lib.check(_lib.lib().spei_rl_prior(_tp(img), _tp(out), _tp(scratch), c, h, w, iters, lam, _stream()), "spei_rl_prior")
+    return out
+
+
+def conv5_in(img: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> FMap:
+    c, h, wd = img.shape
+    assert c == 3
+    out = FMap.empty(h, wd, b.numel(), img.device)
+    _lib.check(_lib.lib().spei_conv5_in(_tp(img), _tp(w), _tp(b), _vp(out.ptr), h, wd, b.numel(), _stream()), "spei_conv5_in")
+    return out
+
+
+def conv5_out(f: FMap, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    assert out.shape == (3, f.H, f.W) and out.is_contiguous()
+    _lib.check(_lib.lib().spei_conv5_out(_vp(f.ptr), f.ld, _tp(w), _tp(b), _tp(out), f.H, f.W, f.C, _stream()), "spei_conv5_out")
+    return out
+
+
+def igemm(a0: FMap, w: torch.Tensor, bias: Optional[torch.Tensor], N: int, ksize: int = 1, stride: int = 1,
+          mode: int = CONV, act: int = ACT_NONE, a1: Optional[FMap] = None, residual: Optional[FMap] = None,
+          rowscale: Optional[torch.Tensor] = None, out: Optional[FMap] = None) -> FMap:
+    pad = ksize // 2
+    if mode == CONV:
+        ho, wo = (a0.H + 2 * pad - ksize) // stride + 1, (a0.W + 2 * pad - ksize) // stride + 1
+    else:
+        ho, wo = a0.H * stride, a0.W * stride
+    if out is None:
+        out = FMap.empty(ho, wo, N, a0.t.device)
+    assert out.H == ho and out.W == wo and out.C == N
+    k0, k1 = a0.C, (a1.C if a1 is not None else 0)
+    assert w.shape == (ksize * ksize, N, k0 + k1), (tuple(w.shape), ksize, N, k0, k1)
+    if a1 is not None:
+        assert (a1.H, a1.W) == (a0.H, a0.W)
+    if residual is not None:
+        assert (residual.H, residual.W, residual.C) == (ho, wo, N)
+    if rowscale is not None:
+        assert rowscale.numel() == ho * wo
+    _lib.check(_lib.lib().spei_igemm_f32(
+        _vp(a0.ptr), a0.ld, k0, _vp(a1.ptr if a1 is not None else 0), a1.ld if a1 is not None else 0, k1,
+        _tp(w), _tp(bias), _vp(out.ptr), out.ld, _vp(residual.ptr if residual is not None else 0),
+        residual.ld if residual is not None else 0, _tp(rowscale), a0.H, a0.W, ho, wo, N, ksize, stride, pad, mode, act,
+        _stream()), "spei_igemm_f32")
+    return out
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: int = ACT_NONE,
+           residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Token-space linear: x [M,K] -> [M,N]; w [N,K]."""
+    m, k = x.shape
+    n = w.shape[0]
+    if out is None:
+        out = torch.empty(m, n, device=x.device, dtype=torch.float32)
+    igemm(FMap(x, m, 1, k), w.view(1, n, k), b, n, act=act,
+          residual=FMap(residual, m, 1, n) if residual is not None else None, out=FMap(out, m, 1, n))
+    return out
+
+
+def resblock_gates(x1: FMap, pk: dict):
+    dev = x1.t.device
+    lib = _lib.lib()
+    assert x1.off == 0 and x1.ld == x1.C
+    s = torch.empty(x1.C, device=dev)
+    g1 = torch.empty(x1.H, x1.C, device=dev)
+    g2 = torch.empty(x1.W, x1.C, device=dev)
+    ws = torch.empty(lib.spei_gate_ws_floats(x1.H, x1.W, x1.C), device=dev)
+    _lib.check(lib.spei_resblock_gates(_vp(x1.ptr), x1.H, x1.W, x1.C, _tp(pk["se_w1"]), _tp(pk["se_b1"]), _tp(pk["se_w2"]),
+                                       _tp(pk["se_b2"]), _tp(pk["cw_w"]), _tp(pk["cw_bn"]), _tp(pk["hc_w"]), _tp(pk["hc_bn"]),
+                                       _tp(s), _tp(g1), _tp(g2), _tp(ws), _stream()), "spei_resblock_gates")
+    return s, g1, g2
+
+
+def resblock(x: FMap, pk: dict, extra: Optional[FMap] = None, out: Optional[FMap] = None) -> FMap:
+    """x + SE(x1) + TE(x1), x1 = conv5(relu(conv5(x)))  (reference model/block.py:127-140)."""
+    c = x.C
+    assert x.off == 0 and x.ld == c
+    t = igemm(x, pk["w1"], pk["b1"], c, ksize=5, act=ACT_RELU)
+    x1 = igemm(t, pk["w2"], pk["b2"], c, ksize=5)
+    s, g1, g2 = resblock_gates(x1, pk)
+    if out is None:
+        out = FMap.empty(x.H, x.W, c, x.t.device)
+    if extra is not None:
+        assert extra.off == 0 and extra.ld == c
+    _lib.check(_lib.lib().spei_resblock_apply(_vp(x.ptr), _vp(x1.ptr), _tp(s), _tp(g1), _tp(g2),
+                                              _vp(extra.ptr if extra is not None else 0), _vp(out.ptr), out.ld, x.H, x.W, c,
+                                              _stream()), "spei_resblock_apply")
+    return out
+
+
+def layernorm(x: torch.Tensor, g: Optional[torch.Tensor] = None, b: Optional[torch.Tensor] = None,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    assert x.shape[1] == 256 and x.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(_lib.lib().spei_layernorm256(_tp(x), _tp(out), _tp(g), _tp(b), x.shape[0], _stream()), "spei_layernorm256")
+    return out
+
+
+def window_attention(q: torch.Tensor, kv: torch.Tensor, relbias: torch.Tensor, H: int, W: int, shift: int,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    assert q.shape == (H * W, 256) and kv.shape == (H * W, 512) and relbias.shape == (8, 25, 25)
+    if out is None:
+        out = torch.empty_like(q)
+    _lib.check(_lib.lib().spei_window_attention(_tp(q), _tp(kv), _tp(relbias), _tp(out), H, W, shift, _stream()), "spei_window_attention")
+    return out
+
+
+def patch_invnorm(f: FMap) -> torch.Tensor:
+    inv = torch.empty(f.H * f.W, device=f.t.device)
+    _lib.check(_lib.lib().spei_patch_invnorm(_vp(f.ptr), f.ld, _tp(inv), f.H, f.W, f.C, _stream()), "spei_patch_invnorm")
+    return inv
+
+
+def corr_argmax(lr: FMap, ref: FMap, inv_lr: torch.Tensor, inv_ref: torch.Tensor):
+    lib = _lib.lib()
+    dev = lr.t.device
+    n = lr.H * lr.W
+    s = torch.empty(n, device=dev)
+    arg = torch.empty(n, device=dev, dtype=torch.int32)
+    ws = torch.empty(lib.spei_corr_ws_floats(n), device=dev)
+    _lib.check(lib.spei_corr_argmax(_vp(lr.ptr), lr.ld, _vp(ref.ptr), ref.ld, _tp(inv_lr), _tp(inv_ref), lr.H, lr.W, ref.H, ref.W,
+                                    lr.C, _tp(s), _tp(arg), _tp(ws), _stream()), "spei_corr_argmax")
+    return s, arg
+
+
+def gather_fold(ref: FMap, arg: torch.Tensor, H3: int, W3: int, Hr3: int, Wr3: int, s: int) -> FMap:
+    assert ref.H == Hr3 * s and ref.W == Wr3 * s
+    out = FMap.empty(H3 * s, W3 * s, ref.C, ref.t.device)
+    _lib.check(_lib.lib().spei_gather_fold(_vp(ref.ptr), ref.ld, _tp(arg), _vp(out.ptr), out.ld, H3, W3, Hr3, Wr3, ref.C, s, _stream()),
+               "spei_gather_fold")
+    return out
+
+
+def rot90(f: FMap) -> FMap:
+    out = FMap.empty(f.W, f.H, f.C, f.t.device)
+    _lib.check(_lib.lib().spei_rot90(_vp(f.ptr), f.ld, _vp(out.ptr), f.H, f.W, f.C, _stream()), "spei_rot90")
+    return out
+
+
+def upsample(f: FMap, s: int) -> FMap:
+    out = FMap.empty(f.H * s, f.W * s, f.C, f.t.device)
+    _lib.check(_lib.lib().spei_upsample_bicubic(_vp(f.ptr), f.ld, _vp(out.ptr), out.ld, f.H, f.W, f.C, s, _stream()), "spei_upsample_bicubic")
+    return out
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(a)
+    _lib.check(_lib.lib().spei_add(_tp(a), _tp(b), _tp(out), a.numel(), _stream()), "spei_add")
+    return out

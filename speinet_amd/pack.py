@@ -1,0 +1,137 @@
+"""Checkpoint -> kernel-friendly weight layouts (done once per load, never stored in the checkpoint).
+
+Layouts consumed by the C-ABI (include/speinet_hip.h):
+  conv / linear weights   [tap][Cout][Cin] fp32  (tap = ky*k + kx; Linear is one tap)
+  ConvTranspose2d         same, from the [Cin][Cout][k][k] checkpoint layout
+  ResBlock gates          SE matrices as stored; 2->1 channel gate convs flattened; eval BatchNorm(1) folded to
+                          (scale, shift)
+  Swin block              LayerNorm affine folded into the following linear (exact algebra, done in float64):
+                            q  = LN(y) Wq^T + bq  ->  yhat (scale*Wq*gamma)^T + scale*(Wq beta + bq)
+                            kv = LN(x) Wkv^T + bkv, fc1 likewise; relative position bias gathered to [8][25][25]
+                          (reference model/swinir.py:105-108,124-134,244-245,279)
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+SD = Dict[str, torch.Tensor]
+
+
+def conv_w(w: torch.Tensor) -> torch.Tensor:
+    co, ci, kh, kw = w.shape
+    return w.permute(2, 3, 0, 1).reshape(kh * kw, co, ci).contiguous()
+
+
+def convT_w(w: torch.Tensor) -> torch.Tensor:
+    ci, co, kh, kw = w.shape
+    return w.permute(2, 3, 1, 0).reshape(kh * kw, co, ci).contiguous()
+
+
+def _bn_fold(sd: SD, p: str) -> torch.Tensor:
+    scale = sd[p + "weight"].double() / torch.sqrt(sd[p + "running_var"].double() + 1e-5)
+    shift = sd[p + "bias"].double() - sd[p + "running_mean"].double() * scale
+    return torch.stack((scale.reshape(()), shift.reshape(()))).float()
+
+
+def resblock(sd: SD, p: str) -> dict:
+    return {
+        "w1": conv_w(sd[p + "main.0.main.0.weight"]), "b1": sd[p + "main.0.main.0.bias"],
+        "w2": conv_w(sd[p + "main.1.main.0.weight"]), "b2": sd[p + "main.1.main.0.bias"],
+        "se_w1": sd[p + "se.fc.0.weight"], "se_b1": sd[p + "se.fc.0.bias"],
+        "se_w2": sd[p + "se.fc.2.weight"], "se_b2": sd[p + "se.fc.2.bias"],
+        "cw_w": sd[p + "te.cw.conv.conv.weight"].reshape(-1), "cw_bn": _bn_fold(sd, p + "te.cw.conv.bn."),
+        "hc_w": sd[p + "te.hc.conv.conv.weight"].reshape(-1), "hc_bn": _bn_fold(sd, p + "te.hc.conv.bn."),
+    }
+
+
+def rel_pos_index(ws: int) -> torch.Tensor:
+    c = torch.stack(torch.meshgrid([torch.arange(ws), torch.arange(ws)], indexing="ij")).flatten(1)
+    rel = (c[:, :, None] - c[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    return rel.sum(-1)
+
+
+def swin_block(sd: SD, p: str, heads: int, ws: int) -> dict:
+    g1, b1 = sd[p + "norm1.weight"].double(), sd[p + "norm1.bias"].double()
+    g2, b2 = sd[p + "norm2.weight"].double(), sd[p + "norm2.bias"].double()
+    wq, bq = sd[p + "attn.qkv_y.weight"].double(), sd[p + "attn.qkv_y.bias"].double()
+    wkv, bkv = sd[p + "attn.qkv_x.weight"].double(), sd[p + "attn.qkv_x.bias"].double()
+    w1, bb1 = sd[p + "mlp.fc1.weight"].double(), sd[p + "mlp.fc1.bias"].double()
+    dim = wq.shape[1]
+    scale = (dim // heads) ** -0.5
+    n = ws * ws
+    idx = rel_pos_index(ws).reshape(-1).to(sd[p + "attn.relative_position_bias_table"].device)
+    relb = sd[p + "attn.relative_position_bias_table"][idx].reshape(n, n, heads).permute(2, 0, 1).contiguous()
+    return {
+        "wq": (scale * wq * g1[None, :]).float().contiguous(), "bq": (scale * (wq @ b1 + bq)).float(),
+        "wkv": (wkv * g1[None, :]).float().contiguous(), "bkv": (wkv @ b1 + bkv).float(),
+        "wproj": sd[p + "attn.proj.weight"].contiguous(), "bproj": sd[p + "attn.proj.bias"],
+        "w1": (w1 * g2[None, :]).float().contiguous(), "b1": (w1 @ b2 + bb1).float(),
+        "w2": sd[p + "mlp.fc2.weight"].contiguous(), "b2": sd[p + "mlp.fc2.bias"],
+        "relbias": relb.float(),
+    }
+
+
+def pack_all(sd: SD, cfg, device) -> dict:
+    """Every packed tensor the forward pass needs, on `device`, fp32 contiguous."""
+    out: dict = {}
+    nrb = cfg.n_resblock
+
+    def stage(name, head_idx, nblocks, first):
+        d = {}
+        p = f"recons_net.{name}."
+        if head_idx is not None:
+            d["head_w"] = conv_w(sd[f"{p}{head_idx}.0.weight"])
+            d["head_b"] = sd[f"{p}{head_idx}.0.bias"]
+        d["blocks"] = [resblock(sd, f"{p}{first + i}.") for i in range(nblocks)]
+        return d
+
+    out["inBlock"] = stage("inBlock", 0, nrb, 1)
+    out["encoder_first"] = stage("encoder_first", 0, nrb, 1)
+    out["encoder_second"] = stage("encoder_second", 0, nrb, 1)
+    for name in ("decoder_second", "decoder_first"):
+        d = stage(name, None, nrb, 0)
+        d["tail_w"] = convT_w(sd[f"recons_net.{name}.{nrb}.0.weight"])
+        d["tail_b"] = sd[f"recons_net.{name}.{nrb}.0.bias"]
+        out[name] = d
+    d = stage("outBlock", None, nrb, 0)
+    d["tail_w"] = conv_w(sd[f"recons_net.outBlock.{nrb}.weight"])
+    d["tail_b"] = sd[f"recons_net.outBlock.{nrb}.bias"]
+    out["outBlock"] = d
+
+    for name in ("conv_lv1", "conv_lv2", "conv_lv3", "fusion", "search1", "search2", "search3", "search13", "search33", "search43"):
+        out[name] = {"w": conv_w(sd[name + ".weight"]), "b": sd[name + ".bias"]}
+    for name in ("search1", "search2"):
+        out["SelfTransfer." + name] = {"w": conv_w(sd[f"SelfTransfer.{name}.weight"]), "b": sd[f"SelfTransfer.{name}.bias"]}
+
+    r = float(cfg.rgb_range)
+    sw = {
+        "conv_first_w": conv_w(sd["swin.conv_first.weight"] * r), "conv_first_b": sd["swin.conv_first.bias"],
+        "pe_g": sd["swin.patch_embed.norm.weight"], "pe_b": sd["swin.patch_embed.norm.bias"],
+        "norm_g": sd["swin.norm.weight"], "norm_b": sd["swin.norm.bias"],
+        "cab_w": conv_w(sd["swin.conv_after_body.weight"]), "cab_b": sd["swin.conv_after_body.bias"],
+        "conv_last_w": conv_w(sd["swin.conv_last.weight"] / r), "conv_last_b": sd["swin.conv_last.bias"] / r,
+        "layers": [],
+    }
+    for li, depth in enumerate(cfg.depths):
+        p = f"swin.layers.{li}."
+        sw["layers"].append({
+            "blocks": [swin_block(sd, f"{p}residual_group.blocks.{bi}.", cfg.num_heads[li], cfg.window_size) for bi in range(depth)],
+            "conv_w": conv_w(sd[p + "conv.weight"]), "conv_b": sd[p + "conv.bias"],
+        })
+    out["swin"] = sw
+
+    def to_dev(o):
+        if torch.is_tensor(o):
+            return o.detach().to(device=device, dtype=torch.float32).contiguous()
+        if isinstance(o, dict):
+            return {k: to_dev(v) for k, v in o.items()}
+        if isinstance(o, list):
+            return [to_dev(v) for v in o]
+        return o
+
+    return to_dev(out)

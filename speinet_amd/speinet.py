@@ -1,0 +1,264 @@
+"""Drop-in for the reference's ``model/speinet.py``: same class name, constructor, ``forward`` contract,
+``make_model(args)`` factory and 1020-entry ``state_dict`` layout — but ``forward``
+runs hand-written gfx950 kernels through the C-ABI in include/speinet_hip.h.
+
+The sub-modules below exist to hold parameters under the reference's names (reference
+model/recons_video_ori.py:16-84, model/block.py:8-140, model/swinir.py:64-149,163-213,421-484,620-761,
+model/SearchTransfer.py:6-11,53-57); none of their ``forward`` methods is ever called.  Weights are re-packed
+into kernel layouts on first use after every (re)load (speinet_amd/pack.py), never in the checkpoint.
+
+There is deliberately NO CPU path: a tensor that is not on a ROCm device, or a missing libspeinet_hip.so,
+raises.  The CPU restatement lives in oracle/ and is test infrastructure only.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import _lib, engine, ops, pack
+
+
+# ---------------------------------------------------------------------------------------------------------
+# parameter containers (names == reference names)
+# ---------------------------------------------------------------------------------------------------------
+class _BasicConv(nn.Module):
+    def __init__(self, cin, cout, k, relu):
+        super().__init__()
+        layers = [nn.Conv2d(cin, cout, k, padding=k // 2)]
+        if relu:
+            layers.append(nn.ReLU(inplace=True))
+        self.main = nn.Sequential(*layers)
+
+
+class _SE(nn.Module):
+    def __init__(self, c, reduction=4):
+        super().__init__()
+        mid = int(c / reduction)
+        self.fc = nn.Sequential(nn.Linear(c, mid), nn.ReLU(inplace=True), nn.Linear(mid, c), nn.Sigmoid())
+
+
+class _GateConv(nn.Module):
+    def __init__(self, k):
+        super().__init__()
+        self.conv = nn.Conv2d(2, 1, k, padding=(k - 1) // 2, bias=False)
+        self.bn = nn.BatchNorm2d(1, eps=1e-5, momentum=0.01, affine=True)
+
+
+class _Gate(nn.Module):
+    def __init__(self, k):
+        super().__init__()
+        self.conv = _GateConv(k)
+
+
+class _Triplet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.cw = _Gate(7)
+        self.hc = _Gate(5)
+
+
+class _ResBlock(nn.Module):
+    def __init__(self, c, k=5):
+        super().__init__()
+        self.main = nn.Sequential(_BasicConv(c, c, k, True), _BasicConv(c, c, k, False))
+        self.se = _SE(c, 4)
+        self.te = _Triplet()
+
+
+class _Recons(nn.Module):
+    def __init__(self, in_ch, out_ch, n_resblock, nf, k=5):
+        super().__init__()
+        rb = lambda c: [_ResBlock(c, k) for _ in range(n_resblock)]
+        head = lambda ci, co, s: nn.Sequential(nn.Conv2d(ci, co, k, stride=s, padding=k // 2), nn.ReLU(inplace=True))
+        tail = lambda ci, co: nn.Sequential(nn.ConvTranspose2d(ci, co, 3, stride=2, padding=1, output_padding=1), nn.ReLU(inplace=True))
+        self.inBlock = nn.Sequential(head(in_ch, nf, 1), *rb(nf))
+        self.encoder_first = nn.Sequential(head(nf, nf * 2, 2), *rb(nf * 2))
+        self.encoder_second = nn.Sequential(head(nf * 2, nf * 4, 2), *rb(nf * 4))
+        self.decoder_second = nn.Sequential(*rb(nf * 4), tail(nf * 4, nf * 2))
+        self.decoder_first = nn.Sequential(*rb(nf * 2), tail(nf * 2, nf))
+        self.outBlock = nn.Sequential(*rb(nf), nn.Conv2d(nf, out_ch, k, padding=k // 2))
+
+
+class _WindowAttention(nn.Module):
+    def __init__(self, dim, ws, heads):
+        super().__init__()
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * ws - 1) * (2 * ws - 1), heads))
+        self.register_buffer("relative_position_index", pack.rel_pos_index(ws))
+        self.qkv_x = nn.Linear(dim, dim * 2)
+        self.qkv_y = nn.Linear(dim, dim)
+        self.proj = nn.Linear(dim, dim)
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+def _shift_mask(h: int, w: int, ws: int, shift: int) -> torch.Tensor:
+    """calculate_mask (reference model/swinir.py:215-236) — kept only as the checkpoint buffer ``attn_mask``;
+    the kernel derives the mask from coordinates."""
+    def region(n):
+        r = torch.zeros(n, dtype=torch.long)
+        r[n - ws:n - shift] = 1
+        r[n - shift:] = 2
+        return r
+    reg = (3 * region(h)[:, None] + region(w)[None, :]).view(h // ws, ws, w // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws)
+    d = reg[:, None, :] - reg[:, :, None]
+    return torch.where(d != 0, torch.tensor(-100.0), torch.tensor(0.0))
+
+
+class _SwinBlock(nn.Module):
+    def __init__(self, dim, res, heads, ws, shift, mlp_ratio):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = _WindowAttention(dim, ws, heads)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+        self.register_buffer("attn_mask", _shift_mask(res, res, ws, shift) if shift > 0 else None)
+
+
+class _BasicLayer(nn.Module):
+    def __init__(self, dim, res, depth, heads, ws, mlp_ratio):
+        super().__init__()
+        self.blocks = nn.ModuleList([_SwinBlock(dim, res, heads, ws, 0 if i % 2 == 0 else ws // 2, mlp_ratio) for i in range(depth)])
+
+
+class _RSTB(nn.Module):
+    def __init__(self, dim, res, depth, heads, ws, mlp_ratio):
+        super().__init__()
+        self.residual_group = _BasicLayer(dim, res, depth, heads, ws, mlp_ratio)
+        self.conv = nn.Conv2d(dim, dim, 3, 1, 1)
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+
+
+class _SwinIR(nn.Module):
+    def __init__(self, in_chans, img_size, ws, depths, embed_dim, heads, mlp_ratio):
+        super().__init__()
+        self.conv_first = nn.Conv2d(in_chans, embed_dim, 3, 1, 1)
+        self.patch_embed = _PatchEmbed(embed_dim)
+        self.layers = nn.ModuleList([_RSTB(embed_dim, img_size, depths[i], heads[i], ws, mlp_ratio) for i in range(len(depths))])
+        self.norm = nn.LayerNorm(embed_dim)
+        self.conv_after_body = nn.Conv2d(embed_dim, embed_dim, 3, 1, 1)
+        self.conv_last = nn.Conv2d(embed_dim, in_chans, 3, 1, 1)
+
+
+class _Transfer(nn.Module):
+    def __init__(self, nf=32):
+        super().__init__()
+        self.search1 = nn.Conv2d(nf * 4, nf * 2, 1)
+        self.search2 = nn.Conv2d(nf * 2, nf, 1)
+
+
+def default_args() -> SimpleNamespace:
+    """The hyper-parameters of the reference's SPEINet template / inference presets
+    (option/template.py:3-21, inference_SPEINet.py:626-697)."""
+    return SimpleNamespace(n_colors=3, n_sequence=3, patch_size=200, n_feat=32, n_resblock=3, size_must_mode=4,
+                           window_size=5, depths=[6] * 6, embed_dim=256, num_heads=[8] * 6, mlp_ratio=2,
+                           resi_connection="1conv", rgb_range=1, n_GPUs=1, cpu=False)
+
+
+# ---------------------------------------------------------------------------------------------------------
+class SPEINet(nn.Module):
+    """Same signature as reference model/speinet.py:29-31; ``forward`` as :150-168."""
+
+    def __init__(self, in_channels=3, n_sequence=3, out_channels=3, n_resblock=3, n_feat=32,
+                 load_flow_net=False, load_recons_net=False, flow_pretrain_fn='', recons_pretrain_fn='',
+                 is_mask_filter=False, device='cuda', args=None):
+        super().__init__()
+        if args is None:
+            args = default_args()
+        if in_channels != 3 or out_channels != 3 or n_feat != 32 or n_sequence != 3:
+            raise ValueError("speinet_amd builds the published configuration: 3 colours, n_feat=32, n_sequence=3")
+        if args.window_size != 5 or args.embed_dim != 256 or any(h != 8 for h in args.num_heads):
+            raise ValueError("speinet_amd kernels are built for window 5, embed_dim 256, 8 heads")
+        if getattr(args, "resi_connection", "1conv") != "1conv":
+            raise ValueError("only resi_connection='1conv' is built")
+        self.n_sequence = n_sequence
+        self.device = device
+        self.is_mask_filter = is_mask_filter
+        self.cfg = SimpleNamespace(n_sequence=n_sequence, n_feat=n_feat, n_resblock=n_resblock, window_size=args.window_size,
+                                   embed_dim=args.embed_dim, depths=tuple(args.depths), num_heads=tuple(args.num_heads),
+                                   mlp_ratio=args.mlp_ratio, rgb_range=float(args.rgb_range), patch_size=args.patch_size)
+        self.swin = _SwinIR(n_feat * 4, args.patch_size // 4, args.window_size, list(args.depths), args.embed_dim,
+                            list(args.num_heads), args.mlp_ratio)
+        self.recons_net = _Recons(in_channels, out_channels, n_resblock, n_feat)
+        self.SearchTransfer = _Transfer(n_feat)
+        self.SelfTransfer = _Transfer(n_feat)
+        nf = n_feat
+        self.conv_lv1 = nn.Conv2d(nf * 2, nf, 1)
+        self.conv_lv2 = nn.Conv2d(nf * 4, nf * 2, 1)
+        self.conv_lv3 = nn.Conv2d(nf * 8, nf * 4, 1)
+        self.fusion = nn.Conv2d(nf * 4 * n_sequence, nf * 4, 1)
+        self.connect = nn.Conv2d(nf * 8, nf * 4, 1)
+        self.search3 = nn.Conv2d(nf * 2, nf * 2, 3, 1, 1)
+        self.search2 = nn.Conv2d(nf * 4, nf * 2, 1)
+        self.search1 = nn.Conv2d(nf * 4, nf * 2, 1)
+        self.search43 = nn.Conv2d(nf, nf, 3, 1, 1)
+        self.search33 = nn.Conv2d(nf * 2, nf, 3, 1, 1)
+        self.search23 = nn.Conv2d(nf * 4, nf, 1)
+        self.search13 = nn.Conv2d(nf * 2, nf, 1)
+        if load_recons_net:
+            self.recons_net.load_state_dict(torch.load(recons_pretrain_fn, weights_only=True))
+        self._packed = None
+        self._packed_key = None
+
+    # ---- weight packing cache -----------------------------------------------------------------------
+    def _pack(self, device):
+        key = (str(device), tuple(p._version for p in self.parameters()), tuple(b._version for b in self.buffers()),
+               tuple(p.data_ptr() for p in self.parameters()))
+        if self._packed is None or self._packed_key != key:
+            self._packed = pack.pack_all(self.state_dict(), self.cfg, device)
+            self._packed_key = key
+        return self._packed
+
+    def _route(self, x: torch.Tensor) -> list:
+        """`_forwardx` (reference :70-73): True where frame 3 is identically zero.  One device reduction per
+        sample, ONE host sync for the batch (the reference syncs twice through `.any()`)."""
+        b = x.shape[0]
+        flags = torch.empty(b, dtype=torch.int32, device=x.device)
+        for i in range(b):
+            ops.any_nonzero(x[i, 3], flags[i:i + 1])
+        return [v == 0 for v in flags.tolist()]
+
+    def forward(self, x: torch.Tensor, routing: Optional[Sequence[bool]] = None) -> torch.Tensor:
+        """x [B, n_sequence+2, 3, H, W] fp32 in [0,1] -> [B, 3, H, W] (unclamped).
+
+        ``routing`` (optional, beyond the reference signature): per-sample "frame 3 is all zero" decisions when the
+        caller already knows them (the harness zeroes the frame itself), which removes the host sync.
+        """
+        if x.dim() != 5 or x.shape[1] != self.n_sequence + 2 or x.shape[2] != 3:
+            raise ValueError(f"expected [B,{self.n_sequence + 2},3,H,W], got {tuple(x.shape)}")
+        h, w = x.shape[-2:]
+        if h % 20 or w % 20:
+            raise ValueError(f"H and W must be multiples of 20 (two stride-2 stages, then 5x5 windows); got {h}x{w}")
+        if not x.is_cuda:
+            raise RuntimeError("speinet_amd.SPEINet runs on MI355X only (HIP kernels); there is no CPU path")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise RuntimeError("speinet_amd: backward kernels are not built yet; use eval() under torch.no_grad()")
+        _lib.lib()
+        x = x.contiguous().float()
+        P = self._pack(x.device)
+        zero_ref = list(routing) if routing is not None else self._route(x)
+        out = torch.empty(x.shape[0], 3, h, w, device=x.device, dtype=torch.float32)
+        for b in range(x.shape[0]):
+            engine.forward_sample(x[b], P, self.n_sequence, not zero_ref[b], out[b])
+        return out
+
+
+def make_model(args):
+    """reference model/speinet.py:18-26."""
+    device = 'cpu' if getattr(args, "cpu", False) else 'cuda'
+    return SPEINet(in_channels=args.n_colors, n_sequence=args.n_sequence, out_channels=args.n_colors,
+                   n_resblock=args.n_resblock, n_feat=args.n_feat, load_recons_net=False, recons_pretrain_fn='',
+                   is_mask_filter=True, device=device, args=args)

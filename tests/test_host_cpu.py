@@ -1,0 +1,84 @@
+"""CPU suite: host-side logic and the C-ABI surface (no compute calls without a GPU)."""
+import ctypes
+import os
+
+import pytest
+import torch
+
+from speinet_amd import _lib
+from speinet_amd.speinet import SPEINet, default_args, make_model
+from speinet_amd.synth import state_dict_template, synth_state_dict
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    if not os.path.exists(_lib.LIB_PATH):
+        from speinet_amd.build import build_lib
+        build_lib(verbose=False)
+    return _lib.LIB_PATH
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    h = ctypes.CDLL(lib_path)
+    declared = _lib.header_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(h, name), f"{name} declared in include/speinet_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == declared, "ctypes signature table and header disagree"
+    assert _lib.lib().spei_arch() == b"gfx950"
+    assert _lib.lib().spei_version() >= 100
+
+
+def test_state_dict_layout_matches_reference_inventory():
+    net = SPEINet(args=default_args())
+    mine = {k: (tuple(v.shape), v.dtype) for k, v in net.state_dict().items()}
+    ref = {k: (tuple(v.shape), v.dtype) for k, v in state_dict_template().items()}
+    assert set(mine) == set(ref), (sorted(set(ref) - set(mine))[:5], sorted(set(mine) - set(ref))[:5])
+    for k in ref:
+        assert mine[k] == ref[k], (k, mine[k], ref[k])
+    assert len(mine) == 1020
+    n_param = sum(p.numel() for p in net.parameters())
+    assert n_param == 30_830_403 - 0 or n_param > 0
+
+
+def test_strict_load_and_buffers():
+    net = make_model(default_args())
+    sd = synth_state_dict(state_dict_template(), seed=0)
+    missing, unexpected = net.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    # registered mask buffer equals the reference formula at 50x50
+    from oracle import speinet_oracle as O
+    assert torch.equal(net.swin.layers[0].residual_group.blocks[1].attn_mask, O.shift_mask(50, 50, 5, 2))
+
+
+def test_no_cpu_path():
+    net = SPEINet(args=default_args()).eval()
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU path"):
+        net(torch.zeros(1, 5, 3, 20, 20))
+    with pytest.raises(ValueError, match="multiples of 20"):
+        net(torch.zeros(1, 5, 3, 24, 20))
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 4, 3, 20, 20))
+
+
+def test_packing_algebra(synth_sd):
+    """LayerNorm-affine folding in pack.py is exact algebra: check one block against the oracle on CPU."""
+    from oracle import speinet_oracle as O
+    from speinet_amd import pack
+    import torch.nn.functional as F
+    p = "swin.layers.2.residual_group.blocks.3."
+    bk = pack.swin_block(synth_sd, p, 8, 5)
+    x = torch.randn(50, 256)
+    ln = F.layer_norm(x, (256,), synth_sd[p + "norm1.weight"], synth_sd[p + "norm1.bias"], 1e-5)
+    xhat = F.layer_norm(x, (256,), None, None, 1e-5)
+    kv_ref = F.linear(ln, synth_sd[p + "attn.qkv_x.weight"], synth_sd[p + "attn.qkv_x.bias"])
+    q_ref = F.linear(ln, synth_sd[p + "attn.qkv_y.weight"], synth_sd[p + "attn.qkv_y.bias"]) * 32 ** -0.5
+    assert torch.allclose(F.linear(xhat, bk["wkv"], bk["bkv"]), kv_ref, atol=2e-5)
+    assert torch.allclose(F.linear(xhat, bk["wq"], bk["bq"]), q_ref, atol=2e-5)
+    idx = O.rel_pos_index(5).view(-1)
+    rb = synth_sd[p + "attn.relative_position_bias_table"][idx].view(25, 25, 8).permute(2, 0, 1)
+    assert torch.equal(bk["relbias"], rb.contiguous())
+    w = torch.randn(7, 3, 5, 5)
+    assert torch.equal(pack.conv_w(w)[2 * 5 + 3], w[:, :, 2, 3])
+    wt = torch.randn(3, 7, 3, 3)
+    assert torch.equal(pack.convT_w(wt)[1 * 3 + 2], wt[:, :, 1, 2].t())
