@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""Headline benchmark: deblurred 720p frames/s of the SPEINet per-sequence forward pass on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU)
+
+A "step" is one forward of one synthetic [1,5,3,720,1280] window (BASELINE.json configs[1]) per rank, inputs already
+resident in HBM.  Frames are independent, so ranks shard by frame with NO data-path collective (weak scaling);
+RCCL carries only the barrier, the max-over-ranks time and an all-gather of per-rank output checksums.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     — the dominant kernel (fused correlation arg-max, 37 % of the path's FLOPs, one launch per frame):
+                 algorithmic FLOPs per launch / its HIP-event duration measured live in the timed region, against the
+                 dense f32 MFMA peak of gfx950 (MI355X_MICROARCH.md: 157.3 TFLOP/s); `path_frac` prices the WHOLE
+                 frame (F = 20.64 TFLOP) against the same peak.
+  cpu_baseline — the oracle (CPU restatement of the reference, PyTorch fp32) timed on this host's cores, rank 0, N=1,
+                 on a bounded sample (one 360x640 frame), scaled to 720p frames by the FLOP formula of BASELINE.md §2.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W = 720, 1280
+F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def path_flops(h: int, w: int) -> float:
+    """F(HW) = 1.410e7*HW + 2304*(HW/16)^2  (`_forwardbs`, reference formulation)."""
+    hw = h * w
+    return 1.410e7 * hw + 2304.0 * (hw / 16.0) ** 2
+
+
+def corr_flops(h: int, w: int) -> float:
+    n3 = (h // 4) * (w // 4)
+    return 2.0 * 1152.0 * n3 * n3     # [N3 x 1152] x [1152 x N3]
+
+
+def cpu_baseline(seed: int) -> dict:
+    from oracle import speinet_oracle as O
+    from speinet_amd.synth import state_dict_template, synth_frames, synth_state_dict
+    threads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    sd = synth_state_dict(state_dict_template(), seed=0)
+    sh, sw = 360, 640
+    x = synth_frames(1, sh, sw, seed=seed)
+    with torch.no_grad():
+        t0 = time.time()
+        O.forward(x, sd, O.Cfg())
+        dt = time.time() - t0
+    scale = path_flops(H, W) / path_flops(sh, sw)
+    return {"value": 1.0 / (dt * scale), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (PyTorch fp32 CPU restatement), one {sw}x{sh} _forwardbs frame in {dt:.1f} s, "
+                      f"scaled x{scale:.2f} to 720p by F(HW) of BASELINE.md"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--branch", choices=["bs", "b"], default="bs", help="bs: with sharp reference (SearchTransfer); b: SelfTransfer")
+    ap.add_argument("--height", type=int, default=H)
+    ap.add_argument("--width", type=int, default=W)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local if world > 1 else 0)
+
+    from speinet_amd import ops
+    from speinet_amd.speinet import SPEINet, default_args
+    from speinet_amd.synth import state_dict_template, synth_frames, synth_state_dict
+
+    h, w = args.height, args.width
+    net = SPEINet(args=default_args())
+    net.load_state_dict(synth_state_dict(state_dict_template(), seed=0), strict=True)
+    net = net.to(dev).eval()
+    # each rank deblurs its own frames (clip shard = rank); two distinct windows alternate so nothing is cached
+    frames = [synth_frames(1, h, w, seed=1234 + 17 * rank + i, zero_ref=(0,) if args.branch == "b" else ()).to(dev) for i in range(2)]
+    routing = [args.branch == "b"]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    checksum = torch.zeros(1, device=dev, dtype=torch.float64)
+    with torch.no_grad():
+        for i in range(args.warmup):
+            net(frames[i % 2], routing=routing)
+        ops.PROFILE = {"corr_argmax": []}
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = net(frames[i % 2], routing=routing)
+            checksum += out.double().sum()
+        barrier()
+        dt = time.perf_counter() - t0
+    prof = ops.PROFILE["corr_argmax"]
+    ops.PROFILE = None
+    corr_ms = sum(s.elapsed_time(e) for s, e in prof) / max(1, len(prof))
+
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    gathered = [checksum.clone()]
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        gathered = [torch.zeros_like(checksum) for _ in range(world)]
+        dist.all_gather(gathered, checksum)          # the only payload that crosses xGMI: per-rank output checksums
+    tmax = tmax.item()
+    assert all(torch.isfinite(g).all() for g in gathered), "non-finite output"
+
+    if rank == 0:
+        fps = world * args.steps / tmax
+        ach = corr_flops(h, w) / (corr_ms * 1e-3) / 1e12 if corr_ms > 0 else 0.0
+        line = {
+            "metric": "deblurred 720p frames/sec", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * tmax / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"SPEINet.forward on synthetic {w}x{h} 5-frame windows, batch 1 per GPU, "
+                                   f"{'_forwardbs (SearchTransfer)' if args.branch == 'bs' else '_forwardb (SelfTransfer)'}, "
+                                   "synthetic name-keyed weights seed 0", "frames_per_step_per_gpu": 1, "sharding": "frames by rank, no data-path collective"},
+            "roofline": {"bound": "mfma", "kernel": "corr_argmax_kernel", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "launch_ms": corr_ms,
+                         "algorithmic_flops_per_launch": corr_flops(h, w),
+                         "path_flops_per_frame": path_flops(h, w),
+                         "path_frac": path_flops(h, w) * fps / world / 1e12 / F32_MFMA_PEAK_TFLOPS},
+            "checksum": float(sum(g.item() for g in gathered)),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(1234)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

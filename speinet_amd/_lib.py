@@ -59,6 +59,9 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m speinet_amd.build` (hipcc --offload-arch=gfx950). "
                 "speinet_amd has no CPU fallback.")
+        # torch ships its own libamdhip64.so.7; it must be in the process BEFORE this library is loaded so
+        # both resolve to ONE HIP runtime (same SONAME) and share device pointers and streams.
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)

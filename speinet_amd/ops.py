@@ -15,6 +15,28 @@ from . import _lib
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 CONV, CONV_T = 0, 1
 
+# Optional per-op timing hook for bench.py: {op name: [(start_event, end_event), ...]} recorded on the
+# current stream (the stream the kernels are launched on).  None = off (default).
+PROFILE = None
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if PROFILE is not None and self.name in PROFILE:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *a):
+        if PROFILE is not None and self.name in PROFILE:
+            self.e.record()
+            PROFILE[self.name].append((self.s, self.e))
+        return False
+
 
 class FMap:
     """NHWC fp32 feature map view: rows = pixels, `C` channels starting at column `off` of a [H*W, ld] buffer."""
@@ -195,8 +217,9 @@ def corr_argmax(lr: FMap, ref: FMap, inv_lr: torch.Tensor, inv_ref: torch.Tensor
     s = torch.empty(n, device=dev)
     arg = torch.empty(n, device=dev, dtype=torch.int32)
     ws = torch.empty(lib.spei_corr_ws_floats(n), device=dev)
-    _lib.check(lib.spei_corr_argmax(_vp(lr.ptr), lr.ld, _vp(ref.ptr), ref.ld, _tp(inv_lr), _tp(inv_ref), lr.H, lr.W, ref.H, ref.W,
-                                    lr.C, _tp(s), _tp(arg), _tp(ws), _stream()), "spei_corr_argmax")
+    with _timed("corr_argmax"):
+        _lib.check(lib.spei_corr_argmax(_vp(lr.ptr), lr.ld, _vp(ref.ptr), ref.ld, _tp(inv_lr), _tp(inv_ref), lr.H, lr.W, ref.H, ref.W,
+                                        lr.C, _tp(s), _tp(arg), _tp(ws), _stream()), "spei_corr_argmax")
     return s, arg
 
 
