@@ -64,6 +64,22 @@ int spei_igemm_f32(const float* a0, int lda0, int k0, const float* a1, int lda1,
                    const float* rowscale, int Hin, int Win, int Hout, int Wout, int N, int ksize, int stride,
                    int pad, int mode, int act, spei_stream_t stream);
 
+/* Same contract on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 activations in HBM rounded to
+ * bf16 while staged to LDS).  w_hi/w_lo: [tap][N][K] bf16.  w_lo == NULL: one bf16 product per MAC ("bf16");
+ * w_lo != NULL: split product al*wh + ah*wl + ah*wh ("bf16x3", f32-grade at 3/16 of the f32 MFMA cost). */
+int spei_igemm_bf16(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w_hi,
+                    const void* w_lo, const float* bias, float* out, int ldo, const float* residual, int ldr,
+                    const float* rowscale, int Hin, int Win, int Hout, int Wout, int N, int ksize, int stride,
+                    int pad, int mode, int act, spei_stream_t stream);
+
+/* Slab-resident variant of spei_igemm_bf16 for SPEI_CONV (stride 1/2) and linears: the input tile + halo is staged
+ * once into LDS as bf16 and the weights stream from HBM/L2 in MFMA fragment order
+ * (wfrag: [N/32][tap][K/16][64][8] bf16, see speinet_amd/pack.py).  Linears: pass Hin = Hout = M, Win = Wout = 1. */
+int spei_conv_slab_bf16(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* wfrag_hi,
+                        const void* wfrag_lo, const float* bias, float* out, int ldo, const float* residual, int ldr,
+                        const float* rowscale, int Hin, int Win, int Hout, int Wout, int N, int ksize, int stride,
+                        int pad, int act, spei_stream_t stream);
+
 /* K3 — ResBlock gates (model/block.py:8-24 SE, 71-96 ZPool+AttentionGate1/2, 108-124 TripletAttention).
  * x1: conv2 output [H][W][C].  Workspace `ws` floats: spei_gate_ws_floats(H,W,C).
  * Produces s[C], g1[H][C], g2[W][C] such that ResBlock = x + x1*s + (x1*g1 + x1*g2).
@@ -99,6 +115,13 @@ int64_t spei_corr_ws_floats(int64_t n_lr);
 int spei_corr_argmax(const float* lr, int ldl, const float* ref, int ldr, const float* inv_lr,
                      const float* inv_ref, int Hl, int Wl, int Hr, int Wr, int C, float* S, int32_t* arg,
                      float* ws, spei_stream_t stream);
+
+/* K11 on the bf16 pipe.  spei_split_bf16 converts a map once: hi = bf16(x), lo = bf16(x - hi) (lo may be NULL);
+ * outputs are dense [M][C] bf16.  spei_corr_argmax_bf16: lo pointers NULL -> single bf16 products, else bf16x3. */
+int spei_split_bf16(const float* x, int ld, void* hi, void* lo, int64_t M, int C, spei_stream_t stream);
+int spei_corr_argmax_bf16(const void* lr_hi, const void* lr_lo, const void* ref_hi, const void* ref_lo,
+                          const float* inv_lr, const float* inv_ref, int Hl, int Wl, int Hr, int Wr, int C, float* S,
+                          int32_t* arg, float* ws, spei_stream_t stream);
 
 /* K12 — gather the best-matching reference patch and overlap-add (unfold -> bis -> fold / 9,
  * model/SearchTransfer.py:36-46).  scale s in {1,2,4}: patch 3s, stride s, pad s. */

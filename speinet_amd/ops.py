@@ -11,9 +11,30 @@ from typing import Optional
 import torch
 
 from . import _lib
+from .pack import PackedW
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 CONV, CONV_T = 0, 1
+
+# Arithmetic of the GEMM-shaped kernels (convolutions, linears, correlation); everything else is always fp32.
+#   "f32"    v_mfma_f32_32x32x2_f32, exact fp32 (the PSNR-parity configuration)
+#   "bf16x3" split-bf16 products on v_mfma_f32_32x32x16_bf16: f32-grade results at 3/16 of the f32 MFMA cost
+#   "bf16"   single bf16 products, fp32 accumulate (the throughput configuration of BASELINE.json configs[1])
+# CORR_PRECISION applies to the correlation arg-max when PRECISION != "f32" ("bf16x3" keeps the arg-max stable).
+PRECISION = "f32"
+CORR_PRECISION = "bf16x3"
+USE_SLAB = True      # bf16 modes: slab-resident conv/linear kernel (conv_slab_bf16.hip) instead of igemm_bf16.hip
+
+
+def set_precision(mode: str, corr: str = None) -> None:
+    global PRECISION, CORR_PRECISION
+    if mode not in ("f32", "bf16x3", "bf16"):
+        raise ValueError(f"unknown precision {mode!r}")
+    PRECISION = mode
+    if corr is not None:
+        if corr not in ("bf16x3", "bf16"):
+            raise ValueError(f"unknown correlation precision {corr!r}")
+        CORR_PRECISION = corr
 
 # Optional per-op timing hook for bench.py: {op name: [(start_event, end_event), ...]} recorded on the
 # current stream (the stream the kernels are launched on).  None = off (default).
@@ -128,18 +149,30 @@ def igemm(a0: FMap, w: torch.Tensor, bias: Optional[torch.Tensor], N: int, ksize
         out = FMap.empty(ho, wo, N, a0.t.device)
     assert out.H == ho and out.W == wo and out.C == N
     k0, k1 = a0.C, (a1.C if a1 is not None else 0)
-    assert w.shape == (ksize * ksize, N, k0 + k1), (tuple(w.shape), ksize, N, k0, k1)
+    if torch.is_tensor(w):
+        w = PackedW(w, a0.t.device)
+    assert tuple(w.shape) == (ksize * ksize, N, k0 + k1), (tuple(w.shape), ksize, N, k0, k1)
     if a1 is not None:
         assert (a1.H, a1.W) == (a0.H, a0.W)
     if residual is not None:
         assert (residual.H, residual.W, residual.C) == (ho, wo, N)
     if rowscale is not None:
         assert rowscale.numel() == ho * wo
-    _lib.check(_lib.lib().spei_igemm_f32(
-        _vp(a0.ptr), a0.ld, k0, _vp(a1.ptr if a1 is not None else 0), a1.ld if a1 is not None else 0, k1,
-        _tp(w), _tp(bias), _vp(out.ptr), out.ld, _vp(residual.ptr if residual is not None else 0),
-        residual.ld if residual is not None else 0, _tp(rowscale), a0.H, a0.W, ho, wo, N, ksize, stride, pad, mode, act,
-        _stream()), "spei_igemm_f32")
+    common = (_vp(out.ptr), out.ld, _vp(residual.ptr if residual is not None else 0),
+              residual.ld if residual is not None else 0, _tp(rowscale), a0.H, a0.W, ho, wo, N, ksize, stride, pad, mode, act,
+              _stream())
+    srcs = (_vp(a0.ptr), a0.ld, k0, _vp(a1.ptr if a1 is not None else 0), a1.ld if a1 is not None else 0, k1)
+    if PRECISION == "f32":
+        _lib.check(_lib.lib().spei_igemm_f32(*srcs, _tp(w.f32), _tp(bias), *common), "spei_igemm_f32")
+    elif USE_SLAB and mode == CONV and w.fhi is not None:
+        dims = (a0.H * a0.W, 1, ho * wo, 1) if (ksize == 1 and stride == 1) else (a0.H, a0.W, ho, wo)
+        _lib.check(_lib.lib().spei_conv_slab_bf16(
+            *srcs, _tp(w.fhi), _tp(w.flo) if PRECISION == "bf16x3" else _vp(0), _tp(bias), _vp(out.ptr), out.ld,
+            _vp(residual.ptr if residual is not None else 0), residual.ld if residual is not None else 0, _tp(rowscale),
+            *dims, N, ksize, stride, pad, act, _stream()), "spei_conv_slab_bf16")
+    else:
+        _lib.check(_lib.lib().spei_igemm_bf16(*srcs, _tp(w.hi), _tp(w.lo) if PRECISION == "bf16x3" else _vp(0), _tp(bias), *common),
+                   "spei_igemm_bf16")
     return out
 
 
@@ -147,10 +180,12 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: int
            residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Token-space linear: x [M,K] -> [M,N]; w [N,K]."""
     m, k = x.shape
-    n = w.shape[0]
+    if torch.is_tensor(w):
+        w = PackedW(w.reshape(1, *w.shape), x.device)
+    n = w.shape[1]
     if out is None:
         out = torch.empty(m, n, device=x.device, dtype=torch.float32)
-    igemm(FMap(x, m, 1, k), w.view(1, n, k), b, n, act=act,
+    igemm(FMap(x, m, 1, k), w, b, n, act=act,
           residual=FMap(residual, m, 1, n) if residual is not None else None, out=FMap(out, m, 1, n))
     return out
 
@@ -217,9 +252,21 @@ def corr_argmax(lr: FMap, ref: FMap, inv_lr: torch.Tensor, inv_ref: torch.Tensor
     s = torch.empty(n, device=dev)
     arg = torch.empty(n, device=dev, dtype=torch.int32)
     ws = torch.empty(lib.spei_corr_ws_floats(n), device=dev)
+    if PRECISION == "f32":
+        with _timed("corr_argmax"):
+            _lib.check(lib.spei_corr_argmax(_vp(lr.ptr), lr.ld, _vp(ref.ptr), ref.ld, _tp(inv_lr), _tp(inv_ref), lr.H, lr.W, ref.H, ref.W,
+                                            lr.C, _tp(s), _tp(arg), _tp(ws), _stream()), "spei_corr_argmax")
+        return s, arg
+    split = CORR_PRECISION == "bf16x3"
+    parts = []
+    for f in (lr, ref):
+        hi = torch.empty(f.H * f.W, f.C, device=dev, dtype=torch.bfloat16)
+        lo = torch.empty_like(hi) if split else None
+        _lib.check(lib.spei_split_bf16(_vp(f.ptr), f.ld, _tp(hi), _tp(lo), f.H * f.W, f.C, _stream()), "spei_split_bf16")
+        parts += [hi, lo]
     with _timed("corr_argmax"):
-        _lib.check(lib.spei_corr_argmax(_vp(lr.ptr), lr.ld, _vp(ref.ptr), ref.ld, _tp(inv_lr), _tp(inv_ref), lr.H, lr.W, ref.H, ref.W,
-                                        lr.C, _tp(s), _tp(arg), _tp(ws), _stream()), "spei_corr_argmax")
+        _lib.check(lib.spei_corr_argmax_bf16(_tp(parts[0]), _tp(parts[1]), _tp(parts[2]), _tp(parts[3]), _tp(inv_lr), _tp(inv_ref),
+                                             lr.H, lr.W, ref.H, ref.W, lr.C, _tp(s), _tp(arg), _tp(ws), _stream()), "spei_corr_argmax_bf16")
     return s, arg
 
 

@@ -19,6 +19,32 @@ import torch
 SD = Dict[str, torch.Tensor]
 
 
+class GemmW:
+    """Marker: a [tap][Cout][Cin] (or [Cout][Cin]) GEMM weight still on the host side of packing."""
+    __slots__ = ("t",)
+
+    def __init__(self, t: torch.Tensor):
+        self.t = t if t.dim() == 3 else t.reshape(1, *t.shape)
+
+
+class PackedW:
+    """Device copies of one GEMM weight: f32 for the exact path, bf16 hi / lo (= bf16(w - hi)) for the bf16 pipe."""
+    __slots__ = ("f32", "hi", "lo", "shape", "fhi", "flo")
+
+    def __init__(self, t: torch.Tensor, device):
+        self.f32 = t.detach().to(device=device, dtype=torch.float32).contiguous()
+        self.hi = self.f32.to(torch.bfloat16)
+        self.lo = (self.f32 - self.hi.float()).to(torch.bfloat16)
+        self.shape = tuple(self.f32.shape)
+        # MFMA fragment order for conv_slab_bf16.hip: [n-tile][tap][k-step of 16][lane = h*32 + n%32][8], element
+        # (t, n, k) with k = 16*ks + 8*h + j  ->  one coalesced 1 KiB load per B fragment
+        t, n, k = self.shape
+        self.fhi = self.flo = None
+        if n % 32 == 0 and k % 32 == 0:
+            frag = lambda w: w.view(t, n // 32, 32, k // 16, 2, 8).permute(1, 0, 3, 4, 2, 5).contiguous()
+            self.fhi, self.flo = frag(self.hi), frag(self.lo)
+
+
 def conv_w(w: torch.Tensor) -> torch.Tensor:
     co, ci, kh, kw = w.shape
     return w.permute(2, 3, 0, 1).reshape(kh * kw, co, ci).contiguous()
@@ -29,6 +55,10 @@ def convT_w(w: torch.Tensor) -> torch.Tensor:
     return w.permute(2, 3, 1, 0).reshape(kh * kw, co, ci).contiguous()
 
 
+def G(t: torch.Tensor) -> GemmW:
+    return GemmW(t)
+
+
 def _bn_fold(sd: SD, p: str) -> torch.Tensor:
     scale = sd[p + "weight"].double() / torch.sqrt(sd[p + "running_var"].double() + 1e-5)
     shift = sd[p + "bias"].double() - sd[p + "running_mean"].double() * scale
@@ -37,8 +67,8 @@ def _bn_fold(sd: SD, p: str) -> torch.Tensor:
 
 def resblock(sd: SD, p: str) -> dict:
     return {
-        "w1": conv_w(sd[p + "main.0.main.0.weight"]), "b1": sd[p + "main.0.main.0.bias"],
-        "w2": conv_w(sd[p + "main.1.main.0.weight"]), "b2": sd[p + "main.1.main.0.bias"],
+        "w1": G(conv_w(sd[p + "main.0.main.0.weight"])), "b1": sd[p + "main.0.main.0.bias"],
+        "w2": G(conv_w(sd[p + "main.1.main.0.weight"])), "b2": sd[p + "main.1.main.0.bias"],
         "se_w1": sd[p + "se.fc.0.weight"], "se_b1": sd[p + "se.fc.0.bias"],
         "se_w2": sd[p + "se.fc.2.weight"], "se_b2": sd[p + "se.fc.2.bias"],
         "cw_w": sd[p + "te.cw.conv.conv.weight"].reshape(-1), "cw_bn": _bn_fold(sd, p + "te.cw.conv.bn."),
@@ -67,11 +97,11 @@ def swin_block(sd: SD, p: str, heads: int, ws: int) -> dict:
     idx = rel_pos_index(ws).reshape(-1).to(sd[p + "attn.relative_position_bias_table"].device)
     relb = sd[p + "attn.relative_position_bias_table"][idx].reshape(n, n, heads).permute(2, 0, 1).contiguous()
     return {
-        "wq": (scale * wq * g1[None, :]).float().contiguous(), "bq": (scale * (wq @ b1 + bq)).float(),
-        "wkv": (wkv * g1[None, :]).float().contiguous(), "bkv": (wkv @ b1 + bkv).float(),
-        "wproj": sd[p + "attn.proj.weight"].contiguous(), "bproj": sd[p + "attn.proj.bias"],
-        "w1": (w1 * g2[None, :]).float().contiguous(), "b1": (w1 @ b2 + bb1).float(),
-        "w2": sd[p + "mlp.fc2.weight"].contiguous(), "b2": sd[p + "mlp.fc2.bias"],
+        "wq": G((scale * wq * g1[None, :]).float().contiguous()), "bq": (scale * (wq @ b1 + bq)).float(),
+        "wkv": G((wkv * g1[None, :]).float().contiguous()), "bkv": (wkv @ b1 + bkv).float(),
+        "wproj": G(sd[p + "attn.proj.weight"].contiguous()), "bproj": sd[p + "attn.proj.bias"],
+        "w1": G((w1 * g2[None, :]).float().contiguous()), "b1": (w1 @ b2 + bb1).float(),
+        "w2": G(sd[p + "mlp.fc2.weight"].contiguous()), "b2": sd[p + "mlp.fc2.bias"],
         "relbias": relb.float(),
     }
 
@@ -85,7 +115,8 @@ def pack_all(sd: SD, cfg, device) -> dict:
         d = {}
         p = f"recons_net.{name}."
         if head_idx is not None:
-            d["head_w"] = conv_w(sd[f"{p}{head_idx}.0.weight"])
+            hw = conv_w(sd[f"{p}{head_idx}.0.weight"])
+            d["head_w"] = hw if name == "inBlock" else G(hw)     # the 3-channel head has its own direct kernel
             d["head_b"] = sd[f"{p}{head_idx}.0.bias"]
         d["blocks"] = [resblock(sd, f"{p}{first + i}.") for i in range(nblocks)]
         return d
@@ -95,7 +126,7 @@ def pack_all(sd: SD, cfg, device) -> dict:
     out["encoder_second"] = stage("encoder_second", 0, nrb, 1)
     for name in ("decoder_second", "decoder_first"):
         d = stage(name, None, nrb, 0)
-        d["tail_w"] = convT_w(sd[f"recons_net.{name}.{nrb}.0.weight"])
+        d["tail_w"] = G(convT_w(sd[f"recons_net.{name}.{nrb}.0.weight"]))
         d["tail_b"] = sd[f"recons_net.{name}.{nrb}.0.bias"]
         out[name] = d
     d = stage("outBlock", None, nrb, 0)
@@ -104,28 +135,30 @@ def pack_all(sd: SD, cfg, device) -> dict:
     out["outBlock"] = d
 
     for name in ("conv_lv1", "conv_lv2", "conv_lv3", "fusion", "search1", "search2", "search3", "search13", "search33", "search43"):
-        out[name] = {"w": conv_w(sd[name + ".weight"]), "b": sd[name + ".bias"]}
+        out[name] = {"w": G(conv_w(sd[name + ".weight"])), "b": sd[name + ".bias"]}
     for name in ("search1", "search2"):
-        out["SelfTransfer." + name] = {"w": conv_w(sd[f"SelfTransfer.{name}.weight"]), "b": sd[f"SelfTransfer.{name}.bias"]}
+        out["SelfTransfer." + name] = {"w": G(conv_w(sd[f"SelfTransfer.{name}.weight"])), "b": sd[f"SelfTransfer.{name}.bias"]}
 
     r = float(cfg.rgb_range)
     sw = {
-        "conv_first_w": conv_w(sd["swin.conv_first.weight"] * r), "conv_first_b": sd["swin.conv_first.bias"],
+        "conv_first_w": G(conv_w(sd["swin.conv_first.weight"] * r)), "conv_first_b": sd["swin.conv_first.bias"],
         "pe_g": sd["swin.patch_embed.norm.weight"], "pe_b": sd["swin.patch_embed.norm.bias"],
         "norm_g": sd["swin.norm.weight"], "norm_b": sd["swin.norm.bias"],
-        "cab_w": conv_w(sd["swin.conv_after_body.weight"]), "cab_b": sd["swin.conv_after_body.bias"],
-        "conv_last_w": conv_w(sd["swin.conv_last.weight"] / r), "conv_last_b": sd["swin.conv_last.bias"] / r,
+        "cab_w": G(conv_w(sd["swin.conv_after_body.weight"])), "cab_b": sd["swin.conv_after_body.bias"],
+        "conv_last_w": G(conv_w(sd["swin.conv_last.weight"] / r)), "conv_last_b": sd["swin.conv_last.bias"] / r,
         "layers": [],
     }
     for li, depth in enumerate(cfg.depths):
         p = f"swin.layers.{li}."
         sw["layers"].append({
             "blocks": [swin_block(sd, f"{p}residual_group.blocks.{bi}.", cfg.num_heads[li], cfg.window_size) for bi in range(depth)],
-            "conv_w": conv_w(sd[p + "conv.weight"]), "conv_b": sd[p + "conv.bias"],
+            "conv_w": G(conv_w(sd[p + "conv.weight"])), "conv_b": sd[p + "conv.bias"],
         })
     out["swin"] = sw
 
     def to_dev(o):
+        if isinstance(o, GemmW):
+            return PackedW(o.t, device)
         if torch.is_tensor(o):
             return o.detach().to(device=device, dtype=torch.float32).contiguous()
         if isinstance(o, dict):

@@ -1,0 +1,152 @@
+"""GPU suite, bf16 matrix-pipe modes of the GEMM-shaped kernels.
+
+  bf16x3  split-bf16 products (3 MFMAs): f32-grade.  Tolerance 2e-5 * max|ref| per kernel; end to end the same
+          bounds as the f32 path (1e-3 absolute, PSNR delta <= 1e-3 dB) and bit-exact arg-max on the golden cases.
+  bf16    single bf16 products, fp32 accumulate: per kernel 2^-8-ish relative error of each operand, tolerance
+          1.5e-2 * max|ref|; end to end the tolerance is reported and bounded at 0.05 absolute on an O(1) image / 0.1 dB.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import speinet_oracle as O           # noqa: E402
+from speinet_amd import engine, ops, pack        # noqa: E402
+from speinet_amd.ops import FMap                 # noqa: E402
+from speinet_amd.speinet import SPEINet, default_args  # noqa: E402
+from speinet_amd.synth import synth_frames       # noqa: E402
+
+DEV = "cuda:0"
+TOL = {"bf16x3": 2e-5, "bf16": 1.5e-2}
+
+
+def g(golden_dir, name):
+    d = np.load(os.path.join(golden_dir, name + ".npz"))
+    return {k: (torch.from_numpy(d[k]) if d[k].ndim > 0 else d[k].item()) for k in d.files}
+
+
+def rnd(seed, *shape, scale=1.0):
+    return torch.from_numpy((np.random.RandomState(seed).randn(*shape) * scale).astype(np.float32))
+
+
+def fm(x):
+    return FMap.from_nchw(x.to(DEV))
+
+
+def relerr(a, b):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    assert a.shape == b.shape and torch.isfinite(a).all()
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+@pytest.fixture(autouse=True)
+def _restore_precision():
+    yield
+    ops.set_precision("f32", "bf16x3")
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("cin,cout,k,stride,h,w", [
+    (32, 32, 5, 1, 20, 24), (64, 64, 5, 1, 13, 17), (128, 128, 5, 1, 10, 15), (32, 64, 5, 2, 40, 60),
+    (64, 128, 5, 2, 22, 18), (128, 256, 3, 1, 10, 15), (256, 256, 3, 1, 9, 11), (256, 128, 3, 1, 10, 15),
+    (384, 128, 1, 1, 10, 15), (64, 32, 1, 1, 21, 19), (96, 32, 3, 1, 21, 19), (512, 256, 1, 1, 33, 7)])
+def test_igemm_conv(mode, cin, cout, k, stride, h, w):
+    ops.set_precision(mode)
+    x = rnd(1, 1, cin, h, w)
+    wt = rnd(2, cout, cin, k, k, scale=1.0 / np.sqrt(cin * k * k))
+    b = rnd(3, cout, scale=0.1)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), stride=stride, padding=k // 2).float()
+    out = ops.igemm(fm(x), pack.conv_w(wt).to(DEV), b.to(DEV), cout, ksize=k, stride=stride)
+    e = relerr(out.nchw(), ref)
+    assert e < TOL[mode], f"{mode}: rel err {e:.2e}"
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+def test_igemm_concat_transpose_epilogue(mode):
+    ops.set_precision(mode)
+    h, w = 14, 22
+    xa, xb = rnd(4, 1, 64, h, w), rnd(5, 1, 32, h, w)
+    wt, b, res = rnd(6, 64, 96, 3, 3, scale=0.05), rnd(7, 64, scale=0.1), rnd(8, 1, 64, h, w)
+    rs = torch.rand(h * w, generator=torch.Generator().manual_seed(9))
+    ref = F.gelu(F.conv2d(torch.cat((xa, xb), 1), wt, b, padding=1)) * rs.view(1, 1, h, w) + res
+    out = ops.igemm(fm(xa), pack.conv_w(wt).to(DEV), b.to(DEV), 64, ksize=3, a1=fm(xb), act=ops.ACT_GELU, residual=fm(res), rowscale=rs.to(DEV))
+    assert relerr(out.nchw(), ref) < TOL[mode]
+    x = rnd(12, 1, 128, 10, 15)
+    wtt, bt = rnd(13, 128, 64, 3, 3, scale=0.05), rnd(14, 64, scale=0.1)
+    ref = F.relu(F.conv_transpose2d(x, wtt, bt, stride=2, padding=1, output_padding=1))
+    out = ops.igemm(fm(x), pack.convT_w(wtt).to(DEV), bt.to(DEV), 64, ksize=3, stride=2, mode=ops.CONV_T, act=ops.ACT_RELU)
+    assert relerr(out.nchw(), ref) < TOL[mode]
+
+
+@pytest.mark.parametrize("name", ["g07_search", "g07_search_tie"])
+def test_search_bf16x3_argmax_exact(golden_dir, name):
+    """With split-bf16 scores the arg-max of the golden cases (incl. the exact-tie one) stays bit exact."""
+    ops.set_precision("bf16x3", "bf16x3")
+    d = g(golden_dir, name)
+    s, t3, t2, t1, arg = engine.search_transfer(fm(d["lr3"]), fm(d["rf1"]), fm(d["rf2"]), fm(d["rf3"]), return_arg=True)
+    assert torch.equal(arg.cpu().long(), d["arg"][0])
+    assert relerr(s.view(1, 1, 10, 15), d["s"]) < 2e-5
+    assert relerr(t1.nchw(), d["t1"]) < 1e-6
+
+
+def test_search_bf16_flip_rate():
+    """Single-bf16 scores: the winner may flip between near-tied candidates; measure it on a 20x30 map."""
+    ops.set_precision("bf16", "bf16")
+    lr3, rf3 = rnd(32, 1, 128, 20, 30), rnd(33, 1, 128, 20, 30)
+    rf2, rf1 = rnd(34, 1, 64, 40, 60), rnd(35, 1, 32, 80, 120)
+    s0, _, _, _, arg0 = O.search_transfer(lr3, rf3, rf1, rf2, rf3, return_arg=True)
+    s, t3, t2, t1, arg = engine.search_transfer(fm(lr3), fm(rf1), fm(rf2), fm(rf3), return_arg=True)
+    flips = (arg.cpu().long() != arg0[0]).float().mean().item()
+    serr = (s.cpu() - s0.reshape(-1)).abs().max().item()
+    print(f"bf16 correlation: flip rate {flips:.3%}, max |S err| {serr:.2e}")
+    assert serr < 5e-3            # the weight map S itself stays accurate
+    assert flips < 0.25           # random (structure-free) features are the worst case for near-ties
+
+
+@pytest.fixture(scope="module")
+def net(synth_sd):
+    n = SPEINet(args=default_args())
+    n.load_state_dict(synth_sd, strict=True)
+    return n.to(DEV).eval()
+
+
+@pytest.mark.parametrize("name,b,h,w", [("g10_fwd_40x60_mixed", 2, 40, 60), ("g10_fwd_100x100", 1, 100, 100),
+                                        ("g10_fwd_200x200", 1, 200, 200), ("g10_fwd_200x200_noref", 1, 200, 200)])
+def test_forward_bf16x3_golden(golden_dir, net, name, b, h, w):
+    d = g(golden_dir, name)
+    zr = tuple(int(i) for i in d["zero_ref"]) if "zero_ref" in d else ()
+    x = synth_frames(b, h, w, seed=int(d["seed"]), zero_ref=zr)
+    net.precision, net.corr_precision = "bf16x3", "bf16x3"
+    with torch.no_grad():
+        out = net(x.to(DEV)).cpu()
+    net.precision = "f32"
+    err = (out - d["out"]).abs().max().item()
+    assert err < 1e-3, f"max abs err {err:.3e}"
+    for i in range(b):
+        tgt = O.to_uint8(x[i:i + 1, 1])
+        dp = abs(O.psnr_uint8(O.to_uint8(out[i:i + 1]), tgt) - O.psnr_uint8(O.to_uint8(d["out"][i:i + 1]), tgt))
+        assert dp <= 1e-3, f"PSNR delta {dp:.2e} dB"
+
+
+@pytest.mark.parametrize("name,b,h,w", [("g10_fwd_100x100", 1, 100, 100), ("g10_fwd_200x200", 1, 200, 200),
+                                        ("g10_fwd_200x200_noref", 1, 200, 200)])
+def test_forward_bf16_golden(golden_dir, net, name, b, h, w):
+    d = g(golden_dir, name)
+    zr = tuple(int(i) for i in d["zero_ref"]) if "zero_ref" in d else ()
+    x = synth_frames(b, h, w, seed=int(d["seed"]), zero_ref=zr)
+    net.precision, net.corr_precision = "bf16", "bf16x3"
+    with torch.no_grad():
+        out = net(x.to(DEV)).cpu()
+    net.precision = "f32"
+    err = (out - d["out"]).abs().max().item()
+    rms = (out - d["out"]).pow(2).mean().sqrt().item()
+    tgt = O.to_uint8(x[:1, 1])
+    dp = abs(O.psnr_uint8(O.to_uint8(out), tgt) - O.psnr_uint8(O.to_uint8(d["out"]), tgt))
+    psnr_vs_ref = O.psnr_uint8(O.to_uint8(out), O.to_uint8(d["out"]))
+    print(f"{name} bf16: max abs err {err:.3e}, rms {rms:.3e}, PSNR(out, ref out) {psnr_vs_ref:.1f} dB, |dPSNR vs target| {dp:.2e} dB")
+    assert err < 0.05 and dp < 0.1

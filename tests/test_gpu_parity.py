@@ -154,7 +154,7 @@ def test_conv5_in_out(h, w):
 @pytest.mark.parametrize("c", [32, 64, 128])
 def test_resblock_golden(golden_dir, synth_sd, c):
     d = g(golden_dir, f"g02_resblock{c}")
-    pk = {k: v.to(DEV).contiguous() for k, v in pack.resblock(synth_sd, str(d["key"])).items()}
+    pk = {k: (pack.PackedW(v.t, DEV) if isinstance(v, pack.GemmW) else v.to(DEV).contiguous()) for k, v in pack.resblock(synth_sd,str(d["key"])).items()}
     for b in range(2):
         out = ops.resblock(fm(d["x"][b:b + 1]), pk)
         close(out.nchw(), d["out"][b:b + 1], 1e-4, 1e-5, f"resblock{c}")
@@ -162,7 +162,7 @@ def test_resblock_golden(golden_dir, synth_sd, c):
 
 def test_resblock_ragged_vs_oracle(synth_sd):
     key = "recons_net.encoder_first.2."
-    pk = {k: v.to(DEV).contiguous() for k, v in pack.resblock(synth_sd, key).items()}
+    pk = {k: (pack.PackedW(v.t, DEV) if isinstance(v, pack.GemmW) else v.to(DEV).contiguous()) for k, v in pack.resblock(synth_sd,key).items()}
     x = rnd(25, 1, 64, 37, 71)
     close(ops.resblock(fm(x), pk).nchw(), O.resblock(x, synth_sd, key), 1e-4, 1e-5, "resblock ragged")
 

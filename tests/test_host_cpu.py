@@ -73,8 +73,8 @@ def test_packing_algebra(synth_sd):
     xhat = F.layer_norm(x, (256,), None, None, 1e-5)
     kv_ref = F.linear(ln, synth_sd[p + "attn.qkv_x.weight"], synth_sd[p + "attn.qkv_x.bias"])
     q_ref = F.linear(ln, synth_sd[p + "attn.qkv_y.weight"], synth_sd[p + "attn.qkv_y.bias"]) * 32 ** -0.5
-    assert torch.allclose(F.linear(xhat, bk["wkv"], bk["bkv"]), kv_ref, atol=2e-5)
-    assert torch.allclose(F.linear(xhat, bk["wq"], bk["bq"]), q_ref, atol=2e-5)
+    assert torch.allclose(F.linear(xhat, bk["wkv"].t[0], bk["bkv"]), kv_ref, atol=2e-5)
+    assert torch.allclose(F.linear(xhat, bk["wq"].t[0], bk["bq"]), q_ref, atol=2e-5)
     idx = O.rel_pos_index(5).view(-1)
     rb = synth_sd[p + "attn.relative_position_bias_table"][idx].view(25, 25, 8).permute(2, 0, 1)
     assert torch.equal(bk["relbias"], rb.contiguous())
