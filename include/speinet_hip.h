@@ -123,6 +123,12 @@ int spei_corr_argmax_bf16(const void* lr_hi, const void* lr_lo, const void* ref_
                           const float* inv_lr, const float* inv_ref, int Hl, int Wl, int Hr, int Wr, int C, float* S,
                           int32_t* arg, float* ws, spei_stream_t stream);
 
+/* Slab-resident variant of spei_corr_argmax_bf16 (same arguments, C == 128): the query block and the streamed
+ * reference blocks live in LDS with their 1-pixel halo, so the 3x3 unfold is LDS addressing, not memory traffic. */
+int spei_corr_slab_bf16(const void* lr_hi, const void* lr_lo, const void* ref_hi, const void* ref_lo,
+                        const float* inv_lr, const float* inv_ref, int Hl, int Wl, int Hr, int Wr, int C, float* S,
+                        int32_t* arg, float* ws, spei_stream_t stream);
+
 /* K12 — gather the best-matching reference patch and overlap-add (unfold -> bis -> fold / 9,
  * model/SearchTransfer.py:36-46).  scale s in {1,2,4}: patch 3s, stride s, pad s. */
 int spei_gather_fold(const float* ref, int ldr, const int32_t* arg, float* out, int ldo, int H3, int W3,

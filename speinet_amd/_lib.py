@@ -32,6 +32,7 @@ SIGNATURES = {
     "spei_igemm_bf16": (I, [P, I, I, P, I, I, P, P, P, P, I, P, I, P, I, I, I, I, I, I, I, I, I, I, P]),
     "spei_conv_slab_bf16": (I, [P, I, I, P, I, I, P, P, P, P, I, P, I, P, I, I, I, I, I, I, I, I, I, P]),
     "spei_split_bf16": (I, [P, I, P, P, L, I, P]),
+    "spei_corr_slab_bf16": (I, [P, P, P, P, P, P, I, I, I, I, I, P, P, P, P]),
     "spei_corr_argmax_bf16": (I, [P, P, P, P, P, P, I, I, I, I, I, P, P, P, P]),
     "spei_gate_ws_floats": (L, [I, I, I]),
     "spei_resblock_gates": (I, [P, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),

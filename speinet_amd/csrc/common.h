@@ -39,3 +39,6 @@ __device__ __forceinline__ float wave_max(float v) {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// 16-byte register staging type.  NOT HIP's uint4: arrays of that struct type are not scalarised by the compiler and end
+// up in scratch memory (measured: 144-160 B/lane of scratch traffic in the staging loops).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));

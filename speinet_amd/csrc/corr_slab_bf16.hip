@@ -1,0 +1,307 @@
+// K11, slab-resident: fused 3x3-patch correlation + arg-max on the bf16 matrix pipe
+// (reference model/SearchTransfer.py:26-34, 61-69).
+//
+//   S[i] = max_j <P_ref[j], P_lr[i]> * inv_ref[j] * inv_lr[i]        arg[i] = lowest maximising j
+//
+// search_bf16.hip re-stages 128 x 64 operand tiles per (tap, K chunk): 18 global->LDS round trips and barriers per
+// reference tile, i.e. every feature pixel crosses L2 -> LDS nine times.  Here the 3x3 unfold is pure LDS
+// addressing:
+//   * the query block (NI rows x 32 lr positions) and its 1-pixel halo sit in LDS for the whole kernel, all 128
+//     channels (pixel pitch 2*128+16 B);
+//   * the reference map is streamed as 4 x 32 position blocks + halo, KC channels at a time, double buffered
+//     (pixel pitch 2*KC+16 B): one global->LDS stage per 9 taps x KC/16 k-steps = 72..144 MFMAs per wave;
+//   * the MFMA (v_mfma_f32_32x32x16_bf16) puts reference positions on accumulator rows and query positions on
+//     lanes, so the running (max, argmax) over j is per lane, in registers; R (13.3 GB at 720p) never exists.
+// lo == NULL: single bf16 products; lo != NULL: split products al*bh + ah*bl + ah*bh (bf16x3, f32-grade scores).
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int CMAXSPLIT = 8;
+constexpr int RB_H = 4, RB_W = 32;           // reference block (128 positions)
+constexpr int SLAB_W = RB_W + 2;             // 34 pixels per slab row (1-pixel halo each side)
+
+struct CorrSlabParams {
+    const __bf16* lrh;
+    const __bf16* lrl;
+    const __bf16* refh;
+    const __bf16* refl;
+    const float* inv_lr;
+    const float* inv_ref;
+    float* pval;
+    int32_t* pidx;
+    int Hl, Wl, Hr, Wr, Nl;
+    int itiles_x;        // query tiles per row
+    int rblocks_x, rblocks;   // reference blocks per row / total
+    int rb_per_split;
+};
+
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+
+// NI: query tile rows (x 32 columns); KC: reference channels per stage; SPLIT: bf16x3
+template <int NI, int KC, bool SPLIT>
+__global__ __launch_bounds__(256) void corr_slab_kernel(const CorrSlabParams p) {
+    constexpr int C = 128;
+    constexpr int TN = NI / 2;                         // 32-column n-tiles per wave (2 waves along i)
+    constexpr int NPART = SPLIT ? 2 : 1;
+    constexpr int PITCH_L = 2 * C + 16;                // lr slab pixel pitch (bytes)
+    constexpr int PITCH_R = 2 * KC + 16;               // ref stage pixel pitch
+    constexpr int LPIX = (NI + 2) * SLAB_W, RPIX = (RB_H + 2) * SLAB_W;
+    constexpr int L_BYTES = ((LPIX * PITCH_L + 15) / 16) * 16;
+    constexpr int R_BYTES = ((RPIX * PITCH_R + 15) / 16) * 16;
+    constexpr int NCH = C / KC;                        // channel chunks per reference block
+    constexpr int RCH16 = KC / 8;                      // 16-byte pieces per pixel per stage
+    constexpr int RLOADS = (RPIX * RCH16 + 255) / 256; // staged 16-byte loads per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* lslab = smem;                                   // [NPART][L_BYTES]
+    unsigned char* rslab = smem + NPART * L_BYTES;                 // [2 buffers][NPART][R_BYTES]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;           // 2 waves along j (64 rows each), 2 along i
+    const int fr = lane & 31, fk = lane >> 5;
+    const int ity = blockIdx.x / p.itiles_x, itx = blockIdx.x - ity * p.itiles_x;
+    const int iy0 = ity * NI, ix0 = itx * RB_W;
+    const int rb0 = blockIdx.y * p.rb_per_split;
+    const int rb1 = min(p.rblocks, rb0 + p.rb_per_split);
+    const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
+
+    // ---- resident query slab ----------------------------------------------------------------------------
+    for (int idx = tid; idx < LPIX * (C / 8); idx += 256) {
+        const int pix = idx >> 4, c16 = idx & 15;      // C/8 == 16 pieces per pixel
+        const int sy = pix / SLAB_W, sx = pix - sy * SLAB_W;
+        const int gy = iy0 + sy - 1, gx = ix0 + sx - 1;
+        const bool ok = (gy >= 0) & (gy < p.Hl) & (gx >= 0) & (gx < p.Wl);
+        const size_t o = ((size_t)gy * p.Wl + gx) * C + c16 * 8;
+        *reinterpret_cast<u32x4*>(lslab + pix * PITCH_L + c16 * 16) = ok ? *reinterpret_cast<const u32x4*>(p.lrh + o) : zero4;
+        if (SPLIT) *reinterpret_cast<u32x4*>(lslab + L_BYTES + pix * PITCH_L + c16 * 16) = ok ? *reinterpret_cast<const u32x4*>(p.lrl + o) : zero4;
+    }
+
+    // ---- reference stage loader -------------------------------------------------------------------------
+    u32x4 rh[RLOADS], rl[SPLIT ? RLOADS : 1];
+    auto load_stage = [&](int stage) __attribute__((always_inline)) {                 // stage = (rb - rb0) * NCH + chunk
+        const int rb = rb0 + stage / NCH, ch = stage % NCH;
+        const int rby = rb / p.rblocks_x, rbx = rb - rby * p.rblocks_x;
+        const int jy0 = rby * RB_H - 1, jx0 = rbx * RB_W - 1;
+#pragma unroll
+        for (int u = 0; u < RLOADS; ++u) {
+            const int idx = tid + u * 256;
+            const int pix = idx / RCH16, c16 = idx - pix * RCH16;
+            const int sy = pix / SLAB_W, sx = pix - sy * SLAB_W;
+            const int gy = jy0 + sy, gx = jx0 + sx;
+            const bool ok = (idx < RPIX * RCH16) & (gy >= 0) & (gy < p.Hr) & (gx >= 0) & (gx < p.Wr);
+            const size_t o = ((size_t)gy * p.Wr + gx) * C + ch * KC + c16 * 8;
+            rh[u] = ok ? *reinterpret_cast<const u32x4*>(p.refh + o) : zero4;
+            if (SPLIT) rl[u] = ok ? *reinterpret_cast<const u32x4*>(p.refl + o) : zero4;
+        }
+    };
+    auto store_stage = [&](int buf) __attribute__((always_inline)) {
+        unsigned char* base = rslab + buf * NPART * R_BYTES;
+#pragma unroll
+        for (int u = 0; u < RLOADS; ++u) {
+            const int idx = tid + u * 256;
+            if (idx < RPIX * RCH16) {
+                const int pix = idx / RCH16, c16 = idx - pix * RCH16;
+                *reinterpret_cast<u32x4*>(base + pix * PITCH_R + c16 * 16) = rh[u];
+                if (SPLIT) *reinterpret_cast<u32x4*>(base + R_BYTES + pix * PITCH_R + c16 * 16) = rl[u];
+            }
+        }
+    };
+
+    // ---- per-lane operand bases ---------------------------------------------------------------------------
+    int abase[2], bbase[TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                       // reference rows: block pixel (py, px) = (wm*2+i, fr)
+        abase[i] = ((wm * 2 + i) * SLAB_W + fr) * PITCH_R + fk * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {                      // query columns: tile pixel (qy, qx) = (wn*TN+j, fr)
+        bbase[j] = ((wn * TN + j) * SLAB_W + fr) * PITCH_L + fk * 16;
+    }
+    float bestv[TN], il[TN];
+    int besti[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        bestv[j] = -INFINITY;
+        besti[j] = 0x7fffffff;
+        const int qy = iy0 + wn * TN + j, qx = ix0 + fr;
+        il[j] = (qy < p.Hl && qx < p.Wl) ? p.inv_lr[qy * p.Wl + qx] : 0.f;
+    }
+
+    f32x16 acc[2][TN];
+    const int nstages = (rb1 - rb0) * NCH;
+    if (nstages > 0) {
+        load_stage(0);
+        store_stage(0);
+    }
+    __syncthreads();
+
+    for (int st = 0; st < nstages; ++st) {
+        const int buf = st & 1;
+        const int ch = st % NCH;
+        if (ch == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+        if (st + 1 < nstages) load_stage(st + 1);
+        const unsigned char* ra = rslab + buf * NPART * R_BYTES;
+        const unsigned char* lb = lslab + ch * (KC * 2);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ty = t / 3, tx = t - ty * 3;
+            const int aoff = (ty * SLAB_W + tx) * PITCH_R;
+            const int boff = (ty * SLAB_W + tx) * PITCH_L;
+#pragma unroll
+            for (int ks = 0; ks < KC / 16; ++ks) {
+                bf16x8 av[2], bv[TN], avl[2], bvl[TN];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    av[i] = *reinterpret_cast<const bf16x8*>(ra + abase[i] + aoff + ks * 32);
+                    if (SPLIT) avl[i] = *reinterpret_cast<const bf16x8*>(ra + R_BYTES + abase[i] + aoff + ks * 32);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bv[j] = *reinterpret_cast<const bf16x8*>(lb + bbase[j] + boff + ks * 32);
+                    if (SPLIT) bvl[j] = *reinterpret_cast<const bf16x8*>(lb + L_BYTES + bbase[j] + boff + ks * 32);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if (SPLIT) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avl[i], bv[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bvl[j], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+        if (st + 1 < nstages) store_stage(buf ^ 1);
+        if (ch == NCH - 1) {
+            // reference block finished: fold its 128 rows into the running (max, argmax) of this lane's columns
+            const int rb = rb0 + st / NCH;
+            const int rby = rb / p.rblocks_x, rbx = rb - rby * p.rblocks_x;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int jy = rby * RB_H + wm * 2 + i;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int jx = rbx * RB_W + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    if (jy < p.Hr && jx < p.Wr) {
+                        const int jj = jy * p.Wr + jx;
+                        const float ir = p.inv_ref[jj];
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const float v = acc[i][j][r] * ir * il[j];
+                            if (better(v, jj, bestv[j], besti[j])) { bestv[j] = v; besti[j] = jj; }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- combine lane halves, then the two waves (wm) sharing the same query columns ---------------------------
+    float* rv = reinterpret_cast<float*>(smem);            // [2 wm][NI*32]
+    int* ri = reinterpret_cast<int*>(smem) + 2 * NI * 32;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const float ov = __shfl_xor(bestv[j], 32, 64);
+        const int oi = __shfl_xor(besti[j], 32, 64);
+        if (better(ov, oi, bestv[j], besti[j])) { bestv[j] = ov; besti[j] = oi; }
+        if (fk == 0) {
+            const int col = (wn * TN + j) * 32 + fr;
+            rv[wm * NI * 32 + col] = bestv[j];
+            ri[wm * NI * 32 + col] = besti[j];
+        }
+    }
+    __syncthreads();
+    if (tid < NI * 32) {
+        const int qy = iy0 + (tid >> 5), qx = ix0 + (tid & 31);
+        if (qy < p.Hl && qx < p.Wl) {
+            float v = rv[tid];
+            int ix = ri[tid];
+            if (better(rv[NI * 32 + tid], ri[NI * 32 + tid], v, ix)) { v = rv[NI * 32 + tid]; ix = ri[NI * 32 + tid]; }
+            const int i = qy * p.Wl + qx;
+            p.pval[(size_t)blockIdx.y * p.Nl + i] = v;
+            p.pidx[(size_t)blockIdx.y * p.Nl + i] = ix;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void corr_slab_final_kernel(const float* __restrict__ pval, const int32_t* __restrict__ pidx,
+                                                              int splits, int Nl, float* __restrict__ S, int32_t* __restrict__ arg) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Nl) return;
+    float v = pval[i];
+    int ix = pidx[i];
+    for (int s = 1; s < splits; ++s) {
+        const float ov = pval[(size_t)s * Nl + i];
+        const int oi = pidx[(size_t)s * Nl + i];
+        if (better(ov, oi, v, ix)) { v = ov; ix = oi; }
+    }
+    S[i] = v;
+    arg[i] = ix == 0x7fffffff ? 0 : ix;
+}
+
+template <int NI, int KC, bool SPLIT>
+void launch_corr(const CorrSlabParams& p, int itiles, int splits, hipStream_t st) {
+    constexpr int C = 128;
+    constexpr int NPART = SPLIT ? 2 : 1;
+    constexpr int L_BYTES = ((((NI + 2) * SLAB_W) * (2 * C + 16) + 15) / 16) * 16;
+    constexpr int R_BYTES = ((((RB_H + 2) * SLAB_W) * (2 * KC + 16) + 15) / 16) * 16;
+    const size_t lds = (size_t)NPART * L_BYTES + (size_t)2 * NPART * R_BYTES;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_slab_kernel<NI, KC, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((corr_slab_kernel<NI, KC, SPLIT>), dim3(itiles, splits), dim3(256), lds, st, p);
+}
+
+}  // namespace
+
+extern "C" int spei_corr_slab_bf16(const void* lr_hi, const void* lr_lo, const void* ref_hi, const void* ref_lo,
+                                   const float* inv_lr, const float* inv_ref, int Hl, int Wl, int Hr, int Wr, int C,
+                                   float* S, int32_t* arg, float* ws, spei_stream_t stream) {
+    SPEI_REQUIRE(lr_hi && ref_hi && inv_lr && inv_ref && S && arg && ws, "spei_corr_slab_bf16: null pointer");
+    SPEI_REQUIRE((lr_lo == nullptr) == (ref_lo == nullptr), "spei_corr_slab_bf16: lo parts must both be given or both be NULL");
+    SPEI_REQUIRE(C == 128, "spei_corr_slab_bf16: C=%d (128 built)", C);
+    SPEI_REQUIRE(Hl > 0 && Wl > 0 && Hr > 0 && Wr > 0, "spei_corr_slab_bf16: empty map");
+    SPEI_REQUIRE((int64_t)Hl * Wl < (1ll << 30) && (int64_t)Hr * Wr < (1ll << 30), "spei_corr_slab_bf16: map too large");
+    SPEI_REQUIRE(((uintptr_t)lr_hi | (uintptr_t)ref_hi | (uintptr_t)lr_lo | (uintptr_t)ref_lo) % 16 == 0, "spei_corr_slab_bf16: 16-byte alignment required");
+    const bool split = lr_lo != nullptr;
+    const int NI = split ? 2 : 4;
+    CorrSlabParams p;
+    p.lrh = (const __bf16*)lr_hi; p.lrl = (const __bf16*)lr_lo; p.refh = (const __bf16*)ref_hi; p.refl = (const __bf16*)ref_lo;
+    p.inv_lr = inv_lr; p.inv_ref = inv_ref;
+    p.Hl = Hl; p.Wl = Wl; p.Hr = Hr; p.Wr = Wr; p.Nl = Hl * Wl;
+    p.itiles_x = cdiv(Wl, RB_W);
+    const int itiles = p.itiles_x * cdiv(Hl, NI);
+    p.rblocks_x = cdiv(Wr, RB_W);
+    p.rblocks = p.rblocks_x * cdiv(Hr, RB_H);
+    // split the reference blocks so that the grid fills 256 CUs (one workgroup per CU) with little tail
+    int best_s = 1;
+    double best_eff = 0.0;
+    for (int s = 1; s <= CMAXSPLIT && s <= p.rblocks; ++s) {
+        const double units = (double)itiles * s;
+        const double eff = units / (256.0 * (double)cdiv((int64_t)units, 256));
+        if (eff > best_eff + 0.02) { best_eff = eff; best_s = s; }
+    }
+    p.rb_per_split = cdiv(p.rblocks, best_s);
+    const int splits = cdiv(p.rblocks, p.rb_per_split);
+    p.pval = ws;
+    p.pidx = reinterpret_cast<int32_t*>(ws + (size_t)CMAXSPLIT * p.Nl);
+    hipStream_t st = (hipStream_t)stream;
+    if (split) launch_corr<2, 32, true>(p, itiles, splits, st);
+    else launch_corr<4, 64, false>(p, itiles, splits, st);
+    hipLaunchKernelGGL(corr_slab_final_kernel, dim3(cdiv(p.Nl, 256)), dim3(256), 0, st, p.pval, p.pidx, splits, p.Nl, S, arg);
+    SPEI_CHECK_LAUNCH("spei_corr_slab_bf16");
+    return 0;
+}

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmParams p) {
     const int niter = p.ks * p.ks * kchunks;
 
     float4 ra[AP];
-    uint4 rbh[BP], rbl[SPLIT ? BP : 1];
+    u32x4 rbh[BP], rbl[SPLIT ? BP : 1];
     auto load_tile = [&](int it) {
         const int t = it / kchunks;
         const int kc = it - t * kchunks;
@@ -117,8 +117,8 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmParams p) {
         for (int j = 0; j < BP; ++j) {
             if (brow + RPP_B * j < BN) {
                 const size_t o = ((size_t)t * p.N + n0 + brow + RPP_B * j) * p.K + kofs + bcol;
-                rbh[j] = *reinterpret_cast<const uint4*>(p.wh + o);
-                if (SPLIT) rbl[j] = *reinterpret_cast<const uint4*>(p.wl + o);
+                rbh[j] = *reinterpret_cast<const u32x4*>(p.wh + o);
+                if (SPLIT) rbl[j] = *reinterpret_cast<const u32x4*>(p.wl + o);
             }
         }
     };
@@ -139,8 +139,8 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmParams p) {
         for (int j = 0; j < BP; ++j) {
             if (brow + RPP_B * j < BN) {
                 const int o = (brow + RPP_B * j) * PITCH + bcol * 2;
-                *reinterpret_cast<uint4*>(bh + o) = rbh[j];
-                if (SPLIT) *reinterpret_cast<uint4*>(bl + o) = rbl[j];
+                *reinterpret_cast<u32x4*>(bh + o) = rbh[j];
+                if (SPLIT) *reinterpret_cast<u32x4*>(bl + o) = rbl[j];
             }
         }
     };

@@ -85,8 +85,8 @@ __global__ __launch_bounds__(256) void corr_bf16_kernel(const CorrParams p) {
             else { a_y[j] = -0x10000000; a_x[j] = 0; }
         }
     };
-    uint4 rah[NP], rbh[NP], ral[SPLIT ? NP : 1], rbl[SPLIT ? NP : 1];
-    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+    u32x4 rah[NP], rbh[NP], ral[SPLIT ? NP : 1], rbl[SPLIT ? NP : 1];
+    const u32x4 zero = u32x4{0u, 0u, 0u, 0u};
     auto load_tile = [&](int it) {
         const int t = it / kchunks, kc = it - t * kchunks;
         const int ty = t / 3 - 1, tx = t - (t / 3) * 3 - 1;
@@ -96,13 +96,13 @@ __global__ __launch_bounds__(256) void corr_bf16_kernel(const CorrParams p) {
             const int yy = a_y[j] + ty, xx = a_x[j] + tx;
             const bool oka = (yy >= 0) & (yy < p.Hr) & (xx >= 0) & (xx < p.Wr);
             const size_t oa = ((size_t)yy * p.Wr + xx) * p.C + kofs;
-            rah[j] = oka ? *reinterpret_cast<const uint4*>(p.refh + oa) : zero;
-            if (SPLIT) ral[j] = oka ? *reinterpret_cast<const uint4*>(p.refl + oa) : zero;
+            rah[j] = oka ? *reinterpret_cast<const u32x4*>(p.refh + oa) : zero;
+            if (SPLIT) ral[j] = oka ? *reinterpret_cast<const u32x4*>(p.refl + oa) : zero;
             const int y2 = b_y[j] + ty, x2 = b_x[j] + tx;
             const bool okb = (y2 >= 0) & (y2 < p.Hl) & (x2 >= 0) & (x2 < p.Wl);
             const size_t ob = ((size_t)y2 * p.Wl + x2) * p.C + kofs;
-            rbh[j] = okb ? *reinterpret_cast<const uint4*>(p.lrh + ob) : zero;
-            if (SPLIT) rbl[j] = okb ? *reinterpret_cast<const uint4*>(p.lrl + ob) : zero;
+            rbh[j] = okb ? *reinterpret_cast<const u32x4*>(p.lrh + ob) : zero;
+            if (SPLIT) rbl[j] = okb ? *reinterpret_cast<const u32x4*>(p.lrl + ob) : zero;
         }
     };
     auto store_tile = [&](int buf) {
@@ -110,10 +110,10 @@ __global__ __launch_bounds__(256) void corr_bf16_kernel(const CorrParams p) {
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const int o = (lrow + RPP * j) * PITCH + lcol * 2;
-            *reinterpret_cast<uint4*>(base + o) = rah[j];
-            if (SPLIT) *reinterpret_cast<uint4*>(base + T_BYTES + o) = ral[j];
-            *reinterpret_cast<uint4*>(base + NPART * T_BYTES + o) = rbh[j];
-            if (SPLIT) *reinterpret_cast<uint4*>(base + (NPART + 1) * T_BYTES + o) = rbl[j];
+            *reinterpret_cast<u32x4*>(base + o) = rah[j];
+            if (SPLIT) *reinterpret_cast<u32x4*>(base + T_BYTES + o) = ral[j];
+            *reinterpret_cast<u32x4*>(base + NPART * T_BYTES + o) = rbh[j];
+            if (SPLIT) *reinterpret_cast<u32x4*>(base + (NPART + 1) * T_BYTES + o) = rbl[j];
         }
     };
 

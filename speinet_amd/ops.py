@@ -264,9 +264,10 @@ def corr_argmax(lr: FMap, ref: FMap, inv_lr: torch.Tensor, inv_ref: torch.Tensor
         lo = torch.empty_like(hi) if split else None
         _lib.check(lib.spei_split_bf16(_vp(f.ptr), f.ld, _tp(hi), _tp(lo), f.H * f.W, f.C, _stream()), "spei_split_bf16")
         parts += [hi, lo]
+    fn, name = (lib.spei_corr_slab_bf16, "spei_corr_slab_bf16") if (USE_SLAB and lr.C == 128) else (lib.spei_corr_argmax_bf16, "spei_corr_argmax_bf16")
     with _timed("corr_argmax"):
-        _lib.check(lib.spei_corr_argmax_bf16(_tp(parts[0]), _tp(parts[1]), _tp(parts[2]), _tp(parts[3]), _tp(inv_lr), _tp(inv_ref),
-                                             lr.H, lr.W, ref.H, ref.W, lr.C, _tp(s), _tp(arg), _tp(ws), _stream()), "spei_corr_argmax_bf16")
+        _lib.check(fn(_tp(parts[0]), _tp(parts[1]), _tp(parts[2]), _tp(parts[3]), _tp(inv_lr), _tp(inv_ref),
+                                             lr.H, lr.W, ref.H, ref.W, lr.C, _tp(s), _tp(arg), _tp(ws), _stream()), name)
     return s, arg
 
 
