@@ -137,14 +137,12 @@ def main():
     ops.PROFILE = None
     corr_ms = sum(s.elapsed_time(e) for s, e in prof) / max(1, len(prof))
 
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    gathered = [checksum.clone()]
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        gathered = [torch.zeros_like(checksum) for _ in range(world)]
-        dist.all_gather(gathered, checksum)          # the only payload that crosses xGMI: per-rank output checksums
-    tmax = tmax.item()
-    assert all(torch.isfinite(g).all() for g in gathered), "non-finite output"
+    from speinet_amd.dist import gather_metrics, max_over_ranks
+    tmax = max_over_ranks(dt, dev, dist)
+    # the only payload that crosses xGMI: one [checksum, frames] row per rank
+    gathered = gather_metrics(torch.cat((checksum, torch.tensor([float(args.steps)], device=dev, dtype=torch.float64))), dist)
+    assert torch.isfinite(gathered).all(), "non-finite output"
+    assert int(gathered[:, 1].sum().item()) == world * args.steps
 
     if rank == 0:
         fps = world * args.steps / tmax
@@ -163,7 +161,7 @@ def main():
                          "algorithmic_flops_per_launch": corr_flops(h, w),
                          "path_flops_per_frame": path_flops(h, w),
                          "path_frac": path_flops(h, w) * fps / world / 1e12 / peak},
-            "checksum": float(sum(g.item() for g in gathered)),
+            "checksum": float(gathered[:, 0].sum().item()),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(1234)

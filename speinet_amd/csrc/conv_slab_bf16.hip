@@ -13,6 +13,7 @@
 //   3. applies the same epilogue as the other GEMM kernels (bias, ReLU/GELU, per-pixel scale, residual).
 // HBM sees every input pixel once per output tile (+halo) instead of once per tap.
 // Call sites replaced: as igemm_f32.hip (convolutions with stride 1/2 and linears; transposed convs stay there).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -41,6 +42,8 @@ struct SlabParams {
     int c4_shift;            // log2(K/4) or -1 when K/4 is not a power of two
     int iw_magic;            // ceil(2^20 / IW): pix / IW == (pix * iw_magic) >> 20 for pix < 2048
     int n_chunks;            // 32*WN*TN-column chunks looped inside the workgroup (gridDim.y == 1)
+    int dbg;                 // ablation switches for tools/ablate_slab.py (0 in production): 1 no staging loads,
+                             // 2 no MFMA loop, 4 no epilogue stores
 };
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
                     const int iy = (int)(((unsigned)pix * (unsigned)p.iw_magic) >> 20), ix = pix - iy * p.IW;
                     const int gy = gy0 + iy, gx = gx0 + ix;
                     off[u] = pix * pitch + c * 2;
-                    if (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win) {
+                    if (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win && !(p.dbg & 1)) {
                         const size_t gp = (size_t)gy * p.Win + gx;
                         v[u] = (c < p.k0) ? *reinterpret_cast<const float4*>(p.a0 + gp * p.lda0 + c)
                                           : *reinterpret_cast<const float4*>(p.a1 + gp * p.lda1 + (c - p.k0));
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    for (int g0 = 0; g0 < ngroups; g0 += RING) {
+    for (int g0 = 0; g0 < ((p.dbg & 2) ? 0 : ngroups); g0 += RING) {
 #pragma unroll
         for (int d = 0; d < RING; ++d) {
             const int g = g0 + d;
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
                 const int pt = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk_e;
                 const int py = pt >> p.tw_shift, px = pt - (py << p.tw_shift);
                 const int oy = oy0 + py, ox = ox0 + px;
-                if (oy < p.Hout && ox < p.Wout) {
+                if (oy < p.Hout && ox < p.Wout && !(p.dbg & 4)) {
                     const size_t m = (size_t)oy * p.Wout + ox;
                     float v = acc[i][j][r] + bias;
                     if (p.act == SPEI_ACT_RELU) v = fmaxf(v, 0.f);
@@ -244,6 +247,8 @@ int launch(const SlabParams& p, size_t lds, hipStream_t s) {
     }
     SlabParams q = p;
     q.n_chunks = p.N / (WN * TN * 32);
+    static const int dbg = getenv("SPEI_SLAB_DBG") ? atoi(getenv("SPEI_SLAB_DBG")) : 0;
+    q.dbg = dbg;
     dim3 grid(p.tiles_x * cdiv(p.Hout, p.TH), 1);
     hipLaunchKernelGGL((conv_slab_kernel<WM, WN, TM, TN, SPLIT>), grid, dim3(256), lds, s, q);
     SPEI_CHECK_LAUNCH("spei_conv_slab_bf16");
@@ -276,7 +281,8 @@ int dispatch(SlabParams& p, hipStream_t s) {
     if (p.N % 128 == 0) {
         size_t lds = setup(128);
         const int64_t tiles128 = (int64_t)p.tiles_x * cdiv(p.Hout, p.TH);
-        if (lds <= budget && tiles128 >= 1024) return launch<1, 4, 4, 1, SPLIT>(p, lds, s);
+        static const int min_tiles = getenv("SPEI_SLAB_MIN_TILES128") ? atoi(getenv("SPEI_SLAB_MIN_TILES128")) : 1024;
+        if (lds <= budget && tiles128 >= min_tiles) return launch<1, 4, 4, 1, SPLIT>(p, lds, s);
         lds = setup(64);
         if (lds <= 160 * 1024 - 512) return launch<1, 4, 2, 1, SPLIT>(p, lds, s);
         spei_set_error("spei_conv_slab_bf16: slab of %zu bytes does not fit LDS", lds);
