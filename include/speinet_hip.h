@@ -74,11 +74,13 @@ int spei_igemm_bf16(const float* a0, int lda0, int k0, const float* a1, int lda1
 
 /* Slab-resident variant of spei_igemm_bf16 for SPEI_CONV (stride 1/2) and linears: the input tile + halo is staged
  * once into LDS as bf16 and the weights stream from HBM/L2 in MFMA fragment order
- * (wfrag: [N/32][tap][K/16][64][8] bf16, see speinet_amd/pack.py).  Linears: pass Hin = Hout = M, Win = Wout = 1. */
-int spei_conv_slab_bf16(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* wfrag_hi,
-                        const void* wfrag_lo, const float* bias, float* out, int ldo, const float* residual, int ldr,
-                        const float* rowscale, int Hin, int Win, int Hout, int Wout, int N, int ksize, int stride,
-                        int pad, int act, spei_stream_t stream);
+ * (wfrag: [N/32][tap][K/16][64][8] bf16, see speinet_amd/pack.py).  Linears: pass Hin = Hout = M, Win = Wout = 1.
+ * a_bf16 / out_bf16: the activations (both sources) / the output are bf16 instead of fp32 in HBM — used for tensors
+ * that only feed the next GEMM or the attention kernel; residual, rowscale and bias stay fp32. */
+int spei_conv_slab_bf16(const void* a0, int lda0, int k0, const void* a1, int lda1, int k1, int a_bf16,
+                        const void* wfrag_hi, const void* wfrag_lo, const float* bias, void* out, int ldo, int out_bf16,
+                        const float* residual, int ldr, const float* rowscale, int Hin, int Win, int Hout, int Wout,
+                        int N, int ksize, int stride, int pad, int act, spei_stream_t stream);
 
 /* K3 — ResBlock gates (model/block.py:8-24 SE, 71-96 ZPool+AttentionGate1/2, 108-124 TripletAttention).
  * x1: conv2 output [H][W][C].  Workspace `ws` floats: spei_gate_ws_floats(H,W,C).
@@ -95,14 +97,15 @@ int spei_resblock_apply(const float* x, const float* x1, const float* s, const f
                         const float* extra, float* out, int ldo, int H, int W, int C, spei_stream_t stream);
 
 /* K7 — LayerNorm over C=256, eps 1e-5 (model/swinir.py:244-245,279,528-529,776).  gamma/beta may be NULL
- * (affine folded into the following linear by pack.py). */
-int spei_layernorm256(const float* x, float* y, const float* gamma, const float* beta, int64_t M,
+ * (affine folded into the following linear by pack.py); out_bf16: y is bf16 (it only feeds a GEMM). */
+int spei_layernorm256(const float* x, void* y, int out_bf16, const float* gamma, const float* beta, int64_t M,
                       spei_stream_t stream);
 
 /* K8 — window attention core: cyclic shift, 5x5 partition, softmax(q k^T + relbias + shift mask) v, reverse
  * (model/swinir.py:115-149, 215-236, 250-275).  q [H*W][256] (scale folded), kv [H*W][512] (K then V, head major),
- * relbias [8][25][25] pre-gathered, out [H*W][256]; heads = 8, head_dim = 32, window 5. */
-int spei_window_attention(const float* q, const float* kv, const float* relbias, float* out, int H, int W,
+ * relbias [8][25][25] pre-gathered, out [H*W][256]; heads = 8, head_dim = 32, window 5.  io_bf16: q, kv and out
+ * are bf16 in HBM (the arithmetic stays fp32 on the f32 MFMA). */
+int spei_window_attention(const void* q, const void* kv, int io_bf16, const float* relbias, void* out, int H, int W,
                           int shift, spei_stream_t stream);
 
 /* K10 — 1 / max(||unfold3x3(f)[p]||_2, 1e-12) per position (F.normalize, model/SearchTransfer.py:30-31). */

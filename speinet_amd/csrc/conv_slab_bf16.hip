@@ -4,13 +4,16 @@
 // ds_write -> barrier round trip per 16..64 MFMAs: at bf16 MFMA rates that loop is latency-bound.  Here each
 // 256-thread workgroup
 //   1. stages ONCE the input pixels its output tile needs — TH x 32 output pixels plus the (k-1) halo, ALL input
-//      channels — into LDS as bf16 (fp32 in HBM -> cvt -> LDS; optional second slab with the bf16 residual for the
-//      split "bf16x3" mode), pixel pitch 2*K+16 bytes (odd multiple of 16 B => conflict-free ds_read_b128);
+//      channels — into LDS as bf16 (fp32 in HBM -> cvt -> LDS, or bf16 in HBM -> LDS unchanged; optional second
+//      slab with the bf16 residual for the split "bf16x3" mode), pixel pitch 2*K+16 bytes (odd multiple of 16 B =>
+//      conflict-free ds_read_b128);
 //   2. runs a BARRIER-FREE main loop: per (tap, 32-wide K group) every wave reads its A fragments from the slab at
 //      a tap-shifted address and takes its B fragments straight from global memory, where the weights were
 //      pre-packed on the host in MFMA fragment order ([n-tile][tap][k-step][lane][8] bf16: one fully coalesced
-//      1 KiB load per fragment), prefetched four groups ahead in a register ring;
-//   3. applies the same epilogue as the other GEMM kernels (bias, ReLU/GELU, per-pixel scale, residual).
+//      1 KiB load per fragment), prefetched four groups ahead in a register ring; all output-channel chunks are
+//      looped inside the workgroup so the slab is staged once;
+//   3. applies the same epilogue as the other GEMM kernels (bias, ReLU/GELU, per-pixel scale, residual) and writes
+//      fp32 (residual streams) or bf16 (tensors that only feed the next GEMM / the attention kernel).
 // HBM sees every input pixel once per output tile (+halo) instead of once per tap.
 // Call sites replaced: as igemm_f32.hip (convolutions with stride 1/2 and linears; transposed convs stay there).
 #include <stdlib.h>
@@ -22,12 +25,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 struct SlabParams {
-    const float* a0;
-    const float* a1;
+    const void* a0;
+    const void* a1;
     const __bf16* wh;    // fragment-ordered
     const __bf16* wl;
     const float* bias;
-    float* out;
+    void* out;
     const float* res;
     const float* rowscale;
     int lda0, lda1, k0, k1;
@@ -39,24 +42,61 @@ struct SlabParams {
     int tiles_x;
     int slab_bytes;          // bytes of one slab (hi); lo follows when SPLIT
     int tw_shift;            // log2(TW): 5 (2-D maps, 32-pixel tile rows) or 0 (token lists)
-    int c4_shift;            // log2(K/4) or -1 when K/4 is not a power of two
+    int cp_shift;            // log2(16-byte chunks per pixel) or -1 when that count is not a power of two <= 256
     int iw_magic;            // ceil(2^20 / IW): pix / IW == (pix * iw_magic) >> 20 for pix < 2048
-    int n_chunks;            // 32*WN*TN-column chunks looped inside the workgroup (gridDim.y == 1)
+    int goff_bytes;          // bytes reserved for the group offset table (multiple of 16)
+    int n_chunks;            // 32*WN*TN-column chunks looped inside the workgroup
     int dbg;                 // ablation switches for tools/ablate_slab.py (0 in production): 1 no staging loads,
                              // 2 no MFMA loop, 4 no epilogue stores
 };
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
+constexpr int EP = 36;      // epilogue tile row pitch (floats): 16-byte aligned rows, write conflict-free
 constexpr int G = 2;        // k-steps (of 16) per group
 constexpr int RING = 4;     // groups of B fragments in flight
 
-template <int WM, int WN, int TM, int TN, bool SPLIT>
+// one 16-byte global chunk -> LDS: 4 fp32 -> 4 bf16 (8 B) [+ residual], or 8 bf16 unchanged (16 B)
+template <typename TA, bool SPLIT>
+struct Stage;
+template <bool SPLIT>
+struct Stage<float, SPLIT> {
+    static constexpr int CH = 4;                       // channels per chunk
+    typedef f32x4 reg_t;
+    static __device__ __forceinline__ reg_t zero() { return reg_t{0.f, 0.f, 0.f, 0.f}; }
+    static __device__ __forceinline__ void put(unsigned char* slab, int slab_bytes, int off, const reg_t v) {
+        bf16x4 h;
+        h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+        *reinterpret_cast<bf16x4*>(slab + off) = h;
+        if (SPLIT) {
+            bf16x4 l;
+            l[0] = (__bf16)(v[0] - (float)h[0]); l[1] = (__bf16)(v[1] - (float)h[1]);
+            l[2] = (__bf16)(v[2] - (float)h[2]); l[3] = (__bf16)(v[3] - (float)h[3]);
+            *reinterpret_cast<bf16x4*>(slab + slab_bytes + off) = l;
+        }
+    }
+};
+template <bool SPLIT>
+struct Stage<__bf16, SPLIT> {
+    static constexpr int CH = 8;
+    typedef u32x4 reg_t;
+    static __device__ __forceinline__ reg_t zero() { return reg_t{0u, 0u, 0u, 0u}; }
+    static __device__ __forceinline__ void put(unsigned char* slab, int, int off, const reg_t v) {
+        *reinterpret_cast<reg_t*>(slab + off) = v;
+    }
+};
+
+template <int WM, int WN, int TM, int TN, bool SPLIT, typename TA, typename TO>
 __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
+    typedef Stage<TA, SPLIT> ST;
+    typedef typename ST::reg_t sreg_t;
+    constexpr int CH = ST::CH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int pitch = 2 * p.K + 16;
     unsigned char* slab = smem;
     int* goff = reinterpret_cast<int*>(smem + (SPLIT ? 2 : 1) * p.slab_bytes);
+    // per-wave 32 x 32 fp32 staging tile (row pitch 36 floats) for the transposing epilogue
+    float* etile = reinterpret_cast<float*>(smem + (SPLIT ? 2 : 1) * p.slab_bytes + p.goff_bytes) + (threadIdx.x >> 6) * (32 * EP);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -74,46 +114,58 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
         goff[g] = (ty * p.IW + tx) * pitch + kg * (G * 32);
     }
 
-    // ---- stage the input slab: fp32 -> bf16 (hi [, lo]) ----------------------------------------------
+    // ---- stage the input slab ----------------------------------------------------------------------------------
     {
-        const int c4n = p.K / 4;
-        const int total = p.IH * p.IW * c4n;
+        const TA* a0 = static_cast<const TA*>(p.a0);
+        const TA* a1 = static_cast<const TA*>(p.a1);
+        const int cpn = p.K / CH;                         // 16-byte chunks per pixel
+        const int npix = p.IH * p.IW;
         const int gy0 = oy0 * p.stride - p.pad, gx0 = ox0 * p.stride - p.pad;
         constexpr int U = 8;
-        for (int base = tid; base < total; base += 256 * U) {
-            float4 v[U];
-            int off[U];
+        if (p.cp_shift >= 0) {
+            // fixed channel chunk per thread, pixels walked with a constant step: no divisions in the loop
+            const int c = (tid & (cpn - 1)) * CH;
+            const int step = 256 >> p.cp_shift;
+            const int step_y = (int)(((unsigned)step * (unsigned)p.iw_magic) >> 20), step_x = step - step_y * p.IW;
+            int pix = tid >> p.cp_shift;
+            int iy = (int)(((unsigned)pix * (unsigned)p.iw_magic) >> 20), ix = pix - iy * p.IW;
+            const TA* src = (c < p.k0) ? a0 + c : a1 + (c - p.k0);
+            const int ld = (c < p.k0) ? p.lda0 : p.lda1;
+            const int lofs = c * 2;
+            while (pix < npix) {
+                // branch-free loads: clamp the coordinates to a valid pixel, select zero afterwards
+                sreg_t v[U];
+                int off[U];
+                bool ok[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int idx = base + u * 256;
-                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                off[u] = -1;
-                if (idx < total) {
-                    const int pix = p.c4_shift >= 0 ? (idx >> p.c4_shift) : idx / c4n;
-                    const int c = (idx - pix * c4n) * 4;
-                    const int iy = (int)(((unsigned)pix * (unsigned)p.iw_magic) >> 20), ix = pix - iy * p.IW;
+                for (int u = 0; u < U; ++u) {
                     const int gy = gy0 + iy, gx = gx0 + ix;
-                    off[u] = pix * pitch + c * 2;
-                    if (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win && !(p.dbg & 1)) {
-                        const size_t gp = (size_t)gy * p.Win + gx;
-                        v[u] = (c < p.k0) ? *reinterpret_cast<const float4*>(p.a0 + gp * p.lda0 + c)
-                                          : *reinterpret_cast<const float4*>(p.a1 + gp * p.lda1 + (c - p.k0));
-                    }
+                    off[u] = pix < npix ? pix * pitch + lofs : -1;
+                    ok[u] = (gy >= 0) & (gy < p.Hin) & (gx >= 0) & (gx < p.Win) & !(p.dbg & 1);
+                    const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
+                    v[u] = *reinterpret_cast<const sreg_t*>(src + ((size_t)cy * p.Win + cx) * ld);
+                    pix += step;
+                    ix += step_x;
+                    iy += step_y;
+                    if (ix >= p.IW) { ix -= p.IW; ++iy; }
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (off[u] >= 0) {
-                    bf16x4 h;
-                    h[0] = (__bf16)v[u].x; h[1] = (__bf16)v[u].y; h[2] = (__bf16)v[u].z; h[3] = (__bf16)v[u].w;
-                    *reinterpret_cast<bf16x4*>(slab + off[u]) = h;
-                    if (SPLIT) {
-                        bf16x4 l;
-                        l[0] = (__bf16)(v[u].x - (float)h[0]); l[1] = (__bf16)(v[u].y - (float)h[1]);
-                        l[2] = (__bf16)(v[u].z - (float)h[2]); l[3] = (__bf16)(v[u].w - (float)h[3]);
-                        *reinterpret_cast<bf16x4*>(slab + p.slab_bytes + off[u]) = l;
-                    }
+                for (int u = 0; u < U; ++u)
+                    if (off[u] >= 0) ST::put(slab, p.slab_bytes, off[u], ok[u] ? v[u] : ST::zero());
+            }
+        } else {
+            const int total = npix * cpn;
+            for (int idx = tid; idx < total; idx += 256) {
+                const int pix = idx / cpn, c = (idx - pix * cpn) * CH;
+                const int iy = pix / p.IW, ix = pix - iy * p.IW;
+                const int gy = gy0 + iy, gx = gx0 + ix;
+                sreg_t v = ST::zero();
+                if (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win && !(p.dbg & 1)) {
+                    const size_t gp = (size_t)gy * p.Win + gx;
+                    v = (c < p.k0) ? *reinterpret_cast<const sreg_t*>(a0 + gp * p.lda0 + c)
+                                   : *reinterpret_cast<const sreg_t*>(a1 + gp * p.lda1 + (c - p.k0));
                 }
+                ST::put(slab, p.slab_bytes, pix * pitch + c * 2, v);
             }
         }
     }
@@ -133,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
     auto set_chunk = [&](int nc) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int nt = ((blockIdx.y * p.n_chunks + nc) * WN + wn) * TN + j;
+            const int nt = (nc * WN + wn) * TN + j;
             bptr[j] = p.wh + nt * frag_per_nt + lane * 8;
             bptr_lo[j] = SPLIT ? p.wl + nt * frag_per_nt + lane * 8 : nullptr;
         }
@@ -160,88 +212,123 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
 
     __syncthreads();     // slab + offset table visible; the only barrier of the kernel
 
-  for (int nc = 0; nc < p.n_chunks; ++nc) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    for (int g0 = 0; g0 < ((p.dbg & 2) ? 0 : ngroups); g0 += RING) {
-#pragma unroll
-        for (int d = 0; d < RING; ++d) {
-            const int g = g0 + d;
-            if (g < ngroups) {
-                const int go = goff[g];
-#pragma unroll
-                for (int s = 0; s < G; ++s) {
-                    bf16x8 av[TM], avl[SPLIT ? TM : 1];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        av[i] = *reinterpret_cast<const bf16x8*>(slab + abase[i] + go + s * 32);
-                        if (SPLIT) avl[i] = *reinterpret_cast<const bf16x8*>(slab + p.slab_bytes + abase[i] + go + s * 32);
-                    }
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) {
-                            if (SPLIT) {
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avl[i], bring[d][s][j], acc[i][j], 0, 0, 0);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bring_lo[SPLIT ? d : 0][s][j], acc[i][j], 0, 0, 0);
-                            }
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bring[d][s][j], acc[i][j], 0, 0, 0);
-                        }
-                }
-                if (g + RING < ngroups) load_b(d, g + RING);
-            }
-        }
-    }
-    // start the next chunk's weight stream before the epilogue's stores
-    const int nbase = ((blockIdx.y * p.n_chunks + nc) * WN + wn) * TN;
-    if (nc + 1 < p.n_chunks) {
-        set_chunk(nc + 1);
-#pragma unroll
-        for (int d = 0; d < RING; ++d)
-            if (d < ngroups) load_b(d, d);
-    }
-
-    // ---- epilogue ------------------------------------------------------------------------------------------
-    // Row / address math is invariant across the chunk loop: launder one input so the compiler does not hoist
-    // ~200 registers of addresses out of the loop and starve the main loop (measured: 255 VGPRs, serialised MFMAs).
-    int fk_e = fk;
-    asm volatile("" : "+v"(fk_e));
+    // output row bookkeeping: in both tilings (TH x 32 pixels of a map, TH x 1 tokens) consecutive tile pixels are
+    // consecutive output rows, so row(m-tile i, q) = mbase[i] + q with q = (r&3) + 8*(r>>2) + 4*fk in [0,32)
+    int mbase[TM], qlim[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        const int pt0 = (wm * TM + i) * 32;
+        if (p.tw_shift == 5) {
+            const int oy = oy0 + (pt0 >> 5);
+            mbase[i] = oy * p.Wout + ox0;
+            qlim[i] = oy < p.Hout ? p.Wout - ox0 : 0;
+        } else {
+            mbase[i] = oy0 + pt0;
+            qlim[i] = p.Hout - oy0 - pt0;
+        }
+    }
+
+    for (int nc = 0; nc < p.n_chunks; ++nc) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = (nbase + j) * 32 + fr;
-            const float bias = p.bias ? p.bias[n] : 0.f;
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pt = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk_e;
-                const int py = pt >> p.tw_shift, px = pt - (py << p.tw_shift);
-                const int oy = oy0 + py, ox = ox0 + px;
-                if (oy < p.Hout && ox < p.Wout && !(p.dbg & 4)) {
-                    const size_t m = (size_t)oy * p.Wout + ox;
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        for (int g0 = 0; g0 < ((p.dbg & 2) ? 0 : ngroups); g0 += RING) {
+#pragma unroll
+            for (int d = 0; d < RING; ++d) {
+                const int g = g0 + d;
+                if (g < ngroups) {
+                    const int go = goff[g];
+#pragma unroll
+                    for (int s = 0; s < G; ++s) {
+                        bf16x8 av[TM], avl[SPLIT ? TM : 1];
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            av[i] = *reinterpret_cast<const bf16x8*>(slab + abase[i] + go + s * 32);
+                            if (SPLIT) avl[i] = *reinterpret_cast<const bf16x8*>(slab + p.slab_bytes + abase[i] + go + s * 32);
+                        }
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) {
+                                if (SPLIT) {
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avl[i], bring[d][s][j], acc[i][j], 0, 0, 0);
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bring_lo[SPLIT ? d : 0][s][j], acc[i][j], 0, 0, 0);
+                                }
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bring[d][s][j], acc[i][j], 0, 0, 0);
+                            }
+                    }
+                    if (g + RING < ngroups) load_b(d, g + RING);
+                }
+            }
+        }
+        // start the next chunk's weight stream before the epilogue's stores
+        const int nbase = (nc * WN + wn) * TN;
+        if (nc + 1 < p.n_chunks) {
+            set_chunk(nc + 1);
+#pragma unroll
+            for (int d = 0; d < RING; ++d)
+                if (d < ngroups) load_b(d, d);
+        }
+
+        // ---- epilogue ----------------------------------------------------------------------------------------
+        // Row / address math is invariant across the chunk loop: launder one input so the compiler does not hoist
+        // ~200 registers of addresses out of the loop and starve the main loop (measured: 255 VGPRs, serialised MFMAs).
+        // The accumulator holds one column (n) per lane and 16 rows in registers: stored directly that is 4 bytes per
+        // lane per instruction.  Transpose each 32 x 32 tile through a per-wave LDS tile instead, so that every lane owns
+        // 4 consecutive channels of one output row: residual loads and stores are 16 B per lane, 8 full 128-byte row
+        // segments per instruction (4 instead of 16 store instructions per tile).
+        int fk_e = fk;
+        asm volatile("" : "+v"(fk_e));
+        TO* outp = static_cast<TO*>(p.out);
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int erow = lane_e >> 3, ecol = (lane_e & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int ncol0 = (nbase + j) * 32;
+                const float bias = p.bias ? p.bias[ncol0 + fr] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int q = (r & 3) + 8 * (r >> 2) + 4 * fk_e;
                     float v = acc[i][j][r] + bias;
                     if (p.act == SPEI_ACT_RELU) v = fmaxf(v, 0.f);
                     else if (p.act == SPEI_ACT_GELU) v = gelu_erf(v);
-                    if (p.rowscale) v *= p.rowscale[m];
-                    if (p.res) v += p.res[m * p.ldr + n];
-                    p.out[m * p.ldo + n] = v;
+                    etile[q * EP + fr] = v;
+                }
+                // same wave wrote and reads: DS operations of one wave complete in order, no barrier needed
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int q = erow + 8 * k;
+                    if (q < qlim[i] && !(p.dbg & 4)) {
+                        const unsigned m = (unsigned)(mbase[i] + q);
+                        f32x4 v = *reinterpret_cast<const f32x4*>(etile + q * EP + ecol);
+                        if (p.rowscale) { const float rs = p.rowscale[m]; v *= rs; }
+                        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * (unsigned)p.ldr + ncol0 + ecol);
+                        if (sizeof(TO) == 4) {
+                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + m * (unsigned)p.ldo + ncol0 + ecol) = v;
+                        } else {
+                            bf16x4 h;
+                            h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+                            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(outp) + m * (unsigned)p.ldo + ncol0 + ecol) = h;
+                        }
+                    }
                 }
             }
         }
-    }
-  }   // n chunks
+    }   // n chunks
 }
 
-template <int WM, int WN, int TM, int TN, bool SPLIT>
+template <int WM, int WN, int TM, int TN, bool SPLIT, typename TA, typename TO>
 int launch(const SlabParams& p, size_t lds, hipStream_t s) {
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_slab_kernel<WM, WN, TM, TN, SPLIT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_slab_kernel<WM, WN, TM, TN, SPLIT, TA, TO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_lds = lds;
     }
@@ -250,18 +337,19 @@ int launch(const SlabParams& p, size_t lds, hipStream_t s) {
     static const int dbg = getenv("SPEI_SLAB_DBG") ? atoi(getenv("SPEI_SLAB_DBG")) : 0;
     q.dbg = dbg;
     dim3 grid(p.tiles_x * cdiv(p.Hout, p.TH), 1);
-    hipLaunchKernelGGL((conv_slab_kernel<WM, WN, TM, TN, SPLIT>), grid, dim3(256), lds, s, q);
+    hipLaunchKernelGGL((conv_slab_kernel<WM, WN, TM, TN, SPLIT, TA, TO>), grid, dim3(256), lds, s, q);
     SPEI_CHECK_LAUNCH("spei_conv_slab_bf16");
     return 0;
 }
 
-template <bool SPLIT>
+template <bool SPLIT, typename TA, typename TO>
 int dispatch(SlabParams& p, hipStream_t s) {
     const int pitch = 2 * p.K + 16;
     const int nparts = SPLIT ? 2 : 1;
     const int T = p.ks * p.ks;
     const int ngroups = T * (p.K / 32);
     const bool linear = (p.Wout == 1 && p.ks == 1);
+    constexpr int CH = sizeof(TA) == 4 ? 4 : 8;
     // tile rows x 32 pixels (2-D maps) or rows x 1 (token lists); pick the largest tile whose slab(s) fit ~96 KB
     auto setup = [&](int mtile) {
         if (linear) { p.TH = mtile; p.TW = 1; }
@@ -271,57 +359,62 @@ int dispatch(SlabParams& p, hipStream_t s) {
         p.slab_bytes = ((p.IH * p.IW * pitch + 15) / 16) * 16;
         p.tiles_x = cdiv(p.Wout, p.TW);
         p.tw_shift = linear ? 0 : 5;
-        const int c4n = p.K / 4;
-        p.c4_shift = -1;
-        for (int sft = 0; sft < 12; ++sft) if ((1 << sft) == c4n) p.c4_shift = sft;
+        const int cpn = p.K / CH;
+        p.cp_shift = -1;
+        for (int sft = 0; sft <= 8; ++sft) if ((1 << sft) == cpn) p.cp_shift = sft;
         p.iw_magic = ((1 << 20) + p.IW - 1) / p.IW;
-        return (size_t)nparts * p.slab_bytes + (size_t)ngroups * sizeof(int);
+        p.goff_bytes = ((ngroups * (int)sizeof(int) + 15) / 16) * 16;
+        return (size_t)nparts * p.slab_bytes + (size_t)p.goff_bytes + (size_t)4 * 32 * EP * sizeof(float);
     };
     const size_t budget = 96 * 1024;
+    const size_t hard = 160 * 1024 - 512;
+    size_t lds;
     if (p.N % 128 == 0) {
-        size_t lds = setup(128);
+        lds = setup(128);
         const int64_t tiles128 = (int64_t)p.tiles_x * cdiv(p.Hout, p.TH);
         static const int min_tiles = getenv("SPEI_SLAB_MIN_TILES128") ? atoi(getenv("SPEI_SLAB_MIN_TILES128")) : 1024;
-        if (lds <= budget && tiles128 >= min_tiles) return launch<1, 4, 4, 1, SPLIT>(p, lds, s);
+        if (lds <= budget && tiles128 >= min_tiles && p.IH * p.IW < 2048) return launch<1, 4, 4, 1, SPLIT, TA, TO>(p, lds, s);
         lds = setup(64);
-        if (lds <= 160 * 1024 - 512) return launch<1, 4, 2, 1, SPLIT>(p, lds, s);
-        spei_set_error("spei_conv_slab_bf16: slab of %zu bytes does not fit LDS", lds);
-        return -1;
+        if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 4, 2, 1, SPLIT, TA, TO>(p, lds, s);
+    } else if (p.N % 64 == 0) {
+        lds = setup(128);
+        if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 2, 2, 1, SPLIT, TA, TO>(p, lds, s);
+    } else {
+        lds = setup(256);
+        if (lds <= budget && p.IH * p.IW < 2048) return launch<4, 1, 2, 1, SPLIT, TA, TO>(p, lds, s);
+        lds = setup(128);
+        if (lds <= hard && p.IH * p.IW < 2048) return launch<4, 1, 1, 1, SPLIT, TA, TO>(p, lds, s);
     }
-    if (p.N % 64 == 0) {
-        size_t lds = setup(128);
-        if (lds <= 160 * 1024 - 512) return launch<2, 2, 2, 1, SPLIT>(p, lds, s);
-        spei_set_error("spei_conv_slab_bf16: slab of %zu bytes does not fit LDS", lds);
-        return -1;
-    }
-    size_t lds = setup(256);
-    if (lds > budget) lds = setup(128);
-    if (p.TH * p.TW == 256) return launch<4, 1, 2, 1, SPLIT>(p, lds, s);
-    if (lds <= 160 * 1024 - 512) return launch<4, 1, 1, 1, SPLIT>(p, lds, s);
-    spei_set_error("spei_conv_slab_bf16: slab of %zu bytes does not fit LDS", lds);
+    spei_set_error("spei_conv_slab_bf16: slab of %zu bytes (K=%d, k=%d, stride %d) does not fit LDS", lds, p.K, p.ks, p.stride);
     return -1;
 }
 
 }  // namespace
 
-extern "C" int spei_conv_slab_bf16(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1,
-                                   const void* wfrag_hi, const void* wfrag_lo, const float* bias, float* out, int ldo,
-                                   const float* residual, int ldr, const float* rowscale, int Hin, int Win, int Hout,
-                                   int Wout, int N, int ksize, int stride, int pad, int act, spei_stream_t stream) {
+extern "C" int spei_conv_slab_bf16(const void* a0, int lda0, int k0, const void* a1, int lda1, int k1, int a_bf16,
+                                   const void* wfrag_hi, const void* wfrag_lo, const float* bias, void* out, int ldo,
+                                   int out_bf16, const float* residual, int ldr, const float* rowscale, int Hin, int Win,
+                                   int Hout, int Wout, int N, int ksize, int stride, int pad, int act,
+                                   spei_stream_t stream) {
     SPEI_REQUIRE(a0 && wfrag_hi && out, "spei_conv_slab_bf16: null pointer");
     SPEI_REQUIRE(k0 > 0 && k0 % 32 == 0 && k1 >= 0 && k1 % 32 == 0, "spei_conv_slab_bf16: k0=%d k1=%d must be multiples of 32", k0, k1);
     SPEI_REQUIRE(k1 == 0 || a1, "spei_conv_slab_bf16: a1 missing");
     SPEI_REQUIRE(N > 0 && N % 32 == 0, "spei_conv_slab_bf16: N=%d must be a multiple of 32", N);
-    SPEI_REQUIRE(lda0 % 4 == 0 && (k1 == 0 || lda1 % 4 == 0) && ldo >= N && lda0 >= k0 && (k1 == 0 || lda1 >= k1),
+    const int ael = a_bf16 ? 8 : 4;
+    SPEI_REQUIRE(lda0 % ael == 0 && (k1 == 0 || lda1 % ael == 0) && ldo >= N && lda0 >= k0 && (k1 == 0 || lda1 >= k1),
                  "spei_conv_slab_bf16: bad row strides");
     SPEI_REQUIRE(ksize == 1 || ksize == 3 || ksize == 5, "spei_conv_slab_bf16: ksize=%d", ksize);
     SPEI_REQUIRE(stride == 1 || stride == 2, "spei_conv_slab_bf16: stride=%d", stride);
     SPEI_REQUIRE(Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "spei_conv_slab_bf16: empty map");
-    SPEI_REQUIRE((int64_t)Hout * Wout < (1ll << 30) && (int64_t)Hin * Win < (1ll << 30), "spei_conv_slab_bf16: map too large");
+    SPEI_REQUIRE((int64_t)Hout * Wout * (int64_t)(ldo > ldr ? ldo : ldr) < (1ll << 32) && (int64_t)Hin * Win < (1ll << 30),
+                 "spei_conv_slab_bf16: map too large for 32-bit element offsets");
     SPEI_REQUIRE(Hout == (Hin + 2 * pad - ksize) / stride + 1 && Wout == (Win + 2 * pad - ksize) / stride + 1,
                  "spei_conv_slab_bf16: output size %dx%d inconsistent with input %dx%d k%d s%d p%d", Hout, Wout, Hin, Win, ksize, stride, pad);
     SPEI_REQUIRE(((uintptr_t)a0 % 16 == 0) && ((uintptr_t)wfrag_hi % 16 == 0) && (!a1 || (uintptr_t)a1 % 16 == 0) &&
                  (!wfrag_lo || (uintptr_t)wfrag_lo % 16 == 0), "spei_conv_slab_bf16: operands must be 16-byte aligned");
+    SPEI_REQUIRE(!(wfrag_lo && (a_bf16 || out_bf16)), "spei_conv_slab_bf16: the split (bf16x3) mode keeps activations fp32");
+    SPEI_REQUIRE(ldo % 4 == 0 && (!residual || ldr % 4 == 0) && ((uintptr_t)out % 16 == 0) && (!residual || (uintptr_t)residual % 16 == 0),
+                 "spei_conv_slab_bf16: out / residual must be 16-byte aligned with row strides that are multiples of 4");
     SlabParams p;
     p.a0 = a0; p.a1 = a1; p.wh = (const __bf16*)wfrag_hi; p.wl = (const __bf16*)wfrag_lo; p.bias = bias; p.out = out;
     p.res = residual; p.rowscale = rowscale;
@@ -329,5 +422,8 @@ extern "C" int spei_conv_slab_bf16(const float* a0, int lda0, int k0, const floa
     p.N = N; p.K = k0 + k1;
     p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout;
     p.ks = ksize; p.stride = stride; p.pad = pad; p.act = act;
-    return wfrag_lo ? dispatch<true>(p, (hipStream_t)stream) : dispatch<false>(p, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (wfrag_lo) return dispatch<true, float, float>(p, st);
+    if (a_bf16) return out_bf16 ? dispatch<false, __bf16, __bf16>(p, st) : dispatch<false, __bf16, float>(p, st);
+    return out_bf16 ? dispatch<false, float, __bf16>(p, st) : dispatch<false, float, float>(p, st);
 }

@@ -7,7 +7,11 @@ namespace {
 // ---------------------------------------------------------------------------------------------------
 // LayerNorm over 256 channels: one wave per token, 4 channels per lane, two-pass moments in registers.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void layernorm256_kernel(const float* __restrict__ x, float* __restrict__ y,
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <typename TO>
+__global__ __launch_bounds__(256) void layernorm256_kernel(const float* __restrict__ x, TO* __restrict__ y,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            int64_t M) {
     const int lane = threadIdx.x & 63;
@@ -27,7 +31,13 @@ __global__ __launch_bounds__(256) void layernorm256_kernel(const float* __restri
         o.y = dy * rstd * g.y + b.y;
         o.z = dz * rstd * g.z + b.z;
         o.w = dw * rstd * g.w + b.w;
-        reinterpret_cast<float4*>(y + m * 256)[lane] = o;
+        if (sizeof(TO) == 4) {
+            reinterpret_cast<float4*>(y + m * 256)[lane] = o;
+        } else {
+            bf16x4 h;
+            h[0] = (__bf16)o.x; h[1] = (__bf16)o.y; h[2] = (__bf16)o.z; h[3] = (__bf16)o.w;
+            reinterpret_cast<bf16x4*>(y + m * 256)[lane] = h;
+        }
     }
 }
 
@@ -46,8 +56,19 @@ __device__ __forceinline__ int mask_region(int v, int n, int shift) {
     return v < n - WS ? 0 : (v < n - shift ? 1 : 2);
 }
 
-__global__ __launch_bounds__(256) void window_attention_kernel(const float* __restrict__ q, const float* __restrict__ kv,
-                                                               const float* __restrict__ relbias, float* __restrict__ out,
+template <typename T>
+__device__ __forceinline__ float4 load4(const T* p);
+template <>
+__device__ __forceinline__ float4 load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <>
+__device__ __forceinline__ float4 load4<__bf16>(const __bf16* p) {
+    const bf16x4 h = *reinterpret_cast<const bf16x4*>(p);
+    return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void window_attention_kernel(const T* __restrict__ q, const T* __restrict__ kv,
+                                                               const float* __restrict__ relbias, T* __restrict__ out,
                                                                int H, int W, int shift) {
     __shared__ float sQ[4][32][LDT], sK[4][32][LDT], sV[4][32][LDT];
     __shared__ int tok_pix[32], tok_reg[32];
@@ -77,9 +98,9 @@ __global__ __launch_bounds__(256) void window_attention_kernel(const float* __re
         float4 vq = make_float4(0.f, 0.f, 0.f, 0.f), vk = vq, vv = vq;
         if (r < NT) {
             const size_t p = (size_t)tok_pix[r];
-            vq = *reinterpret_cast<const float4*>(q + p * 256 + h * HD + c4);
-            vk = *reinterpret_cast<const float4*>(kv + p * 512 + h * HD + c4);
-            vv = *reinterpret_cast<const float4*>(kv + p * 512 + 256 + h * HD + c4);
+            vq = load4<T>(q + p * 256 + h * HD + c4);
+            vk = load4<T>(kv + p * 512 + h * HD + c4);
+            vv = load4<T>(kv + p * 512 + 256 + h * HD + c4);
         }
         float* d = &sQ[hl][r][c4]; d[0] = vq.x; d[1] = vq.y; d[2] = vq.z; d[3] = vq.w;
         d = &sK[hl][r][c4];        d[0] = vk.x; d[1] = vk.y; d[2] = vk.z; d[3] = vk.w;
@@ -130,28 +151,31 @@ __global__ __launch_bounds__(256) void window_attention_kernel(const float* __re
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int qq = (r & 3) + 8 * (r >> 2) + 4 * fk;
-        if (qq < NT) out[(size_t)tok_pix[qq] * 256 + h * HD + fr] = o[r];
+        if (qq < NT) out[(size_t)tok_pix[qq] * 256 + h * HD + fr] = (T)o[r];
     }
 }
 
 }  // namespace
 
-extern "C" int spei_layernorm256(const float* x, float* y, const float* gamma, const float* beta, int64_t M,
+extern "C" int spei_layernorm256(const float* x, void* y, int out_bf16, const float* gamma, const float* beta, int64_t M,
                                  spei_stream_t stream) {
     SPEI_REQUIRE(x && y && M > 0, "spei_layernorm256: bad arguments");
     const int64_t blocks = (M + 3) / 4;
-    hipLaunchKernelGGL(layernorm256_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream,
-                       x, y, gamma, beta, M);
+    const dim3 grid((unsigned)(blocks < 8192 ? blocks : 8192));
+    if (out_bf16) hipLaunchKernelGGL(layernorm256_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, x, (__bf16*)y, gamma, beta, M);
+    else hipLaunchKernelGGL(layernorm256_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, (float*)y, gamma, beta, M);
     SPEI_CHECK_LAUNCH("spei_layernorm256");
     return 0;
 }
 
-extern "C" int spei_window_attention(const float* q, const float* kv, const float* relbias, float* out, int H, int W,
+extern "C" int spei_window_attention(const void* q, const void* kv, int io_bf16, const float* relbias, void* out, int H, int W,
                                      int shift, spei_stream_t stream) {
     SPEI_REQUIRE(q && kv && relbias && out, "spei_window_attention: null pointer");
     SPEI_REQUIRE(H > 0 && W > 0 && H % WS == 0 && W % WS == 0, "spei_window_attention: %dx%d is not a multiple of the 5x5 window", H, W);
     SPEI_REQUIRE(shift >= 0 && shift < WS, "spei_window_attention: shift=%d", shift);
-    hipLaunchKernelGGL(window_attention_kernel, dim3(2 * (H / WS) * (W / WS)), dim3(256), 0, (hipStream_t)stream, q, kv, relbias, out, H, W, shift);
+    const dim3 grid(2 * (H / WS) * (W / WS));
+    if (io_bf16) hipLaunchKernelGGL(window_attention_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)q, (const __bf16*)kv, relbias, (__bf16*)out, H, W, shift);
+    else hipLaunchKernelGGL(window_attention_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)q, (const float*)kv, relbias, (float*)out, H, W, shift);
     SPEI_CHECK_LAUNCH("spei_window_attention");
     return 0;
 }

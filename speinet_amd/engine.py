@@ -57,15 +57,16 @@ def swin(sx: SwinX, feat: FMap, sw: dict, out: FMap) -> FMap:
     dev = feat.t.device
     y_first = ops.igemm(feat, sw["conv_first_w"], sw["conv_first_b"], 256, ksize=3)
     yt = ops.layernorm(y_first.t, sw["pe_g"], sw["pe_b"])
-    yhat = ops.layernorm(yt)                      # norm1(y) without affine; gamma/beta live in wq/bq (pack.py)
+    idt = ops.inter_dtype()                       # bf16 in the throughput mode: these tensors only feed GEMMs / attention
+    yhat = ops.layernorm(yt, out_dtype=idt)       # norm1(y) without affine; gamma/beta live in wq/bq (pack.py)
     del y_first, yt
     r = sx.xt0.clone()                            # RSTB input / running residual
     bufs = [torch.empty(m, 256, device=dev), torch.empty(m, 256, device=dev)]
-    xh = torch.empty(m, 256, device=dev)
-    q = torch.empty(m, 256, device=dev)
-    kv = torch.empty(m, 512, device=dev)
-    att = torch.empty(m, 256, device=dev)
-    hid = torch.empty(m, 512, device=dev)
+    xh = torch.empty(m, 256, device=dev, dtype=idt)
+    q = torch.empty(m, 256, device=dev, dtype=idt)
+    kv = torch.empty(m, 512, device=dev, dtype=idt)
+    att = torch.empty(m, 256, device=dev, dtype=idt)
+    hid = torch.empty(m, 512, device=dev, dtype=idt)
     for layer in sw["layers"]:
         cur = r
         for bi, bk in enumerate(layer["blocks"]):

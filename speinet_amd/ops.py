@@ -24,6 +24,12 @@ CONV, CONV_T = 0, 1
 PRECISION = "f32"
 CORR_PRECISION = "bf16x3"
 USE_SLAB = True      # bf16 modes: slab-resident conv/linear kernel (conv_slab_bf16.hip) instead of igemm_bf16.hip
+BF16_STORAGE = True  # "bf16" mode: tensors that only feed the next GEMM / the attention kernel live in HBM as bf16
+
+
+def inter_dtype() -> torch.dtype:
+    """Storage type of GEMM-only intermediates (x-hat, q, kv, attention output, MLP hidden, ResBlock conv1 output)."""
+    return torch.bfloat16 if (PRECISION == "bf16" and USE_SLAB and BF16_STORAGE) else torch.float32
 
 
 def set_precision(mode: str, corr: str = None) -> None:
@@ -60,28 +66,33 @@ class _timed:
 
 
 class FMap:
-    """NHWC fp32 feature map view: rows = pixels, `C` channels starting at column `off` of a [H*W, ld] buffer."""
+    """NHWC feature map view (fp32, or bf16 for GEMM-only intermediates): rows = pixels, `C` channels starting at
+    column `off` of a [H*W, ld] buffer."""
     __slots__ = ("t", "H", "W", "C", "ld", "off")
 
     def __init__(self, t: torch.Tensor, H: int, W: int, C_: int, off: int = 0):
-        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 2 and t.shape[0] == H * W
+        assert t.is_cuda and t.dtype in (torch.float32, torch.bfloat16) and t.is_contiguous() and t.dim() == 2 and t.shape[0] == H * W
         self.t, self.H, self.W, self.C, self.ld, self.off = t, H, W, C_, t.shape[1], off
         assert off + C_ <= self.ld
 
     @staticmethod
-    def empty(H: int, W: int, C_: int, device) -> "FMap":
-        return FMap(torch.empty(H * W, C_, device=device, dtype=torch.float32), H, W, C_)
+    def empty(H: int, W: int, C_: int, device, dtype=torch.float32) -> "FMap":
+        return FMap(torch.empty(H * W, C_, device=device, dtype=dtype), H, W, C_)
+
+    @property
+    def bf16(self) -> bool:
+        return self.t.dtype == torch.bfloat16
 
     def view(self, off: int, C_: int) -> "FMap":
         return FMap(self.t, self.H, self.W, C_, self.off + off)
 
     @property
     def ptr(self) -> int:
-        return self.t.data_ptr() + 4 * self.off
+        return self.t.data_ptr() + self.t.element_size() * self.off
 
     def dense(self) -> torch.Tensor:
         """[H, W, C] copy-free when the view spans the whole buffer."""
-        return self.t[:, self.off:self.off + self.C].reshape(self.H, self.W, self.C)
+        return self.t[:, self.off:self.off + self.C].float().reshape(self.H, self.W, self.C)
 
     def nchw(self) -> torch.Tensor:
         return self.dense().permute(2, 0, 1).unsqueeze(0).contiguous()
@@ -139,16 +150,20 @@ def conv5_out(f: FMap, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> t
 
 def igemm(a0: FMap, w: torch.Tensor, bias: Optional[torch.Tensor], N: int, ksize: int = 1, stride: int = 1,
           mode: int = CONV, act: int = ACT_NONE, a1: Optional[FMap] = None, residual: Optional[FMap] = None,
-          rowscale: Optional[torch.Tensor] = None, out: Optional[FMap] = None) -> FMap:
+          rowscale: Optional[torch.Tensor] = None, out: Optional[FMap] = None, out_dtype=torch.float32) -> FMap:
     pad = ksize // 2
     if mode == CONV:
         ho, wo = (a0.H + 2 * pad - ksize) // stride + 1, (a0.W + 2 * pad - ksize) // stride + 1
     else:
         ho, wo = a0.H * stride, a0.W * stride
     if out is None:
-        out = FMap.empty(ho, wo, N, a0.t.device)
+        out = FMap.empty(ho, wo, N, a0.t.device, out_dtype)
     assert out.H == ho and out.W == wo and out.C == N
     k0, k1 = a0.C, (a1.C if a1 is not None else 0)
+    slab = PRECISION != "f32" and USE_SLAB and mode == CONV
+    assert slab or not (a0.bf16 or out.bf16), "bf16 activations are only supported by the slab kernel"
+    assert a1 is None or a1.bf16 == a0.bf16
+    assert residual is None or not residual.bf16
     if torch.is_tensor(w):
         w = PackedW(w, a0.t.device)
     assert tuple(w.shape) == (ksize * ksize, N, k0 + k1), (tuple(w.shape), ksize, N, k0, k1)
@@ -164,12 +179,12 @@ def igemm(a0: FMap, w: torch.Tensor, bias: Optional[torch.Tensor], N: int, ksize
     srcs = (_vp(a0.ptr), a0.ld, k0, _vp(a1.ptr if a1 is not None else 0), a1.ld if a1 is not None else 0, k1)
     if PRECISION == "f32":
         _lib.check(_lib.lib().spei_igemm_f32(*srcs, _tp(w.f32), _tp(bias), *common), "spei_igemm_f32")
-    elif USE_SLAB and mode == CONV and w.fhi is not None:
+    elif slab and w.fhi is not None:
         dims = (a0.H * a0.W, 1, ho * wo, 1) if (ksize == 1 and stride == 1) else (a0.H, a0.W, ho, wo)
         _lib.check(_lib.lib().spei_conv_slab_bf16(
-            *srcs, _tp(w.fhi), _tp(w.flo) if PRECISION == "bf16x3" else _vp(0), _tp(bias), _vp(out.ptr), out.ld,
-            _vp(residual.ptr if residual is not None else 0), residual.ld if residual is not None else 0, _tp(rowscale),
-            *dims, N, ksize, stride, pad, act, _stream()), "spei_conv_slab_bf16")
+            *srcs, int(a0.bf16), _tp(w.fhi), _tp(w.flo) if PRECISION == "bf16x3" else _vp(0), _tp(bias), _vp(out.ptr), out.ld,
+            int(out.bf16), _vp(residual.ptr if residual is not None else 0), residual.ld if residual is not None else 0,
+            _tp(rowscale), *dims, N, ksize, stride, pad, act, _stream()), "spei_conv_slab_bf16")
     else:
         _lib.check(_lib.lib().spei_igemm_bf16(*srcs, _tp(w.hi), _tp(w.lo) if PRECISION == "bf16x3" else _vp(0), _tp(bias), *common),
                    "spei_igemm_bf16")
@@ -177,14 +192,14 @@ def igemm(a0: FMap, w: torch.Tensor, bias: Optional[torch.Tensor], N: int, ksize
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: int = ACT_NONE,
-           residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+           residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_dtype=torch.float32) -> torch.Tensor:
     """Token-space linear: x [M,K] -> [M,N]; w [N,K]."""
     m, k = x.shape
     if torch.is_tensor(w):
         w = PackedW(w.reshape(1, *w.shape), x.device)
     n = w.shape[1]
     if out is None:
-        out = torch.empty(m, n, device=x.device, dtype=torch.float32)
+        out = torch.empty(m, n, device=x.device, dtype=out_dtype)
     igemm(FMap(x, m, 1, k), w, b, n, act=act,
           residual=FMap(residual, m, 1, n) if residual is not None else None, out=FMap(out, m, 1, n))
     return out
@@ -208,7 +223,7 @@ def resblock(x: FMap, pk: dict, extra: Optional[FMap] = None, out: Optional[FMap
     """x + SE(x1) + TE(x1), x1 = conv5(relu(conv5(x)))  (reference model/block.py:127-140)."""
     c = x.C
     assert x.off == 0 and x.ld == c
-    t = igemm(x, pk["w1"], pk["b1"], c, ksize=5, act=ACT_RELU)
+    t = igemm(x, pk["w1"], pk["b1"], c, ksize=5, act=ACT_RELU, out_dtype=inter_dtype())   # only conv2 reads it
     x1 = igemm(t, pk["w2"], pk["b2"], c, ksize=5)
     s, g1, g2 = resblock_gates(x1, pk)
     if out is None:
@@ -222,11 +237,12 @@ def resblock(x: FMap, pk: dict, extra: Optional[FMap] = None, out: Optional[FMap
 
 
 def layernorm(x: torch.Tensor, g: Optional[torch.Tensor] = None, b: Optional[torch.Tensor] = None,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    assert x.shape[1] == 256 and x.is_contiguous()
+              out: Optional[torch.Tensor] = None, out_dtype=torch.float32) -> torch.Tensor:
+    assert x.shape[1] == 256 and x.is_contiguous() and x.dtype == torch.float32
     if out is None:
-        out = torch.empty_like(x)
-    _lib.check(_lib.lib().spei_layernorm256(_tp(x), _tp(out), _tp(g), _tp(b), x.shape[0], _stream()), "spei_layernorm256")
+        out = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+    _lib.check(_lib.lib().spei_layernorm256(_tp(x), _tp(out), int(out.dtype == torch.bfloat16), _tp(g), _tp(b), x.shape[0], _stream()),
+               "spei_layernorm256")
     return out
 
 
@@ -235,7 +251,9 @@ def window_attention(q: torch.Tensor, kv: torch.Tensor, relbias: torch.Tensor, H
     assert q.shape == (H * W, 256) and kv.shape == (H * W, 512) and relbias.shape == (8, 25, 25)
     if out is None:
         out = torch.empty_like(q)
-    _lib.check(_lib.lib().spei_window_attention(_tp(q), _tp(kv), _tp(relbias), _tp(out), H, W, shift, _stream()), "spei_window_attention")
+    assert q.dtype == kv.dtype == out.dtype
+    _lib.check(_lib.lib().spei_window_attention(_tp(q), _tp(kv), int(q.dtype == torch.bfloat16), _tp(relbias), _tp(out), H, W, shift,
+                                                _stream()), "spei_window_attention")
     return out
 
 
