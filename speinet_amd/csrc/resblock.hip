@@ -7,88 +7,142 @@
 //   out       = x + (x1*s + (x1*g1 + x1*g2))
 //
 // Three global reductions force a grid-wide dependency, so the gates take three small launches
-// (stats -> reduce+SE -> gate maps) and the application one elementwise launch.  All partial sums are
+// (tile stats -> combine partials -> gate maps + SE) and the application one elementwise launch.  All partial sums are
 // combined in a fixed order: results are bitwise reproducible run to run.
 #include "common.h"
 
 namespace {
 
-constexpr int COL_TW = 64;     // columns per column-stat block
-constexpr int COL_STRIPS = 16; // row strips for the column partials
-
-// workspace layout (floats)
+// Tiling of the statistics pass: a 256-thread block reads a (1024/C) x (1024/C) pixel tile with 16-byte loads,
+// thread = (channel quad cq, tile column pl).  Column partials accumulate in registers down the tile's rows; row
+// partials are reduced across the tile's columns with wave shuffles + a small LDS combine.  Every level launches
+// ~900 blocks (C*pixels is constant), so the pass streams at HBM rate instead of one row per block.
 struct GateWs {
+    float* rowpmax;  // [ntx][H][C]
+    float* rowpsum;  // [ntx][H][C]
+    float* colpmax;  // [nty][W][C]
+    float* colpsum;  // [nty][W][C]
     float* rowmax;   // [H][C]
     float* rowmean;  // [H][C]
-    float* colpmax;  // [S][W][C]
-    float* colpsum;  // [S][W][C]
     float* colmax;   // [W][C]
     float* colmean;  // [W][C]
+    int ntx, nty;
 };
 __host__ __device__ inline GateWs carve(float* ws, int H, int W, int C) {
     GateWs g;
-    g.rowmax = ws;
+    const int T = 1024 / C;
+    g.ntx = (W + T - 1) / T;
+    g.nty = (H + T - 1) / T;
+    g.rowpmax = ws;
+    g.rowpsum = g.rowpmax + (size_t)g.ntx * H * C;
+    g.colpmax = g.rowpsum + (size_t)g.ntx * H * C;
+    g.colpsum = g.colpmax + (size_t)g.nty * W * C;
+    g.rowmax = g.colpsum + (size_t)g.nty * W * C;
     g.rowmean = g.rowmax + (size_t)H * C;
-    g.colpmax = g.rowmean + (size_t)H * C;
-    g.colpsum = g.colpmax + (size_t)COL_STRIPS * W * C;
-    g.colmax = g.colpsum + (size_t)COL_STRIPS * W * C;
+    g.colmax = g.rowmean + (size_t)H * C;
     g.colmean = g.colmax + (size_t)W * C;
     return g;
 }
 
-// ---- launch 1: row stats (blocks [0,H)) and column partials (blocks [H, H + ctiles*S)) --------------
+__device__ __forceinline__ f32x4 max4(f32x4 a, f32x4 b) {
+    return f32x4{fmaxf(a[0], b[0]), fmaxf(a[1], b[1]), fmaxf(a[2], b[2]), fmaxf(a[3], b[3])};
+}
+__device__ __forceinline__ f32x4 shfl4(f32x4 v, int mask) {
+    return f32x4{__shfl_xor(v[0], mask, 64), __shfl_xor(v[1], mask, 64), __shfl_xor(v[2], mask, 64), __shfl_xor(v[3], mask, 64)};
+}
+
+// ---- launch 1: tile statistics -----------------------------------------------------------------------------
 template <int C>
 __global__ __launch_bounds__(256) void gate_stats_kernel(const float* __restrict__ x1, int H, int W, GateWs g) {
-    constexpr int G = 256 / C;      // column groups per block
-    __shared__ float smax[256], ssum[256];
-    const int c = threadIdx.x % C, grp = threadIdx.x / C;
-    if ((int)blockIdx.x < H) {
-        const int y = blockIdx.x;
-        const float* row = x1 + (size_t)y * W * C;
-        float mx = -INFINITY, sm = 0.f;
-        for (int x = grp; x < W; x += G) {
-            const float v = row[(size_t)x * C + c];
-            mx = fmaxf(mx, v);
-            sm += v;
+    constexpr int CQ = C / 4;            // channel quads = threads per pixel
+    constexpr int T = 1024 / C;          // tile rows == tile columns
+    constexpr int PLW = 64 / CQ;         // tile columns held by one wave
+    __shared__ f32x4 smax[T][4][CQ], ssum[T][4][CQ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cq = tid % CQ, pl = tid / CQ;
+    const int tx = blockIdx.x % g.ntx, ty = blockIdx.x / g.ntx;
+    const int x = tx * T + pl, y0 = ty * T;
+    const bool xok = x < W;
+    f32x4 cmax = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY}, csum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k = 0; k < T; ++k) {
+        const int y = y0 + k;
+        f32x4 vmax = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY}, vsum = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (xok && y < H) {
+            vsum = *reinterpret_cast<const f32x4*>(x1 + ((size_t)y * W + x) * C + cq * 4);
+            vmax = vsum;
+            cmax = max4(cmax, vmax);
+            csum += vsum;
         }
-        smax[threadIdx.x] = mx;
-        ssum[threadIdx.x] = sm;
-        __syncthreads();
-        if (grp == 0) {
+        // reduce over the PLW columns of this wave (lanes cq + CQ*j), fixed order => reproducible
 #pragma unroll
-            for (int k = 1; k < G; ++k) {
-                mx = fmaxf(mx, smax[k * C + c]);
-                sm += ssum[k * C + c];
-            }
-            g.rowmax[(size_t)y * C + c] = mx;
-            g.rowmean[(size_t)y * C + c] = sm / (float)W;
+        for (int m = CQ; m < 64; m <<= 1) {
+            vmax = max4(vmax, shfl4(vmax, m));
+            vsum += shfl4(vsum, m);
         }
-    } else {
-        const int b = blockIdx.x - H;
-        const int ctiles = (W + COL_TW - 1) / COL_TW;
-        const int tile = b % ctiles, strip = b / ctiles;
-        const int rows = (H + COL_STRIPS - 1) / COL_STRIPS;
-        const int ya = strip * rows, yb = min(H, ya + rows);
-        for (int xo = grp; xo < COL_TW; xo += G) {
-            const int x = tile * COL_TW + xo;
-            if (x >= W) break;
-            float mx = -INFINITY, sm = 0.f;
-            for (int y = ya; y < yb; ++y) {
-                const float v = x1[((size_t)y * W + x) * C + c];
-                mx = fmaxf(mx, v);
-                sm += v;
-            }
-            g.colpmax[((size_t)strip * W + x) * C + c] = mx;
-            g.colpsum[((size_t)strip * W + x) * C + c] = sm;
+        if (lane < CQ) {
+            smax[k][wave][cq] = vmax;
+            ssum[k][wave][cq] = vsum;
         }
+    }
+    if (xok) {
+        *reinterpret_cast<f32x4*>(g.colpmax + ((size_t)ty * W + x) * C + cq * 4) = cmax;
+        *reinterpret_cast<f32x4*>(g.colpsum + ((size_t)ty * W + x) * C + cq * 4) = csum;
+    }
+    __syncthreads();
+    for (int i = tid; i < T * CQ; i += 256) {
+        const int k = i / CQ, q = i - k * CQ;
+        const int y = y0 + k;
+        if (y < H) {
+            f32x4 mx = smax[k][0][q], sm = ssum[k][0][q];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                mx = max4(mx, smax[k][w][q]);
+                sm += ssum[k][w][q];
+            }
+            *reinterpret_cast<f32x4*>(g.rowpmax + ((size_t)tx * H + y) * C + q * 4) = mx;
+            *reinterpret_cast<f32x4*>(g.rowpsum + ((size_t)tx * H + y) * C + q * 4) = sm;
+        }
+    }
+    (void)PLW;
+}
+
+// ---- launch 2: combine the tile partials -> row / column statistics ---------------------------------------------
+__global__ __launch_bounds__(256) void gate_reduce_kernel(int H, int W, int C, GateWs g) {
+    const int64_t nrow = (int64_t)H * C, ncol = (int64_t)W * C;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nrow) {
+        float mx = -INFINITY, sm = 0.f;
+        for (int k = 0; k < g.ntx; ++k) {
+            mx = fmaxf(mx, g.rowpmax[(size_t)k * nrow + i]);
+            sm += g.rowpsum[(size_t)k * nrow + i];
+        }
+        g.rowmax[i] = mx;
+        g.rowmean[i] = sm / (float)W;
+    } else if (i < nrow + ncol) {
+        const int64_t j = i - nrow;
+        float mx = -INFINITY, sm = 0.f;
+        for (int k = 0; k < g.nty; ++k) {
+            mx = fmaxf(mx, g.colpmax[(size_t)k * ncol + j]);
+            sm += g.colpsum[(size_t)k * ncol + j];
+        }
+        g.colmax[j] = mx;
+        g.colmean[j] = sm / (float)H;
     }
 }
 
-// ---- launch 2: block 0 = SE vector; other blocks = reduce column partials over the strips ----------
-__global__ __launch_bounds__(256) void gate_reduce_kernel(int H, int W, int C, GateWs g, const float* __restrict__ w1,
-                                                          const float* __restrict__ b1, const float* __restrict__ w2,
-                                                          const float* __restrict__ b2, float* __restrict__ s) {
-    if (blockIdx.x == 0) {
+// ---- launch 3: the two 2->1 channel convolutions + eval BatchNorm(1); last block = SE vector ---------------------
+__global__ __launch_bounds__(256) void gate_maps_kernel(int H, int W, int C, GateWs g, const float* __restrict__ cw_w,
+                                                        const float* __restrict__ cw_bn, const float* __restrict__ hc_w,
+                                                        const float* __restrict__ hc_bn, float* __restrict__ g1,
+                                                        float* __restrict__ g2, const float* __restrict__ w1,
+                                                        const float* __restrict__ b1, const float* __restrict__ w2,
+                                                        const float* __restrict__ b2, float* __restrict__ s) {
+    __shared__ float wk[98];
+    const int64_t n1 = (int64_t)H * C;
+    const int nb1 = (int)((n1 + 255) / 256);
+    const int nb2 = (int)(((int64_t)W * C + 255) / 256);
+    if ((int)blockIdx.x == nb1 + nb2) {
         __shared__ float mean[128], hid[32], part[256];
         const int G = 256 / C;
         const int c = threadIdx.x % C, grp = threadIdx.x / C;
@@ -113,30 +167,8 @@ __global__ __launch_bounds__(256) void gate_reduce_kernel(int H, int W, int C, G
             for (int k = 0; k < mid; ++k) a = fmaf(w2[threadIdx.x * mid + k], hid[k], a);
             s[threadIdx.x] = 1.0f / (1.0f + expf(-a));
         }
-    } else {
-        const int64_t i = (int64_t)(blockIdx.x - 1) * 256 + threadIdx.x;
-        if (i < (int64_t)W * C) {
-            float mx = -INFINITY, sm = 0.f;
-            const int rows = (H + COL_STRIPS - 1) / COL_STRIPS;
-            for (int k = 0; k < COL_STRIPS; ++k) {
-                if (k * rows >= H) break;
-                mx = fmaxf(mx, g.colpmax[(size_t)k * W * C + i]);
-                sm += g.colpsum[(size_t)k * W * C + i];
-            }
-            g.colmax[i] = mx;
-            g.colmean[i] = sm / (float)H;
-        }
+        return;
     }
-}
-
-// ---- launch 3: the two 2->1 channel convolutions + eval BatchNorm(1) ------------------------------
-__global__ __launch_bounds__(256) void gate_maps_kernel(int H, int W, int C, GateWs g, const float* __restrict__ cw_w,
-                                                        const float* __restrict__ cw_bn, const float* __restrict__ hc_w,
-                                                        const float* __restrict__ hc_bn, float* __restrict__ g1,
-                                                        float* __restrict__ g2) {
-    __shared__ float wk[98];
-    const int64_t n1 = (int64_t)H * C;
-    const int nb1 = (int)((n1 + 255) / 256);
     if ((int)blockIdx.x < nb1) {
         if (threadIdx.x < 98) wk[threadIdx.x] = cw_w[threadIdx.x];
         __syncthreads();
@@ -217,7 +249,10 @@ __global__ __launch_bounds__(256) void resblock_apply_kernel(const float* __rest
 }  // namespace
 
 extern "C" int64_t spei_gate_ws_floats(int H, int W, int C) {
-    return (int64_t)2 * H * C + (int64_t)2 * COL_STRIPS * W * C + (int64_t)2 * W * C;
+    if (C != 32 && C != 64 && C != 128) return 0;
+    const int T = 1024 / C;
+    const int64_t ntx = (W + T - 1) / T, nty = (H + T - 1) / T;
+    return 2 * ntx * H * C + 2 * nty * W * C + 2 * (int64_t)H * C + 2 * (int64_t)W * C;
 }
 
 extern "C" int spei_resblock_gates(const float* x1, int H, int W, int C, const float* se_w1, const float* se_b1,
@@ -228,18 +263,16 @@ extern "C" int spei_resblock_gates(const float* x1, int H, int W, int C, const f
                  "spei_resblock_gates: null pointer");
     SPEI_REQUIRE(C == 32 || C == 64 || C == 128, "spei_resblock_gates: C=%d (32/64/128 built)", C);
     SPEI_REQUIRE(H > 0 && W > 0, "spei_resblock_gates: empty map");
+    SPEI_REQUIRE(((uintptr_t)x1 | (uintptr_t)ws) % 16 == 0, "spei_resblock_gates: 16-byte alignment required");
     hipStream_t st = (hipStream_t)stream;
     GateWs g = carve(ws, H, W, C);
-    const int ctiles = cdiv(W, COL_TW);
-    const int rows = cdiv(H, COL_STRIPS);
-    const int strips = cdiv(H, rows);
-    dim3 grid1(H + ctiles * strips);
+    dim3 grid1(g.ntx * g.nty);
     if (C == 32) hipLaunchKernelGGL(gate_stats_kernel<32>, grid1, dim3(256), 0, st, x1, H, W, g);
     else if (C == 64) hipLaunchKernelGGL(gate_stats_kernel<64>, grid1, dim3(256), 0, st, x1, H, W, g);
     else hipLaunchKernelGGL(gate_stats_kernel<128>, grid1, dim3(256), 0, st, x1, H, W, g);
-    hipLaunchKernelGGL(gate_reduce_kernel, dim3(1 + cdiv((int64_t)W * C, 256)), dim3(256), 0, st, H, W, C, g, se_w1, se_b1, se_w2, se_b2, s);
-    hipLaunchKernelGGL(gate_maps_kernel, dim3(cdiv((int64_t)H * C, 256) + cdiv((int64_t)W * C, 256)), dim3(256), 0, st, H, W, C, g,
-                       cw_w, cw_bn, hc_w, hc_bn, g1, g2);
+    hipLaunchKernelGGL(gate_reduce_kernel, dim3(cdiv((int64_t)(H + W) * C, 256)), dim3(256), 0, st, H, W, C, g);
+    hipLaunchKernelGGL(gate_maps_kernel, dim3(cdiv((int64_t)H * C, 256) + cdiv((int64_t)W * C, 256) + 1), dim3(256), 0, st, H, W, C, g,
+                       cw_w, cw_bn, hc_w, hc_bn, g1, g2, se_w1, se_b1, se_w2, se_b2, s);
     SPEI_CHECK_LAUNCH("spei_resblock_gates");
     return 0;
 }
