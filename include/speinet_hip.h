@@ -82,6 +82,12 @@ int spei_conv_slab_bf16(const void* a0, int lda0, int k0, const void* a1, int ld
                         const float* residual, int ldr, const float* rowscale, int Hin, int Win, int Hout, int Wout,
                         int N, int ksize, int stride, int pad, int act, spei_stream_t stream);
 
+/* Fused Swin MLP branch (model/swinir.py:12-29 Mlp.forward + the `x + mlp(norm2(x))` tail of :279), bf16 matrix pipe:
+ * out = x + fc2(GELU(fc1(LayerNorm256(x)))), LayerNorm affine folded into w1/b1 (pack.py); w*_frag in MFMA fragment
+ * order; the normalised tokens and the 512-wide hidden activations live only in LDS.  x, out: [M][256] fp32, may alias. */
+int spei_mlp_fused_bf16(const float* x, float* out, const void* w1_frag, const float* b1, const void* w2_frag,
+                        const float* b2, int64_t M, spei_stream_t stream);
+
 /* K3 — ResBlock gates (model/block.py:8-24 SE, 71-96 ZPool+AttentionGate1/2, 108-124 TripletAttention).
  * x1: conv2 output [H][W][C].  Workspace `ws` floats: spei_gate_ws_floats(H,W,C).
  * Produces s[C], g1[H][C], g2[W][C] such that ResBlock = x + x1*s + (x1*g1 + x1*g2).

@@ -77,9 +77,12 @@ def swin(sx: SwinX, feat: FMap, sw: dict, out: FMap) -> FMap:
             ops.linear(yhat, bk["wq"], bk["bq"], out=q)
             ops.window_attention(q, kv, bk["relbias"], h, w, shift, out=att)
             ops.linear(att, bk["wproj"], bk["bproj"], residual=cur, out=nxt)
-            ops.layernorm(nxt, out=xh)
-            ops.linear(xh, bk["w1"], bk["b1"], act=ACT_GELU, out=hid)
-            ops.linear(hid, bk["w2"], bk["b2"], residual=nxt, out=nxt)
+            if ops.mlp_fused_available():
+                ops.mlp_fused(nxt, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out=nxt)
+            else:
+                ops.layernorm(nxt, out=xh)
+                ops.linear(xh, bk["w1"], bk["b1"], act=ACT_GELU, out=hid)
+                ops.linear(hid, bk["w2"], bk["b2"], residual=nxt, out=nxt)
             cur = nxt
         # RSTB: conv3x3(blocks(x)) + x   (swinir.py:483-484), in place on the residual buffer
         rf = FMap(r, h, w, 256)

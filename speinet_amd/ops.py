@@ -236,6 +236,22 @@ def resblock(x: FMap, pk: dict, extra: Optional[FMap] = None, out: Optional[FMap
     return out
 
 
+FUSE_MLP = True      # "bf16" mode: LayerNorm -> fc1 -> GELU -> fc2 -> +x in one kernel (mlp_fused_bf16.hip)
+
+
+def mlp_fused_available() -> bool:
+    return PRECISION == "bf16" and USE_SLAB and FUSE_MLP
+
+
+def mlp_fused(x: torch.Tensor, w1, b1: torch.Tensor, w2, b2: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out = x + fc2(gelu(fc1(LN(x))))  (reference model/swinir.py:279); in place when out is x."""
+    assert x.shape[1] == 256 and x.dtype == torch.float32 and out.shape == x.shape and out.dtype == torch.float32
+    assert tuple(w1.shape) == (1, 512, 256) and tuple(w2.shape) == (1, 256, 512)
+    _lib.check(_lib.lib().spei_mlp_fused_bf16(_tp(x), _tp(out), _tp(w1.fhi), _tp(b1), _tp(w2.fhi), _tp(b2), x.shape[0], _stream()),
+               "spei_mlp_fused_bf16")
+    return out
+
+
 def layernorm(x: torch.Tensor, g: Optional[torch.Tensor] = None, b: Optional[torch.Tensor] = None,
               out: Optional[torch.Tensor] = None, out_dtype=torch.float32) -> torch.Tensor:
     assert x.shape[1] == 256 and x.is_contiguous() and x.dtype == torch.float32

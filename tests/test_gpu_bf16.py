@@ -150,3 +150,22 @@ def test_forward_bf16_golden(golden_dir, net, name, b, h, w):
     psnr_vs_ref = O.psnr_uint8(O.to_uint8(out), O.to_uint8(d["out"]))
     print(f"{name} bf16: max abs err {err:.3e}, rms {rms:.3e}, PSNR(out, ref out) {psnr_vs_ref:.1f} dB, |dPSNR vs target| {dp:.2e} dB")
     assert err < 0.05 and dp < 0.1
+
+
+def test_mlp_fused_vs_oracle(synth_sd):
+    """Fused LN -> fc1 -> GELU -> fc2 -> +x kernel against the fp32 formula (bf16 products: 1.5e-2 of max|ref|)."""
+    ops.set_precision("bf16")
+    p = "swin.layers.1.residual_group.blocks.2."
+    bk = pack.swin_block(synth_sd, p, 8, 5)
+    w1, w2 = pack.PackedW(bk["w1"].t, DEV), pack.PackedW(bk["w2"].t, DEV)
+    for m in (64, 1000, 2500):                     # whole tile, ragged tail, many tiles
+        x = rnd(40 + m, m, 256, scale=1.5) + 0.3
+        ref = x + F.linear(F.gelu(F.linear(F.layer_norm(x, (256,), synth_sd[p + "norm2.weight"], synth_sd[p + "norm2.bias"], 1e-5),
+                                           synth_sd[p + "mlp.fc1.weight"], synth_sd[p + "mlp.fc1.bias"])),
+                           synth_sd[p + "mlp.fc2.weight"], synth_sd[p + "mlp.fc2.bias"])
+        xd = x.to(DEV)
+        out = ops.mlp_fused(xd, w1, bk["b1"].to(DEV), w2, bk["b2"].to(DEV), out=torch.empty_like(xd))
+        e = ((out.cpu() - ref).abs().max() / (ref - x).abs().max()).item()      # relative to the MLP branch itself
+        assert e < 1.5e-2, f"M={m}: rel err {e:.2e}"
+        inplace = ops.mlp_fused(xd, w1, bk["b1"].to(DEV), w2, bk["b2"].to(DEV), out=xd)
+        assert torch.equal(inplace, out)
