@@ -11,8 +11,10 @@ RCCL carries only the barrier, the max-over-ranks time and an all-gather of per-
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     — the dominant kernel (fused correlation arg-max, 37 % of the path's FLOPs, one launch per frame):
                  algorithmic FLOPs per launch / its HIP-event duration measured live in the timed region, against the
-                 dense f32 MFMA peak of gfx950 (MI355X_MICROARCH.md: 157.3 TFLOP/s); `path_frac` prices the WHOLE
-                 frame (F = 20.64 TFLOP) against the same peak.
+                 dense MFMA peak of the dtype in use (MI355X_MICROARCH.md: 2500 TFLOP/s bf16, 157.3 TFLOP/s f32);
+                 `path_frac` prices the WHOLE frame (F = 20.64 TFLOP) against the same peak; `traffic` is
+                 the kernel's HBM bytes per launch from rocprofv3 PMC passes (profiles/r01_traffic.json, FETCH_SIZE
+                 doubled as the guide prescribes for wide coalesced reads on gfx950) or null when that file is absent.
   cpu_baseline — the oracle (CPU restatement of the reference, PyTorch fp32) timed on this host's cores, rank 0, N=1,
                  on a bounded sample (one 360x640 frame), scaled to 720p frames by the FLOP formula of BASELINE.md §2.
 """
@@ -45,6 +47,15 @@ def corr_flops(h: int, w: int) -> float:
     return 2.0 * 1152.0 * n3 * n3     # [N3 x 1152] x [1152 x N3]
 
 
+def traffic_bytes(precision: str, corr_precision: str):
+    """HBM bytes per launch of the roofline kernel, measured offline with rocprofv3 --pmc (see profiles/)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        return d.get(f"{precision}/{corr_precision if precision != 'f32' else 'f32'}", {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(seed: int) -> dict:
     from oracle import speinet_oracle as O
     from speinet_amd.synth import state_dict_template, synth_frames, synth_state_dict
@@ -71,8 +82,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=["f32", "bf16x3", "bf16"], default="bf16",
                     help="arithmetic of the GEMM-shaped kernels; BASELINE.json configs[1] is the bf16 forward")
-    ap.add_argument("--corr-precision", choices=["bf16x3", "bf16"], default="bf16x3",
-                    help="correlation arg-max products when --precision is not f32")
+    ap.add_argument("--corr-precision", choices=["bf16x3", "bf16"], default="bf16",
+                    help="correlation arg-max products when --precision is not f32 (bf16x3 = f32-grade scores, 2.4x the kernel time)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying one hipGraph per frame")
     ap.add_argument("--branch", choices=["bs", "b"], default="bs", help="bs: with sharp reference (SearchTransfer); b: SelfTransfer")
     ap.add_argument("--height", type=int, default=H)
@@ -157,7 +168,7 @@ def main():
                                    f"{'_forwardbs (SearchTransfer)' if args.branch == 'bs' else '_forwardb (SelfTransfer)'}, "
                                    "synthetic name-keyed weights seed 0", "frames_per_step_per_gpu": 1, "sharding": "frames by rank, no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": "corr_argmax_kernel", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                         "frac": ach / peak, "traffic": None, "launch_ms": corr_ms,
+                         "frac": ach / peak, "traffic": traffic_bytes(args.precision, args.corr_precision), "launch_ms": corr_ms,
                          "algorithmic_flops_per_launch": corr_flops(h, w),
                          "path_flops_per_frame": path_flops(h, w),
                          "path_frac": path_flops(h, w) * fps / world / 1e12 / peak},

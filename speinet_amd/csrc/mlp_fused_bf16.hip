@@ -33,7 +33,19 @@ struct MlpParams {
     int M;
 };
 
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+// GELU with erf from Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7): ~15 VALU ops instead of ~60 for erff.  Only used
+// where the result is rounded to bf16 right away (2^-9 relative), i.e. in the "bf16" arithmetic mode.
+__device__ __forceinline__ float gelu_fast(float v) {
+    const float z = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = poly * t * __expf(-z * z);
+    const float erf_abs = 1.0f - e;
+    return 0.5f * v * (1.0f + copysignf(erf_abs, v));
+}
 
 __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -42,15 +54,22 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams p) {
     float* etile = reinterpret_cast<float*>(smem + MT * PA + MT * PH) + (threadIdx.x >> 6) * (32 * EP);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;                // 2 token halves x 4 column slots
+    const int wn = wave;                                    // 8 column slots; every wave covers both 32-token halves
     const int fr = lane & 31, fk = lane >> 5;
     const int m0 = blockIdx.x * MT;
 
     // ---- 1. LayerNorm(256) per token row, one wave per row ---------------------------------------------------
-    for (int r = wave; r < MT; r += 8) {
-        const int m = m0 + r;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < p.M) v = reinterpret_cast<const float4*>(p.x + (size_t)m * D)[lane];
+    // all 8 rows of this wave are requested before the first reduction (one HBM latency, not eight)
+    f32x4 rows[MT / 8];
+#pragma unroll
+    for (int i = 0; i < MT / 8; ++i) {
+        const int m = min(m0 + wave + 8 * i, p.M - 1);
+        rows[i] = reinterpret_cast<const f32x4*>(p.x + (size_t)m * D)[lane];
+    }
+#pragma unroll
+    for (int i = 0; i < MT / 8; ++i) {
+        const int r = wave + 8 * i;
+        const float4 v = make_float4(rows[i][0], rows[i][1], rows[i][2], rows[i][3]);
         const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 256.0f);
         const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
         const float var = wave_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.0f / 256.0f);
@@ -73,13 +92,16 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams p) {
     __syncthreads();
 
     // ---- 2. fc1 + GELU -> hidden slab ------------------------------------------------------------------------------
-    const unsigned char* abase = sa + (wm * 32 + fr) * PA + fk * 16;
+    // every B fragment is fetched by exactly one wave of the workgroup and used for both token halves
+    const unsigned char* abase = sa + fr * PA + fk * 16;
     constexpr int NG1 = (D / 16) / G;                       // 8 groups per 32-column tile
-    for (int pass = 0; pass < HID / 128; ++pass) {
-        const int nt = pass * 4 + wn;                       // 32-column tile of the hidden dim
-        f32x16 acc;
+    for (int pass = 0; pass < HID / 256; ++pass) {
+        const int nt = pass * 8 + wn;                       // 32-column tile of the hidden dim
+        f32x16 acc[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 #pragma unroll
         for (int g0 = 0; g0 < NG1; g0 += RING) {
 #pragma unroll
@@ -87,35 +109,41 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams p) {
                 const int g = g0 + d;
 #pragma unroll
                 for (int s = 0; s < G; ++s) {
-                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(abase + (g * G + s) * 32);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bring[d][s], acc, 0, 0, 0);
+                    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(abase + (g * G + s) * 32);
+                    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(abase + 32 * PA + (g * G + s) * 32);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bring[d][s], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bring[d][s], acc[1], 0, 0, 0);
                 }
                 if (g + RING < NG1) load_b(d, g + RING);
             }
         }
-        // next pass's (or fc2's first) weight stream
-        if (pass + 1 < HID / 128) bptr = p.w1 + (size_t)(nt + 4) * (D / 16) * 512 + lane * 8;
+        // next pass's (or fc2's) weight stream
+        if (pass + 1 < HID / 256) bptr = p.w1 + (size_t)(nt + 8) * (D / 16) * 512 + lane * 8;
         else bptr = p.w2 + (size_t)wn * (HID / 16) * 512 + lane * 8;
 #pragma unroll
         for (int d = 0; d < RING; ++d) load_b(d, d);
         const float bias = p.b1[nt * 32 + fr];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q = (r & 3) + 8 * (r >> 2) + 4 * fk;
-            *reinterpret_cast<__bf16*>(sh + (wm * 32 + q) * PH + (nt * 32 + fr) * 2) = (__bf16)gelu_erf(acc[r] + bias);
-        }
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = (r & 3) + 8 * (r >> 2) + 4 * fk;
+                *reinterpret_cast<__bf16*>(sh + (i * 32 + q) * PH + (nt * 32 + fr) * 2) = (__bf16)gelu_fast(acc[i][r] + bias);
+            }
     }
     __syncthreads();
 
     // ---- 3. fc2 + bias + residual ------------------------------------------------------------------------------------
-    const unsigned char* hbase = sh + (wm * 32 + fr) * PH + fk * 16;
+    const unsigned char* hbase = sh + fr * PH + fk * 16;
     constexpr int NG2 = (HID / 16) / G;                     // 16 groups
     const int erow = lane >> 3, ecol = (lane & 7) * 4;
-    for (int pass = 0; pass < D / 128; ++pass) {
-        const int nt = pass * 4 + wn;
-        f32x16 acc;
+    {
+        const int nt = wn;                                  // 8 waves x 32 columns = the 256 output channels
+        f32x16 acc[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 #pragma unroll
         for (int g0 = 0; g0 < NG2; g0 += RING) {
 #pragma unroll
@@ -123,31 +151,31 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams p) {
                 const int g = g0 + d;
 #pragma unroll
                 for (int s = 0; s < G; ++s) {
-                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(hbase + (g * G + s) * 32);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bring[d][s], acc, 0, 0, 0);
+                    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(hbase + (g * G + s) * 32);
+                    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(hbase + 32 * PH + (g * G + s) * 32);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bring[d][s], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bring[d][s], acc[1], 0, 0, 0);
                 }
                 if (g + RING < NG2) load_b(d, g + RING);
             }
         }
-        if (pass + 1 < D / 128) {
-            bptr = p.w2 + (size_t)(nt + 4) * (HID / 16) * 512 + lane * 8;
-#pragma unroll
-            for (int d = 0; d < RING; ++d) load_b(d, d);
-        }
         const float bias = p.b2[nt * 32 + fr];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q = (r & 3) + 8 * (r >> 2) + 4 * fk;
-            etile[q * EP + fr] = acc[r] + bias;
-        }
+        for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int q = erow + 8 * k;
-            const int m = m0 + wm * 32 + q;
-            if (m < p.M) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(etile + q * EP + ecol);
-                v += *reinterpret_cast<const f32x4*>(p.x + (size_t)m * D + nt * 32 + ecol);
-                *reinterpret_cast<f32x4*>(p.out + (size_t)m * D + nt * 32 + ecol) = v;
+            for (int r = 0; r < 16; ++r) {
+                const int q = (r & 3) + 8 * (r >> 2) + 4 * fk;
+                etile[q * EP + fr] = acc[i][r] + bias;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int q = erow + 8 * k;
+                const int m = m0 + i * 32 + q;
+                if (m < p.M) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(etile + q * EP + ecol);
+                    v += *reinterpret_cast<const f32x4*>(p.x + (size_t)m * D + nt * 32 + ecol);
+                    *reinterpret_cast<f32x4*>(p.out + (size_t)m * D + nt * 32 + ecol) = v;
+                }
             }
         }
     }
