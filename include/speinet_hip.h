@@ -76,11 +76,13 @@ int spei_igemm_bf16(const float* a0, int lda0, int k0, const float* a1, int lda1
  * once into LDS as bf16 and the weights stream from HBM/L2 in MFMA fragment order
  * (wfrag: [N/32][tap][K/16][64][8] bf16, see speinet_amd/pack.py).  Linears: pass Hin = Hout = M, Win = Wout = 1.
  * a_bf16 / out_bf16: the activations (both sources) / the output are bf16 instead of fp32 in HBM — used for tensors
- * that only feed the next GEMM or the attention kernel; residual, rowscale and bias stay fp32. */
+ * that only feed the next GEMM or the attention kernel; residual, rowscale and bias stay fp32.
+ * ln_input: LayerNorm(256) without affine (model/swinir.py:244, affine folded into the weights) is applied to each
+ * 256-wide fp32 input row while it is staged, so the normalised tokens never exist in HBM. */
 int spei_conv_slab_bf16(const void* a0, int lda0, int k0, const void* a1, int lda1, int k1, int a_bf16,
                         const void* wfrag_hi, const void* wfrag_lo, const float* bias, void* out, int ldo, int out_bf16,
                         const float* residual, int ldr, const float* rowscale, int Hin, int Win, int Hout, int Wout,
-                        int N, int ksize, int stride, int pad, int act, spei_stream_t stream);
+                        int N, int ksize, int stride, int pad, int act, int ln_input, spei_stream_t stream);
 
 /* Fused Swin MLP branch (model/swinir.py:12-29 Mlp.forward + the `x + mlp(norm2(x))` tail of :279), bf16 matrix pipe:
  * out = x + fc2(GELU(fc1(LayerNorm256(x)))), LayerNorm affine folded into w1/b1 (pack.py); w*_frag in MFMA fragment
@@ -89,17 +91,17 @@ int spei_mlp_fused_bf16(const float* x, float* out, const void* w1_frag, const f
                         const float* b2, int64_t M, spei_stream_t stream);
 
 /* K3 — ResBlock gates (model/block.py:8-24 SE, 71-96 ZPool+AttentionGate1/2, 108-124 TripletAttention).
- * x1: conv2 output [H][W][C].  Workspace `ws` floats: spei_gate_ws_floats(H,W,C).
+ * x1: conv2 output [H][W][C], fp32 or (x1_bf16) bf16.  Workspace `ws` floats: spei_gate_ws_floats(H,W,C).
  * Produces s[C], g1[H][C], g2[W][C] such that ResBlock = x + x1*s + (x1*g1 + x1*g2).
  * gate params (packed by speinet_amd/pack.py): se_w1[C/4][C], se_b1[C/4], se_w2[C][C/4], se_b2[C],
  * cw_w[2][7][7], cw_bn[2] = {scale, shift}, hc_w[2][5][5], hc_bn[2]. */
 int64_t spei_gate_ws_floats(int H, int W, int C);
-int spei_resblock_gates(const float* x1, int H, int W, int C, const float* se_w1, const float* se_b1,
+int spei_resblock_gates(const void* x1, int x1_bf16, int H, int W, int C, const float* se_w1, const float* se_b1,
                         const float* se_w2, const float* se_b2, const float* cw_w, const float* cw_bn,
                         const float* hc_w, const float* hc_bn, float* s, float* g1, float* g2, float* ws,
                         spei_stream_t stream);
 /* out = x + x1*s + (x1*g1 + x1*g2) [+ extra]   (model/block.py:136-140; `extra` fuses speinet.py:84,132) */
-int spei_resblock_apply(const float* x, const float* x1, const float* s, const float* g1, const float* g2,
+int spei_resblock_apply(const float* x, const void* x1, int x1_bf16, const float* s, const float* g1, const float* g2,
                         const float* extra, float* out, int ldo, int H, int W, int C, spei_stream_t stream);
 
 /* K7 — LayerNorm over C=256, eps 1e-5 (model/swinir.py:244-245,279,528-529,776).  gamma/beta may be NULL

@@ -46,6 +46,8 @@ struct SlabParams {
     int iw_magic;            // ceil(2^20 / IW): pix / IW == (pix * iw_magic) >> 20 for pix < 2048
     int goff_bytes;          // bytes reserved for the group offset table (multiple of 16)
     int n_chunks;            // 32*WN*TN-column chunks looped inside the workgroup
+    int ln;                  // 1: LayerNorm(256) without affine is applied to every input row while it is staged
+                             //    (fp32 input, K == 256: one wave-instruction loads exactly one token row)
     int dbg;                 // ablation switches for tools/ablate_slab.py (0 in production): 1 no staging loads,
                              // 2 no MFMA loop, 4 no epilogue stores
 };
@@ -151,7 +153,18 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u)
-                    if (off[u] >= 0) ST::put(slab, p.slab_bytes, off[u], ok[u] ? v[u] : ST::zero());
+                {
+                    sreg_t val = ok[u] ? v[u] : ST::zero();
+                    if constexpr (sizeof(TA) == 4) {
+                        if (p.ln) {      // the 64 lanes of this wave hold the 256 channels of one row
+                            const float mean = wave_sum((val[0] + val[1]) + (val[2] + val[3])) * (1.0f / 256.0f);
+                            val -= mean;
+                            const float var = wave_sum((val[0] * val[0] + val[1] * val[1]) + (val[2] * val[2] + val[3] * val[3])) * (1.0f / 256.0f);
+                            val *= 1.0f / sqrtf(var + 1e-5f);
+                        }
+                    }
+                    if (off[u] >= 0) ST::put(slab, p.slab_bytes, off[u], val);
+                }
             }
         } else {
             const int total = npix * cpn;
@@ -394,7 +407,7 @@ int dispatch(SlabParams& p, hipStream_t s) {
 extern "C" int spei_conv_slab_bf16(const void* a0, int lda0, int k0, const void* a1, int lda1, int k1, int a_bf16,
                                    const void* wfrag_hi, const void* wfrag_lo, const float* bias, void* out, int ldo,
                                    int out_bf16, const float* residual, int ldr, const float* rowscale, int Hin, int Win,
-                                   int Hout, int Wout, int N, int ksize, int stride, int pad, int act,
+                                   int Hout, int Wout, int N, int ksize, int stride, int pad, int act, int ln_input,
                                    spei_stream_t stream) {
     SPEI_REQUIRE(a0 && wfrag_hi && out, "spei_conv_slab_bf16: null pointer");
     SPEI_REQUIRE(k0 > 0 && k0 % 32 == 0 && k1 >= 0 && k1 % 32 == 0, "spei_conv_slab_bf16: k0=%d k1=%d must be multiples of 32", k0, k1);
@@ -422,6 +435,8 @@ extern "C" int spei_conv_slab_bf16(const void* a0, int lda0, int k0, const void*
     p.N = N; p.K = k0 + k1;
     p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout;
     p.ks = ksize; p.stride = stride; p.pad = pad; p.act = act;
+    SPEI_REQUIRE(!ln_input || (!a_bf16 && k0 == 256 && k1 == 0 && ksize == 1), "spei_conv_slab_bf16: ln_input needs a 256-wide fp32 linear");
+    p.ln = ln_input;
     hipStream_t st = (hipStream_t)stream;
     if (wfrag_lo) return dispatch<true, float, float>(p, st);
     if (a_bf16) return out_bf16 ? dispatch<false, __bf16, __bf16>(p, st) : dispatch<false, __bf16, float>(p, st);

@@ -44,6 +44,17 @@ __host__ __device__ inline GateWs carve(float* ws, int H, int W, int C) {
     return g;
 }
 
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ f32x4 ld4(const T* p);
+template <>
+__device__ __forceinline__ f32x4 ld4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <>
+__device__ __forceinline__ f32x4 ld4<__bf16>(const __bf16* p) {
+    const bf16x4 h = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+
 __device__ __forceinline__ f32x4 max4(f32x4 a, f32x4 b) {
     return f32x4{fmaxf(a[0], b[0]), fmaxf(a[1], b[1]), fmaxf(a[2], b[2]), fmaxf(a[3], b[3])};
 }
@@ -52,8 +63,8 @@ __device__ __forceinline__ f32x4 shfl4(f32x4 v, int mask) {
 }
 
 // ---- launch 1: tile statistics -----------------------------------------------------------------------------
-template <int C>
-__global__ __launch_bounds__(256) void gate_stats_kernel(const float* __restrict__ x1, int H, int W, GateWs g) {
+template <int C, typename TX>
+__global__ __launch_bounds__(256) void gate_stats_kernel(const TX* __restrict__ x1, int H, int W, GateWs g) {
     constexpr int CQ = C / 4;            // channel quads = threads per pixel
     constexpr int T = 1024 / C;          // tile rows == tile columns
     constexpr int PLW = 64 / CQ;         // tile columns held by one wave
@@ -69,7 +80,7 @@ __global__ __launch_bounds__(256) void gate_stats_kernel(const float* __restrict
         const int y = y0 + k;
         f32x4 vmax = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY}, vsum = f32x4{0.f, 0.f, 0.f, 0.f};
         if (xok && y < H) {
-            vsum = *reinterpret_cast<const f32x4*>(x1 + ((size_t)y * W + x) * C + cq * 4);
+            vsum = ld4<TX>(x1 + ((size_t)y * W + x) * C + cq * 4);
             vmax = vsum;
             cmax = max4(cmax, vmax);
             csum += vsum;
@@ -143,15 +154,23 @@ __global__ __launch_bounds__(256) void gate_maps_kernel(int H, int W, int C, Gat
     const int nb1 = (int)((n1 + 255) / 256);
     const int nb2 = (int)(((int64_t)W * C + 255) / 256);
     if ((int)blockIdx.x == nb1 + nb2) {
-        __shared__ float mean[128], hid[32], part[256];
-        const int G = 256 / C;
-        const int c = threadIdx.x % C, grp = threadIdx.x / C;
-        float sm = 0.f;
-        for (int y = grp; y < H; y += G) sm += g.rowmean[(size_t)y * C + c];
-        part[threadIdx.x] = sm;
+        __shared__ float mean[128], hid[32];
+        __shared__ f32x4 part[256];
+        // rowmean is [H][C]; 1024 % C == 0, so float4 index t + 256*k always covers the same 4 channels for thread t
+        const int n4 = H * C / 4;
+        f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+        const f32x4* rm = reinterpret_cast<const f32x4*>(g.rowmean);
+        int i = threadIdx.x;
+        for (; i + 768 < n4; i += 1024) {
+            s0 += rm[i]; s1 += rm[i + 256]; s2 += rm[i + 512]; s3 += rm[i + 768];
+        }
+        for (; i < n4; i += 256) s0 += rm[i];
+        part[threadIdx.x] = (s0 + s1) + (s2 + s3);
         __syncthreads();
-        if (grp == 0) {
-            for (int k = 1; k < G; ++k) sm += part[k * C + c];
+        if ((int)threadIdx.x < C) {
+            const int c = threadIdx.x, q = c >> 2, e = c & 3, nq = C / 4;      // threads q, q+nq, q+2nq, ... share the quad
+            float sm = 0.f;
+            for (int t = q; t < 256; t += nq) sm += part[t][e];
             mean[c] = sm / (float)H;
         }
         __syncthreads();
@@ -217,7 +236,8 @@ __global__ __launch_bounds__(256) void gate_maps_kernel(int H, int W, int C, Gat
 }
 
 // ---- apply ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void resblock_apply_kernel(const float* __restrict__ x, const float* __restrict__ x1,
+template <typename T>
+__global__ __launch_bounds__(256) void resblock_apply_kernel(const float* __restrict__ x, const T* __restrict__ x1,
                                                              const float* __restrict__ s, const float* __restrict__ g1,
                                                              const float* __restrict__ g2, const float* __restrict__ extra,
                                                              float* __restrict__ out, int ldo, int H, int W, int C) {
@@ -228,7 +248,8 @@ __global__ __launch_bounds__(256) void resblock_apply_kernel(const float* __rest
         const int64_t pix = i / cg;
         const int xx = (int)(pix % W), yy = (int)(pix / W);
         const float4 a = *reinterpret_cast<const float4*>(x + pix * C + c);
-        const float4 b = *reinterpret_cast<const float4*>(x1 + pix * C + c);
+        const f32x4 bv = ld4<T>(x1 + pix * C + c);
+        const float4 b = make_float4(bv[0], bv[1], bv[2], bv[3]);
         const float4 sv = *reinterpret_cast<const float4*>(s + c);
         const float4 u = *reinterpret_cast<const float4*>(g1 + (size_t)yy * C + c);
         const float4 v = *reinterpret_cast<const float4*>(g2 + (size_t)xx * C + c);
@@ -255,7 +276,7 @@ extern "C" int64_t spei_gate_ws_floats(int H, int W, int C) {
     return 2 * ntx * H * C + 2 * nty * W * C + 2 * (int64_t)H * C + 2 * (int64_t)W * C;
 }
 
-extern "C" int spei_resblock_gates(const float* x1, int H, int W, int C, const float* se_w1, const float* se_b1,
+extern "C" int spei_resblock_gates(const void* x1, int x1_bf16, int H, int W, int C, const float* se_w1, const float* se_b1,
                                    const float* se_w2, const float* se_b2, const float* cw_w, const float* cw_bn,
                                    const float* hc_w, const float* hc_bn, float* s, float* g1, float* g2, float* ws,
                                    spei_stream_t stream) {
@@ -267,9 +288,17 @@ extern "C" int spei_resblock_gates(const float* x1, int H, int W, int C, const f
     hipStream_t st = (hipStream_t)stream;
     GateWs g = carve(ws, H, W, C);
     dim3 grid1(g.ntx * g.nty);
-    if (C == 32) hipLaunchKernelGGL(gate_stats_kernel<32>, grid1, dim3(256), 0, st, x1, H, W, g);
-    else if (C == 64) hipLaunchKernelGGL(gate_stats_kernel<64>, grid1, dim3(256), 0, st, x1, H, W, g);
-    else hipLaunchKernelGGL(gate_stats_kernel<128>, grid1, dim3(256), 0, st, x1, H, W, g);
+    if (x1_bf16) {
+        const __bf16* xp = (const __bf16*)x1;
+        if (C == 32) hipLaunchKernelGGL((gate_stats_kernel<32, __bf16>), grid1, dim3(256), 0, st, xp, H, W, g);
+        else if (C == 64) hipLaunchKernelGGL((gate_stats_kernel<64, __bf16>), grid1, dim3(256), 0, st, xp, H, W, g);
+        else hipLaunchKernelGGL((gate_stats_kernel<128, __bf16>), grid1, dim3(256), 0, st, xp, H, W, g);
+    } else {
+        const float* xp = (const float*)x1;
+        if (C == 32) hipLaunchKernelGGL((gate_stats_kernel<32, float>), grid1, dim3(256), 0, st, xp, H, W, g);
+        else if (C == 64) hipLaunchKernelGGL((gate_stats_kernel<64, float>), grid1, dim3(256), 0, st, xp, H, W, g);
+        else hipLaunchKernelGGL((gate_stats_kernel<128, float>), grid1, dim3(256), 0, st, xp, H, W, g);
+    }
     hipLaunchKernelGGL(gate_reduce_kernel, dim3(cdiv((int64_t)(H + W) * C, 256)), dim3(256), 0, st, H, W, C, g);
     hipLaunchKernelGGL(gate_maps_kernel, dim3(cdiv((int64_t)H * C, 256) + cdiv((int64_t)W * C, 256) + 1), dim3(256), 0, st, H, W, C, g,
                        cw_w, cw_bn, hc_w, hc_bn, g1, g2, se_w1, se_b1, se_w2, se_b2, s);
@@ -277,13 +306,14 @@ extern "C" int spei_resblock_gates(const float* x1, int H, int W, int C, const f
     return 0;
 }
 
-extern "C" int spei_resblock_apply(const float* x, const float* x1, const float* s, const float* g1, const float* g2,
+extern "C" int spei_resblock_apply(const float* x, const void* x1, int x1_bf16, const float* s, const float* g1, const float* g2,
                                    const float* extra, float* out, int ldo, int H, int W, int C, spei_stream_t stream) {
     SPEI_REQUIRE(x && x1 && s && g1 && g2 && out, "spei_resblock_apply: null pointer");
     SPEI_REQUIRE(C % 4 == 0 && ldo % 4 == 0 && ldo >= C && H > 0 && W > 0, "spei_resblock_apply: bad shape");
     const int64_t total = (int64_t)H * W * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(resblock_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, x1, s, g1, g2, extra, out, ldo, H, W, C);
+    if (x1_bf16) hipLaunchKernelGGL(resblock_apply_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (const __bf16*)x1, s, g1, g2, extra, out, ldo, H, W, C);
+    else hipLaunchKernelGGL(resblock_apply_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (const float*)x1, s, g1, g2, extra, out, ldo, H, W, C);
     SPEI_CHECK_LAUNCH("spei_resblock_apply");
     return 0;
 }

@@ -72,16 +72,22 @@ def swin(sx: SwinX, feat: FMap, sw: dict, out: FMap) -> FMap:
         for bi, bk in enumerate(layer["blocks"]):
             shift = 0 if bi % 2 == 0 else 2
             nxt = bufs[bi % 2]
-            ops.layernorm(cur, out=xh)
-            ops.linear(xh, bk["wkv"], bk["bkv"], out=kv)
+            if ops.ln_fused_available():
+                ops.linear(cur, bk["wkv"], bk["bkv"], out=kv, ln_input=True)      # norm1 inside the GEMM's staging
+            else:
+                ops.layernorm(cur, out=xh)
+                ops.linear(xh, bk["wkv"], bk["bkv"], out=kv)
             ops.linear(yhat, bk["wq"], bk["bq"], out=q)
             ops.window_attention(q, kv, bk["relbias"], h, w, shift, out=att)
             ops.linear(att, bk["wproj"], bk["bproj"], residual=cur, out=nxt)
             if ops.mlp_fused_available():
                 ops.mlp_fused(nxt, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out=nxt)
             else:
-                ops.layernorm(nxt, out=xh)
-                ops.linear(xh, bk["w1"], bk["b1"], act=ACT_GELU, out=hid)
+                if ops.ln_fused_available():
+                    ops.linear(nxt, bk["w1"], bk["b1"], act=ACT_GELU, out=hid, ln_input=True)
+                else:
+                    ops.layernorm(nxt, out=xh)
+                    ops.linear(xh, bk["w1"], bk["b1"], act=ACT_GELU, out=hid)
                 ops.linear(hid, bk["w2"], bk["b2"], residual=nxt, out=nxt)
             cur = nxt
         # RSTB: conv3x3(blocks(x)) + x   (swinir.py:483-484), in place on the residual buffer

@@ -150,7 +150,8 @@ def conv5_out(f: FMap, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> t
 
 def igemm(a0: FMap, w: torch.Tensor, bias: Optional[torch.Tensor], N: int, ksize: int = 1, stride: int = 1,
           mode: int = CONV, act: int = ACT_NONE, a1: Optional[FMap] = None, residual: Optional[FMap] = None,
-          rowscale: Optional[torch.Tensor] = None, out: Optional[FMap] = None, out_dtype=torch.float32) -> FMap:
+          rowscale: Optional[torch.Tensor] = None, out: Optional[FMap] = None, out_dtype=torch.float32,
+          ln_input: bool = False) -> FMap:
     pad = ksize // 2
     if mode == CONV:
         ho, wo = (a0.H + 2 * pad - ksize) // stride + 1, (a0.W + 2 * pad - ksize) // stride + 1
@@ -164,6 +165,7 @@ def igemm(a0: FMap, w: torch.Tensor, bias: Optional[torch.Tensor], N: int, ksize
     assert slab or not (a0.bf16 or out.bf16), "bf16 activations are only supported by the slab kernel"
     assert a1 is None or a1.bf16 == a0.bf16
     assert residual is None or not residual.bf16
+    assert not ln_input or (slab and w.fhi is not None), "ln_input is a feature of the slab kernel"
     if torch.is_tensor(w):
         w = PackedW(w, a0.t.device)
     assert tuple(w.shape) == (ksize * ksize, N, k0 + k1), (tuple(w.shape), ksize, N, k0, k1)
@@ -184,7 +186,7 @@ def igemm(a0: FMap, w: torch.Tensor, bias: Optional[torch.Tensor], N: int, ksize
         _lib.check(_lib.lib().spei_conv_slab_bf16(
             *srcs, int(a0.bf16), _tp(w.fhi), _tp(w.flo) if PRECISION == "bf16x3" else _vp(0), _tp(bias), _vp(out.ptr), out.ld,
             int(out.bf16), _vp(residual.ptr if residual is not None else 0), residual.ld if residual is not None else 0,
-            _tp(rowscale), *dims, N, ksize, stride, pad, act, _stream()), "spei_conv_slab_bf16")
+            _tp(rowscale), *dims, N, ksize, stride, pad, act, int(ln_input), _stream()), "spei_conv_slab_bf16")
     else:
         _lib.check(_lib.lib().spei_igemm_bf16(*srcs, _tp(w.hi), _tp(w.lo) if PRECISION == "bf16x3" else _vp(0), _tp(bias), *common),
                    "spei_igemm_bf16")
@@ -192,7 +194,8 @@ def igemm(a0: FMap, w: torch.Tensor, bias: Optional[torch.Tensor], N: int, ksize
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: int = ACT_NONE,
-           residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_dtype=torch.float32) -> torch.Tensor:
+           residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_dtype=torch.float32,
+           ln_input: bool = False) -> torch.Tensor:
     """Token-space linear: x [M,K] -> [M,N]; w [N,K]."""
     m, k = x.shape
     if torch.is_tensor(w):
@@ -200,7 +203,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: int
     n = w.shape[1]
     if out is None:
         out = torch.empty(m, n, device=x.device, dtype=out_dtype)
-    igemm(FMap(x, m, 1, k), w, b, n, act=act,
+    igemm(FMap(x, m, 1, k), w, b, n, act=act, ln_input=ln_input,
           residual=FMap(residual, m, 1, n) if residual is not None else None, out=FMap(out, m, 1, n))
     return out
 
@@ -213,7 +216,7 @@ def resblock_gates(x1: FMap, pk: dict):
     g1 = torch.empty(x1.H, x1.C, device=dev)
     g2 = torch.empty(x1.W, x1.C, device=dev)
     ws = torch.empty(lib.spei_gate_ws_floats(x1.H, x1.W, x1.C), device=dev)
-    _lib.check(lib.spei_resblock_gates(_vp(x1.ptr), x1.H, x1.W, x1.C, _tp(pk["se_w1"]), _tp(pk["se_b1"]), _tp(pk["se_w2"]),
+    _lib.check(lib.spei_resblock_gates(_vp(x1.ptr), int(x1.bf16), x1.H, x1.W, x1.C, _tp(pk["se_w1"]), _tp(pk["se_b1"]), _tp(pk["se_w2"]),
                                        _tp(pk["se_b2"]), _tp(pk["cw_w"]), _tp(pk["cw_bn"]), _tp(pk["hc_w"]), _tp(pk["hc_bn"]),
                                        _tp(s), _tp(g1), _tp(g2), _tp(ws), _stream()), "spei_resblock_gates")
     return s, g1, g2
@@ -224,19 +227,25 @@ def resblock(x: FMap, pk: dict, extra: Optional[FMap] = None, out: Optional[FMap
     c = x.C
     assert x.off == 0 and x.ld == c
     t = igemm(x, pk["w1"], pk["b1"], c, ksize=5, act=ACT_RELU, out_dtype=inter_dtype())   # only conv2 reads it
-    x1 = igemm(t, pk["w2"], pk["b2"], c, ksize=5)
+    x1 = igemm(t, pk["w2"], pk["b2"], c, ksize=5, out_dtype=inter_dtype() if X1_BF16 else torch.float32)
     s, g1, g2 = resblock_gates(x1, pk)
     if out is None:
         out = FMap.empty(x.H, x.W, c, x.t.device)
     if extra is not None:
         assert extra.off == 0 and extra.ld == c
-    _lib.check(_lib.lib().spei_resblock_apply(_vp(x.ptr), _vp(x1.ptr), _tp(s), _tp(g1), _tp(g2),
+    _lib.check(_lib.lib().spei_resblock_apply(_vp(x.ptr), _vp(x1.ptr), int(x1.bf16), _tp(s), _tp(g1), _tp(g2),
                                               _vp(extra.ptr if extra is not None else 0), _vp(out.ptr), out.ld, x.H, x.W, c,
                                               _stream()), "spei_resblock_apply")
     return out
 
 
+X1_BF16 = True       # "bf16" mode: the ResBlock's conv2 output (read by the gate statistics and the apply pass) is bf16
 FUSE_MLP = True      # "bf16" mode: LayerNorm -> fc1 -> GELU -> fc2 -> +x in one kernel (mlp_fused_bf16.hip)
+
+
+def ln_fused_available() -> bool:
+    """LayerNorm folded into the staging of the following 256-wide linear (slab kernel, any bf16 mode)."""
+    return PRECISION != "f32" and USE_SLAB
 
 
 def mlp_fused_available() -> bool:
