@@ -97,8 +97,6 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
     const int pitch = 2 * p.K + 16;
     unsigned char* slab = smem;
     int* goff = reinterpret_cast<int*>(smem + (SPLIT ? 2 : 1) * p.slab_bytes);
-    // per-wave 32 x 32 fp32 staging tile (row pitch 36 floats) for the transposing epilogue
-    float* etile = reinterpret_cast<float*>(smem + (SPLIT ? 2 : 1) * p.slab_bytes + p.goff_bytes) + (threadIdx.x >> 6) * (32 * EP);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -291,15 +289,15 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
         // Row / address math is invariant across the chunk loop: launder one input so the compiler does not hoist
         // ~200 registers of addresses out of the loop and starve the main loop (measured: 255 VGPRs, serialised MFMAs).
         // The accumulator holds one column (n) per lane and 16 rows in registers: stored directly that is 4 bytes per
-        // lane per instruction.  Transpose each 32 x 32 tile through a per-wave LDS tile instead, so that every lane owns
-        // 4 consecutive channels of one output row: residual loads and stores are 16 B per lane, 8 full 128-byte row
-        // segments per instruction (4 instead of 16 store instructions per tile).
+        // lane per instruction.  A 4x4 transpose inside each lane quad (DPP, no LDS) gives every lane 4 consecutive
+        // channels of one output row: residual loads and stores are 16 B per lane, full 128-byte row segments,
+        // 4 instead of 16 store instructions per 32 x 32 tile.
         int fk_e = fk;
         asm volatile("" : "+v"(fk_e));
         TO* outp = static_cast<TO*>(p.out);
-        int lane_e = lane;
-        asm volatile("" : "+v"(lane_e));
-        const int erow = lane_e >> 3, ecol = (lane_e & 7) * 4;
+        int fr_e = fr;
+        asm volatile("" : "+v"(fr_e));
+        const int et = fr_e & 3, ecol = (fr_e >> 2) * 4;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -307,20 +305,20 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
                 const int ncol0 = (nbase + j) * 32;
                 const float bias = p.bias ? p.bias[ncol0 + fr] : 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int q = (r & 3) + 8 * (r >> 2) + 4 * fk_e;
-                    float v = acc[i][j][r] + bias;
-                    if (p.act == SPEI_ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (p.act == SPEI_ACT_GELU) v = gelu_erf(v);
-                    etile[q * EP + fr] = v;
-                }
-                // same wave wrote and reads: DS operations of one wave complete in order, no barrier needed
-#pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int q = erow + 8 * k;
+                    float a[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[i][j][4 * k + e] + bias;
+                        if (p.act == SPEI_ACT_RELU) v = fmaxf(v, 0.f);
+                        else if (p.act == SPEI_ACT_GELU) v = gelu_erf(v);
+                        a[e] = v;
+                    }
+                    quad_transpose4(a[0], a[1], a[2], a[3], et);
+                    const int q = 8 * k + 4 * fk_e + et;         // accumulator row (r&3) + 8*(r>>2) + 4*fk with r = 4k + et
                     if (q < qlim[i] && !(p.dbg & 4)) {
                         const unsigned m = (unsigned)(mbase[i] + q);
-                        f32x4 v = *reinterpret_cast<const f32x4*>(etile + q * EP + ecol);
+                        f32x4 v = f32x4{a[0], a[1], a[2], a[3]};
                         if (p.rowscale) { const float rs = p.rowscale[m]; v *= rs; }
                         if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * (unsigned)p.ldr + ncol0 + ecol);
                         if (sizeof(TO) == 4) {
@@ -377,7 +375,7 @@ int dispatch(SlabParams& p, hipStream_t s) {
         for (int sft = 0; sft <= 8; ++sft) if ((1 << sft) == cpn) p.cp_shift = sft;
         p.iw_magic = ((1 << 20) + p.IW - 1) / p.IW;
         p.goff_bytes = ((ngroups * (int)sizeof(int) + 15) / 16) * 16;
-        return (size_t)nparts * p.slab_bytes + (size_t)p.goff_bytes + (size_t)4 * 32 * EP * sizeof(float);
+        return (size_t)nparts * p.slab_bytes + (size_t)p.goff_bytes;
     };
     const size_t budget = 96 * 1024;
     const size_t hard = 160 * 1024 - 512;
@@ -385,7 +383,7 @@ int dispatch(SlabParams& p, hipStream_t s) {
     if (p.N % 128 == 0) {
         lds = setup(128);
         const int64_t tiles128 = (int64_t)p.tiles_x * cdiv(p.Hout, p.TH);
-        static const int min_tiles = getenv("SPEI_SLAB_MIN_TILES128") ? atoi(getenv("SPEI_SLAB_MIN_TILES128")) : 1024;
+        static const int min_tiles = getenv("SPEI_SLAB_MIN_TILES128") ? atoi(getenv("SPEI_SLAB_MIN_TILES128")) : 0;
         if (lds <= budget && tiles128 >= min_tiles && p.IH * p.IW < 2048) return launch<1, 4, 4, 1, SPLIT, TA, TO>(p, lds, s);
         lds = setup(64);
         if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 4, 2, 1, SPLIT, TA, TO>(p, lds, s);
