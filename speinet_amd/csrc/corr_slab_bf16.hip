@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void corr_slab_kernel(const CorrSlabParams p) 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* lslab = smem;                                   // [NPART][L_BYTES]
     unsigned char* rslab = smem + NPART * L_BYTES;                 // [2 buffers][NPART][R_BYTES]
+    float* inv_s = reinterpret_cast<float*>(smem + NPART * L_BYTES + 2 * NPART * R_BYTES);   // [2][128] 1/|patch| of the block
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;           // 2 waves along j (64 rows each), 2 along i
@@ -80,10 +81,15 @@ __global__ __launch_bounds__(256) void corr_slab_kernel(const CorrSlabParams p) 
 
     // ---- reference stage loader -------------------------------------------------------------------------
     u32x4 rh[RLOADS], rl[SPLIT ? RLOADS : 1];
+    float riv = 0.f;
     auto load_stage = [&](int stage) __attribute__((always_inline)) {                 // stage = (rb - rb0) * NCH + chunk
         const int rb = rb0 + stage / NCH, ch = stage % NCH;
         const int rby = rb / p.rblocks_x, rbx = rb - rby * p.rblocks_x;
         const int jy0 = rby * RB_H - 1, jx0 = rbx * RB_W - 1;
+        if (ch == 0 && tid < RB_H * RB_W) {              // the block's normalisers ride along with its first stage
+            const int jy = rby * RB_H + (tid >> 5), jx = rbx * RB_W + (tid & 31);
+            riv = (jy < p.Hr && jx < p.Wr) ? p.inv_ref[jy * p.Wr + jx] : 0.f;
+        }
 #pragma unroll
         for (int u = 0; u < RLOADS; ++u) {
             const int idx = tid + u * 256;
@@ -96,8 +102,9 @@ __global__ __launch_bounds__(256) void corr_slab_kernel(const CorrSlabParams p) 
             if (SPLIT) rl[u] = ok ? *reinterpret_cast<const u32x4*>(p.refl + o) : zero4;
         }
     };
-    auto store_stage = [&](int buf) __attribute__((always_inline)) {
+    auto store_stage = [&](int buf, int stage) __attribute__((always_inline)) {
         unsigned char* base = rslab + buf * NPART * R_BYTES;
+        if (stage % NCH == 0 && tid < RB_H * RB_W) inv_s[((stage / NCH) & 1) * (RB_H * RB_W) + tid] = riv;
 #pragma unroll
         for (int u = 0; u < RLOADS; ++u) {
             const int idx = tid + u * 256;
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(256) void corr_slab_kernel(const CorrSlabParams p) 
     const int nstages = (rb1 - rb0) * NCH;
     if (nstages > 0) {
         load_stage(0);
-        store_stage(0);
+        store_stage(0, 0);
     }
     __syncthreads();
 
@@ -151,37 +158,47 @@ __global__ __launch_bounds__(256) void corr_slab_kernel(const CorrSlabParams p) 
         if (st + 1 < nstages) load_stage(st + 1);
         const unsigned char* ra = rslab + buf * NPART * R_BYTES;
         const unsigned char* lb = lslab + ch * (KC * 2);
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
+        // Software-pipelined over the 9 taps x KC/16 k-steps: the fragments of step s+1 are requested from LDS before
+        // the MFMAs of step s issue (two register sets), and sched_group_barrier pins that interleave — left alone the
+        // compiler reuses three fragment registers and waits on every ds_read right before its MFMA (29 % MFMA rate).
+        constexpr int KS = KC / 16, NS = 9 * KS;
+        constexpr int NRD = (2 + TN) * NPART, NMF = 2 * TN * (SPLIT ? 3 : 1);
+        bf16x8 fa[2][2], fb[2][TN], fal[2][2], fbl[2][TN];
+        auto load_frags = [&](int s, int slot) __attribute__((always_inline)) {
+            const int t = s / KS, ks = s - t * KS;
             const int ty = t / 3, tx = t - ty * 3;
-            const int aoff = (ty * SLAB_W + tx) * PITCH_R;
-            const int boff = (ty * SLAB_W + tx) * PITCH_L;
+            const int aoff = (ty * SLAB_W + tx) * PITCH_R + ks * 32;
+            const int boff = (ty * SLAB_W + tx) * PITCH_L + ks * 32;
 #pragma unroll
-            for (int ks = 0; ks < KC / 16; ++ks) {
-                bf16x8 av[2], bv[TN], avl[2], bvl[TN];
+            for (int i = 0; i < 2; ++i) {
+                fa[slot][i] = *reinterpret_cast<const bf16x8*>(ra + abase[i] + aoff);
+                if (SPLIT) fal[slot][i] = *reinterpret_cast<const bf16x8*>(ra + R_BYTES + abase[i] + aoff);
+            }
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    av[i] = *reinterpret_cast<const bf16x8*>(ra + abase[i] + aoff + ks * 32);
-                    if (SPLIT) avl[i] = *reinterpret_cast<const bf16x8*>(ra + R_BYTES + abase[i] + aoff + ks * 32);
-                }
+            for (int j = 0; j < TN; ++j) {
+                fb[slot][j] = *reinterpret_cast<const bf16x8*>(lb + bbase[j] + boff);
+                if (SPLIT) fbl[slot][j] = *reinterpret_cast<const bf16x8*>(lb + L_BYTES + bbase[j] + boff);
+            }
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int cur = s & 1;
+            if (s + 1 < NS) load_frags(s + 1, cur ^ 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    bv[j] = *reinterpret_cast<const bf16x8*>(lb + bbase[j] + boff + ks * 32);
-                    if (SPLIT) bvl[j] = *reinterpret_cast<const bf16x8*>(lb + L_BYTES + bbase[j] + boff + ks * 32);
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        if (SPLIT) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avl[i], bv[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bvl[j], acc[i][j], 0, 0, 0);
-                        }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    if (SPLIT) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fbl[cur][j], acc[i][j], 0, 0, 0);
                     }
-            }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+                }
+            if (s + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);   // DS reads of step s+1 ...
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);                    // ... then the MFMAs of step s
         }
-        if (st + 1 < nstages) store_stage(buf ^ 1);
+        if (st + 1 < nstages) store_stage(buf ^ 1, st + 1);
         if (ch == NCH - 1) {
             // reference block finished: fold its 128 rows into the running (max, argmax) of this lane's columns
             const int rb = rb0 + st / NCH;
@@ -194,7 +211,7 @@ __global__ __launch_bounds__(256) void corr_slab_kernel(const CorrSlabParams p) 
                     const int jx = rbx * RB_W + (r & 3) + 8 * (r >> 2) + 4 * fk;
                     if (jy < p.Hr && jx < p.Wr) {
                         const int jj = jy * p.Wr + jx;
-                        const float ir = p.inv_ref[jj];
+                        const float ir = inv_s[((st / NCH) & 1) * (RB_H * RB_W) + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk];
 #pragma unroll
                         for (int j = 0; j < TN; ++j) {
                             const float v = acc[i][j][r] * ir * il[j];
@@ -256,7 +273,7 @@ void launch_corr(const CorrSlabParams& p, int itiles, int splits, hipStream_t st
     constexpr int NPART = SPLIT ? 2 : 1;
     constexpr int L_BYTES = ((((NI + 2) * SLAB_W) * (2 * C + 16) + 15) / 16) * 16;
     constexpr int R_BYTES = ((((RB_H + 2) * SLAB_W) * (2 * KC + 16) + 15) / 16) * 16;
-    const size_t lds = (size_t)NPART * L_BYTES + (size_t)2 * NPART * R_BYTES;
+    const size_t lds = (size_t)NPART * L_BYTES + (size_t)2 * NPART * R_BYTES + (size_t)2 * RB_H * RB_W * sizeof(float);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_slab_kernel<NI, KC, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
