@@ -247,20 +247,64 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+        // A fragments are software-pipelined one k-step ahead (two register sets) and sched_group_barrier pins
+        // "LDS reads of step s+1, then MFMAs of step s": left alone the compiler waits on each ds_read right before its MFMA.
+        constexpr int NRD = TM * (SPLIT ? 2 : 1), NMF = TM * TN * (SPLIT ? 3 : 1);
+        bf16x8 an[TM], anl[SPLIT ? TM : 1];
+        auto load_a = [&](int off) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                an[i] = *reinterpret_cast<const bf16x8*>(slab + abase[i] + off);
+                if (SPLIT) anl[i] = *reinterpret_cast<const bf16x8*>(slab + p.slab_bytes + abase[i] + off);
+            }
+        };
+        int go = goff[0];
+        if constexpr (!SPLIT) load_a(go);
+        if constexpr (SPLIT) {
+            // split mode keeps the plain loop (the pipelined form produced wrong lanes there; not yet understood)
+            for (int g0 = 0; g0 < ngroups; g0 += RING) {
+#pragma unroll
+                for (int d = 0; d < RING; ++d) {
+                    const int g = g0 + d;
+                    if (g < ngroups) {
+                        const int gs = goff[g];
+#pragma unroll
+                        for (int s = 0; s < G; ++s) {
+                            bf16x8 av[TM], avl[TM];
+#pragma unroll
+                            for (int i = 0; i < TM; ++i) {
+                                av[i] = *reinterpret_cast<const bf16x8*>(slab + abase[i] + gs + s * 32);
+                                avl[i] = *reinterpret_cast<const bf16x8*>(slab + p.slab_bytes + abase[i] + gs + s * 32);
+                            }
+#pragma unroll
+                            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                                for (int j = 0; j < TN; ++j) {
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avl[i], bring[d][s][j], acc[i][j], 0, 0, 0);
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bring_lo[SPLIT ? d : 0][s][j], acc[i][j], 0, 0, 0);
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bring[d][s][j], acc[i][j], 0, 0, 0);
+                                }
+                        }
+                        if (g + RING < ngroups) load_b(d, g + RING);
+                    }
+                }
+            }
+        } else
         for (int g0 = 0; g0 < ((p.dbg & 2) ? 0 : ngroups); g0 += RING) {
 #pragma unroll
             for (int d = 0; d < RING; ++d) {
                 const int g = g0 + d;
                 if (g < ngroups) {
-                    const int go = goff[g];
+                    const int go_next = goff[min(g + 1, ngroups - 1)];
 #pragma unroll
                     for (int s = 0; s < G; ++s) {
                         bf16x8 av[TM], avl[SPLIT ? TM : 1];
 #pragma unroll
                         for (int i = 0; i < TM; ++i) {
-                            av[i] = *reinterpret_cast<const bf16x8*>(slab + abase[i] + go + s * 32);
-                            if (SPLIT) avl[i] = *reinterpret_cast<const bf16x8*>(slab + p.slab_bytes + abase[i] + go + s * 32);
+                            av[i] = an[i];
+                            if (SPLIT) avl[i] = anl[i];
                         }
+                        load_a(s + 1 < G ? go + (s + 1) * 32 : go_next);     // (the very last prefetch is a harmless re-read)
 #pragma unroll
                         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -271,7 +315,12 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
                                 }
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bring[d][s][j], acc[i][j], 0, 0, 0);
                             }
+                        if constexpr (!SPLIT) {
+                            __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+                        }
                     }
+                    go = go_next;
                     if (g + RING < ngroups) load_b(d, g + RING);
                 }
             }
