@@ -94,14 +94,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if "RANK" in os.environ:            # launched by torch.distributed.run: one rank per GPU over RCCL, also for N = 1
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        assert dist.get_world_size() == world
     else:
+        local = 0
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local if world > 1 else 0)
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run for N > 1", file=sys.stderr)
+    dev = torch.device("cuda", local)
 
     from speinet_amd import ops
     from speinet_amd.speinet import SPEINet, default_args

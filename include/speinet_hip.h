@@ -156,6 +156,13 @@ int spei_upsample_bicubic(const float* in, int ldi, float* out, int ldo, int H, 
 /* K14 — out = a + b over n floats. */
 int spei_add(const float* a, const float* b, float* out, int64_t n, spei_stream_t stream);
 
+/* Row a11 — LD sharpness detector features (inference_SPEINet.py:54-189).  spei_det_gray: [N][3][H][W] fp32 0..255 ->
+ * gray [N][H][W] in 0..1 (ITU-R 601 weights).  spei_det_features: gray -> out [N][6] = LAP1, MIS3, WAV1, GRA7, STA3, DCT3
+ * with window size k (odd; the reference uses 11).  ws: spei_det_ws_floats(N,H,W,k) floats. */
+int spei_det_gray(const float* rgb, float* gray, int N, int H, int W, spei_stream_t stream);
+int64_t spei_det_ws_floats(int N, int H, int W, int k);
+int spei_det_features(const float* gray, float* out, float* ws, int N, int H, int W, int k, spei_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,9 @@ SIGNATURES = {
     "spei_rot90": (I, [P, I, P, I, I, I, P]),
     "spei_upsample_bicubic": (I, [P, I, P, I, I, I, I, I, P]),
     "spei_add": (I, [P, P, P, L, P]),
+    "spei_det_gray": (I, [P, P, I, I, I, P]),
+    "spei_det_ws_floats": (L, [I, I, I, I]),
+    "spei_det_features": (I, [P, P, P, I, I, I, I, P]),
 }
 
 
