@@ -1,0 +1,190 @@
+"""Harness counterpart of the reference's `inference_SPEINet.py`: same flags, data layout,
+selection logic, uint8 round trip, PSNR/SSIM and log-line format — with the forward pass on the HIP path, an explicit
+`--device`, presets that no longer clobber explicit paths, and clip sharding over ranks instead of DataParallel.
+
+    <data_path>/{blur,gt}/<clip>/<frame>.png       [<data_path>/label/<clip>.npy  (0/1 per frame, 1 = sharp)]
+
+Without a label file the LD detector (speinet_amd.detector, row a11) labels the frames on the GPU.
+Reference: inference_SPEINet.py:193-237 (__init__), :338-429 (infer), :484-543 (metrics), :610-700 (flags / presets).
+SSIM is restated with numpy (cv2 is absent): Gaussian 11x11, sigma 1.5, valid region — parity unpinned.
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import detector, selection
+from .dist import gather_metrics, shard_clips_by_length
+from .speinet import SPEINet, default_args
+
+
+def _imread(path: str) -> np.ndarray:
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("RGB"))
+
+
+def _imwrite(path: str, img: np.ndarray) -> None:
+    from PIL import Image
+    Image.fromarray(img).save(path)
+
+
+def calc_ssim(img1: np.ndarray, img2: np.ndarray) -> float:
+    """inference_SPEINet.py:502-543: the reference averages the same 3-channel value three times."""
+    ax = np.arange(11) - 5
+    k = np.exp(-(ax ** 2) / (2 * 1.5 ** 2))
+    k /= k.sum()
+    win = np.outer(k, k)
+    c1, c2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    a, b = img1.astype(np.float64), img2.astype(np.float64)
+
+    def filt(x):   # valid region only ([5:-5, 5:-5] of the reference's same-size filter2D)
+        from numpy.lib.stride_tricks import sliding_window_view
+        v = sliding_window_view(x, (11, 11), axis=(0, 1))
+        return np.einsum("ijc...kl,kl->ijc...", v, win) if x.ndim == 3 else np.einsum("ijkl,kl->ij", v, win)
+
+    mu1, mu2 = filt(a), filt(b)
+    s1, s2, s12 = filt(a * a) - mu1 ** 2, filt(b * b) - mu2 ** 2, filt(a * b) - mu1 * mu2
+    m = ((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 ** 2 + mu2 ** 2 + c1) * (s1 + s2 + c2))
+    return float(m.mean())
+
+
+class Logger:
+    def __init__(self, result_dir: str, name: str, echo: bool = True):
+        os.makedirs(result_dir, exist_ok=True)
+        self.f = open(os.path.join(result_dir, name), "a")
+        self.echo = echo
+
+    def write_log(self, line: str) -> None:
+        if self.echo:
+            print(line)
+        self.f.write(line + "\n")
+        self.f.flush()
+
+
+class Inference:
+    def __init__(self, args):
+        self.args = args
+        self.n_seq = args.n_sequence
+        self.device = torch.device(args.device)
+        self.rank, self.world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        now = time.strftime("%Y-%m-%d %H:%M:%S", time.localtime())
+        self.logger = Logger(args.result_path, f"inference_log_{now}_rank{self.rank}.txt", echo=self.rank == 0)
+        for k in ("save_image", "border", "model_path", "data_path", "result_path"):
+            self.logger.write_log(f"{k}: {getattr(args, k)}")
+        self.net = SPEINet(in_channels=3, n_sequence=self.n_seq, out_channels=3, n_resblock=3, n_feat=32, device=str(self.device), args=args)
+        if args.model_path and args.model_path != "synthetic":
+            self.net.load_state_dict(torch.load(args.model_path, map_location="cpu", weights_only=True))      # strict, like :232
+        else:
+            from .synth import state_dict_template, synth_state_dict
+            self.net.load_state_dict(synth_state_dict(state_dict_template(), seed=0))
+        self.net = self.net.to(self.device).eval()
+        self.net.precision = args.precision
+        self.net.corr_precision = args.precision if args.precision != "f32" else "bf16x3"
+
+    def labels_for(self, clip: str, frames: list) -> np.ndarray:
+        p = os.path.join(self.args.data_path, "label", clip + ".npy")
+        if os.path.exists(p):
+            return np.load(p)                                   # allow_pickle=False: plain int arrays only
+        imgs = torch.from_numpy(np.stack([_imread(f) for f in frames]).astype(np.float32)).permute(0, 3, 1, 2)
+        feats = torch.cat([detector.focus_measures(imgs[i:i + 16].to(self.device), 11) for i in range(0, len(imgs), 16)])
+        return detector.predict(feats)
+
+    def infer(self):
+        a = self.args
+        clips = sorted(os.listdir(os.path.join(a.data_path, "blur")))
+        lengths = [len(glob.glob(os.path.join(a.data_path, "blur", c, "*"))) for c in clips]
+        mine = shard_clips_by_length(lengths, self.world)[self.rank]
+        stats = torch.zeros(3, dtype=torch.float64)             # sum psnr, sum ssim, frames
+        with torch.no_grad():
+            for ci in mine:
+                clip = clips[ci]
+                blur = sorted(glob.glob(os.path.join(a.data_path, "blur", clip, "*")))
+                gts = sorted(glob.glob(os.path.join(a.data_path, "gt", clip, "*")))
+                wins = selection.assemble_windows(blur, self.labels_for(clip, blur), self.n_seq, a.border)
+                gt_seqs, _ = selection.gene_seq(gts, self.n_seq, a.border)
+                vp, vs = [], []
+                for w, gseq in zip(wins, gt_seqs):
+                    t0 = time.time()
+                    imgs = [_imread(p) for p in w["window"] + [w["pre"], w["sub"]]]
+                    gt = _imread(gseq[self.n_seq // 2])
+                    h, wd = imgs[self.n_seq // 2].shape[:2]
+                    nh, nw = h - h % 20, wd - wd % 20           # the model needs multiples of 20 (reference crops to 4)
+                    imgs = [im[:nh, :nw] for im in imgs]
+                    gt = gt[:nh, :nw]
+                    if w["zero_pre"]:
+                        imgs[-2] = np.zeros_like(imgs[-2])
+                    if w["zero_sub"]:
+                        imgs[-1] = np.zeros_like(imgs[-1])
+                    x = selection.numpy2tensor(imgs).to(self.device)
+                    t1 = time.time()
+                    out = self.net(x, routing=[bool(w["zero_pre"])])
+                    torch.cuda.synchronize()
+                    t2 = time.time()
+                    out_img = selection.tensor2numpy(out)
+                    psnr = selection.calc_psnr(gt[4:-4, 4:-4], out_img[4:-4, 4:-4])
+                    ssim = calc_ssim(gt[4:-4, 4:-4], out_img[4:-4, 4:-4])
+                    vp.append(psnr)
+                    vs.append(ssim)
+                    if a.save_image:
+                        os.makedirs(os.path.join(a.result_path, clip), exist_ok=True)
+                        _imwrite(os.path.join(a.result_path, clip, w["name"] + ".png"), out_img)
+                    t3 = time.time()
+                    self.logger.write_log('> {}-{} PSNR={:.5}, SSIM={:.4} pre_time:{:.3}s, forward_time:{:.3}s, post_time:{:.3}s, total_time:{:.3}s'
+                                          .format(clip, w["name"], psnr, ssim, t1 - t0, t2 - t1, t3 - t2, t3 - t0))
+                self.logger.write_log("# Video:{} AVG-PSNR={:.5}, AVG-SSIM={:.4}".format(clip, sum(vp) / len(vp), sum(vs) / len(vs)))
+                stats += torch.tensor([sum(vp), sum(vs), float(len(vp))], dtype=torch.float64)
+        dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+        allm = gather_metrics(stats.to(self.device) if self.world > 1 else stats, dist)
+        tot = allm.sum(dim=0)
+        if self.rank == 0 and tot[2] > 0:
+            self.logger.write_log("# Total AVG-PSNR={:.5}, AVG-SSIM={:.4}".format(tot[0].item() / tot[2].item(), tot[1].item() / tot[2].item()))
+        return tot
+
+
+PRESETS = {   # inference_SPEINet.py:626-697 (paths only fill in what the command line left at its default)
+    "REDS": dict(data_path="./data/deblur/REDS_8x_Random/test", model_path="../experiment/model/model_best.pt", result_path="../infer_results/bsdtest_reds"),
+    "GOPRO": dict(data_path="./data/deblur/GOPRO/test", model_path="../experiment/model/model_best.pt", result_path="../infer_results/gopro"),
+    "BSD": dict(data_path="./data/deblur/BSDtest", model_path="./model/model_best.pt", result_path="../infer_results/BSDtest_finetune"),
+    "BSDtest_all": dict(data_path="./data/deblur/BSDtest_all/BSD_3ms24ms", model_path="./model/model_best.pt", result_path="../infer_results/BSD_1ms8ms"),
+}
+
+
+def build_args(argv=None):
+    p = argparse.ArgumentParser(description="SPEINet inference (MI355X)")
+    p.add_argument("--save_image", action="store_true", default=True)
+    p.add_argument("--no_save_image", dest="save_image", action="store_false")
+    p.add_argument("--border", action="store_true", default=True)
+    p.add_argument("--default_data", type=str, default="BSDtest_all")
+    p.add_argument("--data_path", type=str, default=None)
+    p.add_argument("--model_path", type=str, default=None)
+    p.add_argument("--result_path", type=str, default=None)
+    p.add_argument("--device", type=str, default="cuda")
+    p.add_argument("--precision", choices=["f32", "bf16x3", "bf16"], default="f32")
+    a = p.parse_args(argv)
+    for k, v in PRESETS.get(a.default_data, {}).items():
+        if getattr(a, k) is None:
+            setattr(a, k, v)
+    for k, v in vars(default_args()).items():
+        setattr(a, k, v)
+    return a
+
+
+def main(argv=None):
+    a = build_args(argv)
+    if "RANK" in os.environ:
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        a.device = f"cuda:{os.environ.get('LOCAL_RANK', '0')}"
+        dist.init_process_group("nccl")
+    Inference(a).infer()
+
+
+if __name__ == "__main__":
+    main()
