@@ -106,6 +106,10 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
     const int ks16 = p.K / 16;
     const int kg_per_tap = ks16 / G;
     const int ngroups = p.ks * p.ks * kg_per_tap;
+    // every workgroup walks the (tap, K group) sequence from a different start: otherwise all CUs stream the same weight
+    // fragment from the same L2 channel at the same time
+    const int rot = (blockIdx.x * 7) % ngroups;
+    auto rg = [&](int g) __attribute__((always_inline)) { const int r = g + rot; return r >= ngroups ? r - ngroups : r; };
 
     // ---- group -> slab byte offset table ------------------------------------------------------------
     for (int g = tid; g < ngroups; g += 256) {
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int d = 0; d < RING; ++d)
-        if (d < ngroups) load_b(d, d);
+        if (d < ngroups) load_b(d, rg(d));
 
     __syncthreads();     // slab + offset table visible; the only barrier of the kernel
 
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
                 if (SPLIT) anl[i] = *reinterpret_cast<const bf16x8*>(slab + p.slab_bytes + abase[i] + off);
             }
         };
-        int go = goff[0];
+        int go = goff[rg(0)];
         if constexpr (!SPLIT) load_a(go);
         if constexpr (SPLIT) {
             // split mode keeps the plain loop (the pipelined form produced wrong lanes there; not yet understood)
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
                 for (int d = 0; d < RING; ++d) {
                     const int g = g0 + d;
                     if (g < ngroups) {
-                        const int gs = goff[g];
+                        const int gs = goff[rg(g)];
 #pragma unroll
                         for (int s = 0; s < G; ++s) {
                             bf16x8 av[TM], avl[TM];
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
                                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bring[d][s][j], acc[i][j], 0, 0, 0);
                                 }
                         }
-                        if (g + RING < ngroups) load_b(d, g + RING);
+                        if (g + RING < ngroups) load_b(d, rg(g + RING));
                     }
                 }
             }
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
             for (int d = 0; d < RING; ++d) {
                 const int g = g0 + d;
                 if (g < ngroups) {
-                    const int go_next = goff[min(g + 1, ngroups - 1)];
+                    const int go_next = goff[rg(min(g + 1, ngroups - 1))];
 #pragma unroll
                     for (int s = 0; s < G; ++s) {
                         bf16x8 av[TM], avl[SPLIT ? TM : 1];
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
                         }
                     }
                     go = go_next;
-                    if (g + RING < ngroups) load_b(d, g + RING);
+                    if (g + RING < ngroups) load_b(d, rg(g + RING));
                 }
             }
         }
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
             set_chunk(nc + 1);
 #pragma unroll
             for (int d = 0; d < RING; ++d)
-                if (d < ngroups) load_b(d, d);
+                if (d < ngroups) load_b(d, rg(d));
         }
 
         // ---- epilogue ----------------------------------------------------------------------------------------
@@ -440,8 +444,9 @@ int dispatch(SlabParams& p, hipStream_t s) {
         lds = setup(128);
         if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 2, 2, 1, SPLIT, TA, TO>(p, lds, s);
     } else {
+        static const int n32_tile = getenv("SPEI_SLAB_N32_TILE") ? atoi(getenv("SPEI_SLAB_N32_TILE")) : 256;
         lds = setup(256);
-        if (lds <= budget && p.IH * p.IW < 2048) return launch<4, 1, 2, 1, SPLIT, TA, TO>(p, lds, s);
+        if (n32_tile == 256 && lds <= budget && p.IH * p.IW < 2048) return launch<4, 1, 2, 1, SPLIT, TA, TO>(p, lds, s);
         lds = setup(128);
         if (lds <= hard && p.IH * p.IW < 2048) return launch<4, 1, 1, 1, SPLIT, TA, TO>(p, lds, s);
     }

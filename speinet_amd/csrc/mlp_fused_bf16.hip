@@ -86,15 +86,19 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams p) {
         for (int s = 0; s < G; ++s) bring[slot][s] = *reinterpret_cast<const bf16x8*>(bptr + (size_t)(g * G + s) * 512);
     };
     // weight stream of the first fc1 pass starts before the barrier
+    // Every workgroup walks the K dimension of each GEMM from a different starting group (rot): otherwise all 256 CUs
+    // request the same weight fragment from the same L2 channel at the same time.
+    constexpr int NG1 = (D / 16) / G;                       // 8 groups per 32-column tile of fc1
+    constexpr int NG2 = (HID / 16) / G;                     // 16 groups per tile of fc2
+    const int rot1 = blockIdx.x & (NG1 - 1), rot2 = (blockIdx.x * 5) & (NG2 - 1);
     bptr = p.w1 + (size_t)wn * (D / 16) * 512 + lane * 8;
 #pragma unroll
-    for (int d = 0; d < RING; ++d) load_b(d, d);
+    for (int d = 0; d < RING; ++d) load_b(d, (d + rot1) & (NG1 - 1));
     __syncthreads();
 
     // ---- 2. fc1 + GELU -> hidden slab ------------------------------------------------------------------------------
     // every B fragment is fetched by exactly one wave of the workgroup and used for both token halves
     const unsigned char* abase = sa + fr * PA + fk * 16;
-    constexpr int NG1 = (D / 16) / G;                       // 8 groups per 32-column tile
     for (int pass = 0; pass < HID / 256; ++pass) {
         const int nt = pass * 8 + wn;                       // 32-column tile of the hidden dim
         f32x16 acc[2];
@@ -106,22 +110,23 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams p) {
         for (int g0 = 0; g0 < NG1; g0 += RING) {
 #pragma unroll
             for (int d = 0; d < RING; ++d) {
-                const int g = g0 + d;
+                const int g = g0 + d, gr = (g + rot1) & (NG1 - 1);
 #pragma unroll
                 for (int s = 0; s < G; ++s) {
-                    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(abase + (g * G + s) * 32);
-                    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(abase + 32 * PA + (g * G + s) * 32);
+                    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(abase + (gr * G + s) * 32);
+                    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(abase + 32 * PA + (gr * G + s) * 32);
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bring[d][s], acc[0], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bring[d][s], acc[1], 0, 0, 0);
                 }
-                if (g + RING < NG1) load_b(d, g + RING);
+                if (g + RING < NG1) load_b(d, (g + RING + rot1) & (NG1 - 1));
             }
         }
         // next pass's (or fc2's) weight stream
-        if (pass + 1 < HID / 256) bptr = p.w1 + (size_t)(nt + 8) * (D / 16) * 512 + lane * 8;
+        const bool more1 = pass + 1 < HID / 256;
+        if (more1) bptr = p.w1 + (size_t)(nt + 8) * (D / 16) * 512 + lane * 8;
         else bptr = p.w2 + (size_t)wn * (HID / 16) * 512 + lane * 8;
 #pragma unroll
-        for (int d = 0; d < RING; ++d) load_b(d, d);
+        for (int d = 0; d < RING; ++d) load_b(d, more1 ? ((d + rot1) & (NG1 - 1)) : ((d + rot2) & (NG2 - 1)));
         const float bias = p.b1[nt * 32 + fr];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -135,7 +140,6 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams p) {
 
     // ---- 3. fc2 + bias + residual ------------------------------------------------------------------------------------
     const unsigned char* hbase = sh + fr * PH + fk * 16;
-    constexpr int NG2 = (HID / 16) / G;                     // 16 groups
     const int erow = lane >> 3, ecol = (lane & 7) * 4;
     {
         const int nt = wn;                                  // 8 waves x 32 columns = the 256 output channels
@@ -148,15 +152,15 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams p) {
         for (int g0 = 0; g0 < NG2; g0 += RING) {
 #pragma unroll
             for (int d = 0; d < RING; ++d) {
-                const int g = g0 + d;
+                const int g = g0 + d, gr = (g + rot2) & (NG2 - 1);
 #pragma unroll
                 for (int s = 0; s < G; ++s) {
-                    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(hbase + (g * G + s) * 32);
-                    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(hbase + 32 * PH + (g * G + s) * 32);
+                    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(hbase + (gr * G + s) * 32);
+                    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(hbase + 32 * PH + (gr * G + s) * 32);
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bring[d][s], acc[0], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bring[d][s], acc[1], 0, 0, 0);
                 }
-                if (g + RING < NG2) load_b(d, g + RING);
+                if (g + RING < NG2) load_b(d, (g + RING + rot2) & (NG2 - 1));
             }
         }
         const float bias = p.b2[nt * 32 + fr];
