@@ -90,6 +90,14 @@ int spei_conv_slab_bf16(const void* a0, int lda0, int k0, const void* a1, int ld
 int spei_mlp_fused_bf16(const float* x, float* out, const void* w1_frag, const float* b1, const void* w2_frag,
                         const float* b2, int64_t M, spei_stream_t stream);
 
+/* Fused attention branch of a Swin block (model/swinir.py:238-278 + :115-149): out = x + proj(W-MSA(q = yhat Wq,
+ * [k,v] = LayerNorm(x) Wkv)) with cyclic shift `shift`, 5x5 windows, 8 heads; x,out [H*W][256] fp32 (may alias), yhat
+ * [H*W][256] bf16 (LayerNorm of y without affine); w*_frag in MFMA fragment order with the LayerNorm affine and the q
+ * scale folded in (pack.py); relbias [8][25][25].  q, k, v, the attention matrix and its output never reach HBM. */
+int spei_attn_fused_bf16(const float* x, float* out, const void* yhat, const void* wq_frag, const float* bq,
+                         const void* wkv_frag, const float* bkv, const void* wproj_frag, const float* bproj,
+                         const float* relbias, int H, int W, int shift, spei_stream_t stream);
+
 /* K3 — ResBlock gates (model/block.py:8-24 SE, 71-96 ZPool+AttentionGate1/2, 108-124 TripletAttention).
  * x1: conv2 output [H][W][C], fp32 or (x1_bf16) bf16.  Workspace `ws` floats: spei_gate_ws_floats(H,W,C).
  * Produces s[C], g1[H][C], g2[W][C] such that ResBlock = x + x1*s + (x1*g1 + x1*g2).

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libspeinet_hip.so")
-SOURCES = ["stencil.hip", "igemm_f32.hip", "igemm_bf16.hip", "conv_slab_bf16.hip", "mlp_fused_bf16.hip", "resblock.hip", "swin.hip", "search.hip", "search_bf16.hip", "corr_slab_bf16.hip", "detector.hip"]
+SOURCES = ["stencil.hip", "igemm_f32.hip", "igemm_bf16.hip", "conv_slab_bf16.hip", "mlp_fused_bf16.hip", "attn_fused_bf16.hip", "resblock.hip", "swin.hip", "search.hip", "search_bf16.hip", "corr_slab_bf16.hip", "detector.hip"]
 
 
 def _stale() -> bool:

@@ -72,14 +72,17 @@ def swin(sx: SwinX, feat: FMap, sw: dict, out: FMap) -> FMap:
         for bi, bk in enumerate(layer["blocks"]):
             shift = 0 if bi % 2 == 0 else 2
             nxt = bufs[bi % 2]
-            if ops.ln_fused_available():
-                ops.linear(cur, bk["wkv"], bk["bkv"], out=kv, ln_input=True)      # norm1 inside the GEMM's staging
+            if ops.attn_fused_available():
+                ops.attn_fused(cur, yhat, bk, h, w, shift, out=nxt)               # whole attention branch, one kernel
             else:
-                ops.layernorm(cur, out=xh)
-                ops.linear(xh, bk["wkv"], bk["bkv"], out=kv)
-            ops.linear(yhat, bk["wq"], bk["bq"], out=q)
-            ops.window_attention(q, kv, bk["relbias"], h, w, shift, out=att)
-            ops.linear(att, bk["wproj"], bk["bproj"], residual=cur, out=nxt)
+                if ops.ln_fused_available():
+                    ops.linear(cur, bk["wkv"], bk["bkv"], out=kv, ln_input=True)  # norm1 inside the GEMM's staging
+                else:
+                    ops.layernorm(cur, out=xh)
+                    ops.linear(xh, bk["wkv"], bk["bkv"], out=kv)
+                ops.linear(yhat, bk["wq"], bk["bq"], out=q)
+                ops.window_attention(q, kv, bk["relbias"], h, w, shift, out=att)
+                ops.linear(att, bk["wproj"], bk["bproj"], residual=cur, out=nxt)
             if ops.mlp_fused_available():
                 ops.mlp_fused(nxt, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out=nxt)
             else:

@@ -248,6 +248,23 @@ def ln_fused_available() -> bool:
     return PRECISION != "f32" and USE_SLAB
 
 
+FUSE_ATTN = True     # "bf16" mode: LayerNorm -> q/kv GEMMs -> window attention -> proj -> +x in one kernel
+
+
+def attn_fused_available() -> bool:
+    return PRECISION == "bf16" and USE_SLAB and FUSE_ATTN and BF16_STORAGE
+
+
+def attn_fused(x: torch.Tensor, yhat: torch.Tensor, bk: dict, H: int, W: int, shift: int, out: torch.Tensor) -> torch.Tensor:
+    """out = x + proj(window_attention(...))  (reference model/swinir.py:238-278); in place when out is x."""
+    assert x.shape == (H * W, 256) and x.dtype == torch.float32 and out.shape == x.shape and out.dtype == torch.float32
+    assert yhat.shape == x.shape and yhat.dtype == torch.bfloat16
+    _lib.check(_lib.lib().spei_attn_fused_bf16(_tp(x), _tp(out), _tp(yhat), _tp(bk["wq"].fhi), _tp(bk["bq"]), _tp(bk["wkv"].fhi),
+                                               _tp(bk["bkv"]), _tp(bk["wproj"].fhi), _tp(bk["bproj"]), _tp(bk["relbias"]), H, W, shift,
+                                               _stream()), "spei_attn_fused_bf16")
+    return out
+
+
 def mlp_fused_available() -> bool:
     return PRECISION == "bf16" and USE_SLAB and FUSE_MLP
 

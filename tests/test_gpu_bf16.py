@@ -169,3 +169,32 @@ def test_mlp_fused_vs_oracle(synth_sd):
         assert e < 1.5e-2, f"M={m}: rel err {e:.2e}"
         inplace = ops.mlp_fused(xd, w1, bk["b1"].to(DEV), w2, bk["b2"].to(DEV), out=xd)
         assert torch.equal(inplace, out)
+
+
+@pytest.mark.parametrize("h,w,shift", [(5, 5, 0), (5, 5, 2), (10, 15, 0), (10, 15, 2), (15, 25, 2), (20, 35, 0), (20, 35, 2)])
+def test_attn_fused_vs_oracle(synth_sd, h, w, shift):
+    """Fused LN -> q/kv -> shifted-window attention -> proj -> +x kernel against the oracle's attention branch
+    (model/swinir.py:238-278); odd window counts leave the second window slot of the last workgroup empty."""
+    ops.set_precision("bf16")
+    p = "swin.layers.2.residual_group.blocks.1."
+    bk = {k: (v.to(DEV) if torch.is_tensor(v) else pack.PackedW(v.t, DEV)) for k, v in pack.swin_block(synth_sd, p, 8, 5).items()}
+    m = h * w
+    x = rnd(300 + m + shift, 1, m, 256, scale=1.3) + 0.2
+    y = rnd(400 + m + shift, 1, m, 256, scale=0.9) - 0.1
+    ln = lambda t: F.layer_norm(t, (256,), synth_sd[p + "norm1.weight"], synth_sd[p + "norm1.bias"], 1e-5).view(1, h, w, 256)
+    xn, yn = ln(x), ln(y)
+    if shift:
+        xn, yn = (torch.roll(t, shifts=(-shift, -shift), dims=(1, 2)) for t in (xn, yn))
+    xw, yw = (O.window_partition(t, 5).view(-1, 25, 256) for t in (xn, yn))
+    mask = O.shift_mask(h, w, 5, shift) if shift else None
+    branch = O.window_reverse(O.window_attention(xw, yw, synth_sd, p + "attn.", 8, 5, mask).view(-1, 5, 5, 256), 5, h, w)
+    if shift:
+        branch = torch.roll(branch, shifts=(shift, shift), dims=(1, 2))
+    branch = branch.reshape(m, 256)
+    xd = x[0].to(DEV).contiguous()
+    yhat = ops.layernorm(y[0].to(DEV).contiguous(), out_dtype=torch.bfloat16)
+    out = ops.attn_fused(xd, yhat, bk, h, w, shift, out=torch.empty_like(xd))
+    e = ((out.cpu() - x[0] - branch).abs().max() / branch.abs().max()).item()
+    assert torch.isfinite(out).all() and e < 1.5e-2, f"{h}x{w} shift {shift}: rel err {e:.2e}"
+    inplace = ops.attn_fused(xd, yhat, bk, h, w, shift, out=xd)
+    assert torch.equal(inplace, out)
