@@ -4,13 +4,16 @@
 //
 // Unfused this is LayerNorm -> GEMM 256->512 + GELU -> GEMM 512->256 + residual: the normalised tokens and the 512-wide
 // hidden activations each make a round trip through HBM (59 + 118 MB per call at 720p, 72 calls per frame).  Here a
-// 512-thread workgroup owns 64 tokens end to end:
-//   1. one wave per token row: fp32 load, two-pass moments by wave shuffles, normalise (the LayerNorm affine is folded
-//      into fc1 by pack.py) -> bf16 row in LDS (pitch 2*256+16 B);
-//   2. fc1: A fragments from that slab, B fragments streamed from HBM/L2 in MFMA fragment order (as conv_slab_bf16),
-//      bias + exact-erf GELU on the accumulator -> bf16 hidden slab in LDS (pitch 2*512+16 B), never in HBM;
-//   3. fc2: A fragments from the hidden slab, bias, transposing per-wave LDS tile -> + residual x -> 16-byte stores.
-// HBM traffic: x read (twice, the second time from L2 for the residual) and out written: 118 MB instead of 531 MB.
+// 512-thread workgroup owns 128 tokens end to end.  The weights (512 KB of bf16 per workgroup) stream from L2 in MFMA
+// fragment order; a CU takes them in at only ~30 B/clk, so every fragment is fetched by exactly ONE wave of the
+// workgroup and feeds four MFMAs (the four 32-token row tiles):
+//   1. LayerNorm(256), 16 lanes per token (4 DPP steps per reduction; the affine is folded into fc1 by pack.py) -> bf16
+//      token slab in LDS (pitch 2*256+16 B);
+//   2. per half of the hidden dim: fc1 TRANSPOSED (weights as the A operand, tokens on the lanes) so that a lane holds
+//      4 consecutive hidden channels of one token -> bias + erf-GELU -> 8-byte writes into the hidden slab (bf16, LDS only);
+//      then the fc2 partial product over that half accumulates into registers;
+//   3. + bias, in-register quad transpose, + residual x, 16-byte stores.
+// HBM traffic: x read (twice, the second time mostly from L2 for the residual) and out written: 118 MB instead of 531 MB.
 #include "common.h"
 
 namespace {
@@ -18,10 +21,10 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int D = 256, HID = 512, MT = 64;          // model dim, hidden dim, tokens per workgroup
-constexpr int PA = 2 * D + 16, PH = 2 * HID + 16;   // LDS row pitches (bytes)
-constexpr int EP = 36;                              // epilogue tile pitch (floats)
-constexpr int G = 2, RING = 4;
+constexpr int D = 256, HID = 512, MT = 128;         // model dim, hidden dim, tokens per workgroup
+constexpr int RT = MT / 32;                         // 32-token row tiles
+constexpr int PA = 2 * D + 16;                      // LDS row pitch (bytes), token slab and hidden-half slab alike
+constexpr int RING = 4;                             // weight fragments in flight per wave
 
 struct MlpParams {
     const float* x;
@@ -33,153 +36,191 @@ struct MlpParams {
     int M;
 };
 
-// GELU with erf from Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7): ~15 VALU ops instead of ~60 for erff.  Only used
-// where the result is rounded to bf16 right away (2^-9 relative), i.e. in the "bf16" arithmetic mode.
-__device__ __forceinline__ float gelu_fast(float v) {
-    const float z = fabsf(v) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float e = poly * t * __expf(-z * z);
-    const float erf_abs = 1.0f - e;
-    return 0.5f * v * (1.0f + copysignf(erf_abs, v));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// erf-GELU v * Phi(v) on two values (packed fp32 FMAs, no transcendental): Phi(v) - 1/2 = v Q(v^2) on |v| < 4, a degree-7
+// weighted least-squares fit in v^2 constrained to Phi(4) = 1; beyond that GELU is max(v, 0) to fp32.  Max abs error of
+// v Phi(v) 1.1e-4 -- below the bf16 rounding (2^-9 relative) the result gets right away, for every |v| > 0.06.  Only
+// used in the "bf16" arithmetic mode; the f32 / bf16x3 modes apply erff in the GEMM epilogue.  The Abramowitz-Stegun
+// 7.1.26 form used before cost one rcp + one exp + 14 VALU ops per value and made the hidden-slab write VALU-bound.
+__device__ __forceinline__ f32x2 gelu2(f32x2 v) {
+    const f32x2 u = v * v;
+    f32x2 q = u * -1.419582270e-09f + 1.126438985e-07f;
+    q = q * u + -3.898368825e-06f;
+    q = q * u + 7.838465745e-05f;
+    q = q * u + -1.034571474e-03f;
+    q = q * u + 9.623637850e-03f;
+    q = q * u + -6.612132016e-02f;
+    q = q * u + 3.988274675e-01f;
+    const f32x2 g = v * (v * q + 0.5f);
+    f32x2 r;
+    r[0] = fabsf(v[0]) < 4.0f ? g[0] : fmaxf(v[0], 0.f);
+    r[1] = fabsf(v[1]) < 4.0f ? g[1] : fmaxf(v[1], 0.f);
+    return r;
 }
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) { return v + dpp_quad<CTRL>(v); }
+// all-reduce over each aligned group of 16 lanes: xor 1, xor 2 (quad_perm), then row_half_mirror / row_mirror
+__device__ __forceinline__ float sum16(float v) { return dpp_add<0x140>(dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(v)))); }
 
 __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sa = smem;                               // [MT][PA]   normalised tokens, bf16
-    unsigned char* sh = smem + MT * PA;                     // [MT][PH]   hidden activations, bf16
-    float* etile = reinterpret_cast<float*>(smem + MT * PA + MT * PH) + (threadIdx.x >> 6) * (32 * EP);
+    unsigned char* sh = smem + MT * PA;                     // [MT][PA]   one half (256 channels) of the hidden activations
+    float* bias1 = reinterpret_cast<float*>(smem + 2 * MT * PA);   // [512]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave;                                    // 8 column slots; every wave covers both 32-token halves
     const int fr = lane & 31, fk = lane >> 5;
     const int m0 = blockIdx.x * MT;
 
-    // ---- 1. LayerNorm(256) per token row, one wave per row ---------------------------------------------------
-    // all 8 rows of this wave are requested before the first reduction (one HBM latency, not eight)
-    f32x4 rows[MT / 8];
-#pragma unroll
-    for (int i = 0; i < MT / 8; ++i) {
-        const int m = min(m0 + wave + 8 * i, p.M - 1);
-        rows[i] = reinterpret_cast<const f32x4*>(p.x + (size_t)m * D)[lane];
-    }
-#pragma unroll
-    for (int i = 0; i < MT / 8; ++i) {
-        const int r = wave + 8 * i;
-        const float4 v = make_float4(rows[i][0], rows[i][1], rows[i][2], rows[i][3]);
-        const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 256.0f);
-        const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
-        const float var = wave_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.0f / 256.0f);
-        const float rstd = 1.0f / sqrtf(var + 1e-5f);
-        bf16x4 h;
-        h[0] = (__bf16)(dx * rstd); h[1] = (__bf16)(dy * rstd); h[2] = (__bf16)(dz * rstd); h[3] = (__bf16)(dw * rstd);
-        *reinterpret_cast<bf16x4*>(sa + r * PA + lane * 8) = h;
-    }
+    bias1[tid] = p.b1[tid];
 
-    bf16x8 bring[RING][G];
-    const __bf16* bptr;
-    auto load_b = [&](int slot, int g) __attribute__((always_inline)) {
-#pragma unroll
-        for (int s = 0; s < G; ++s) bring[slot][s] = *reinterpret_cast<const bf16x8*>(bptr + (size_t)(g * G + s) * 512);
-    };
-    // weight stream of the first fc1 pass starts before the barrier
-    // Every workgroup walks the K dimension of each GEMM from a different starting group (rot): otherwise all 256 CUs
-    // request the same weight fragment from the same L2 channel at the same time.
-    constexpr int NG1 = (D / 16) / G;                       // 8 groups per 32-column tile of fc1
-    constexpr int NG2 = (HID / 16) / G;                     // 16 groups per tile of fc2
-    const int rot1 = blockIdx.x & (NG1 - 1), rot2 = (blockIdx.x * 5) & (NG2 - 1);
-    bptr = p.w1 + (size_t)wn * (D / 16) * 512 + lane * 8;
-#pragma unroll
-    for (int d = 0; d < RING; ++d) load_b(d, (d + rot1) & (NG1 - 1));
-    __syncthreads();
-
-    // ---- 2. fc1 + GELU -> hidden slab ------------------------------------------------------------------------------
-    // every B fragment is fetched by exactly one wave of the workgroup and used for both token halves
-    const unsigned char* abase = sa + fr * PA + fk * 16;
-    for (int pass = 0; pass < HID / 256; ++pass) {
-        const int nt = pass * 8 + wn;                       // 32-column tile of the hidden dim
-        f32x16 acc[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-#pragma unroll
-        for (int g0 = 0; g0 < NG1; g0 += RING) {
-#pragma unroll
-            for (int d = 0; d < RING; ++d) {
-                const int g = g0 + d, gr = (g + rot1) & (NG1 - 1);
-#pragma unroll
-                for (int s = 0; s < G; ++s) {
-                    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(abase + (gr * G + s) * 32);
-                    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(abase + 32 * PA + (gr * G + s) * 32);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bring[d][s], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bring[d][s], acc[1], 0, 0, 0);
-                }
-                if (g + RING < NG1) load_b(d, (g + RING + rot1) & (NG1 - 1));
-            }
-        }
-        // next pass's (or fc2's) weight stream
-        const bool more1 = pass + 1 < HID / 256;
-        if (more1) bptr = p.w1 + (size_t)(nt + 8) * (D / 16) * 512 + lane * 8;
-        else bptr = p.w2 + (size_t)wn * (HID / 16) * 512 + lane * 8;
-#pragma unroll
-        for (int d = 0; d < RING; ++d) load_b(d, more1 ? ((d + rot1) & (NG1 - 1)) : ((d + rot2) & (NG2 - 1)));
-        const float bias = p.b1[nt * 32 + fr];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int q = (r & 3) + 8 * (r >> 2) + 4 * fk;
-                *reinterpret_cast<__bf16*>(sh + (i * 32 + q) * PH + (nt * 32 + fr) * 2) = (__bf16)gelu_fast(acc[i][r] + bias);
-            }
-    }
-    __syncthreads();
-
-    // ---- 3. fc2 + bias + residual ------------------------------------------------------------------------------------
-    const unsigned char* hbase = sh + fr * PH + fk * 16;
-    const int erow = lane >> 3, ecol = (lane & 7) * 4;
+    // ---- 1. LayerNorm(256): 16 lanes per token, 32 tokens per pass; every load is issued before the first reduction ----
     {
-        const int nt = wn;                                  // 8 waves x 32 columns = the 256 output channels
-        f32x16 acc[2];
+        const int l16 = tid & 15, rsub = tid >> 4;
+        f32x4 xr[MT / 32][4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int b = 0; b < MT / 32; ++b) {
+            const int m = min(m0 + b * 32 + rsub, p.M - 1);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            for (int j = 0; j < 4; ++j) xr[b][j] = reinterpret_cast<const f32x4*>(p.x + (size_t)m * D)[l16 + 16 * j];
+        }
 #pragma unroll
-        for (int g0 = 0; g0 < NG2; g0 += RING) {
+        for (int b = 0; b < MT / 32; ++b) {
+            const int r = b * 32 + rsub;
+            float s = 0.f;
 #pragma unroll
-            for (int d = 0; d < RING; ++d) {
-                const int g = g0 + d, gr = (g + rot2) & (NG2 - 1);
+            for (int j = 0; j < 4; ++j) s += (xr[b][j][0] + xr[b][j][1]) + (xr[b][j][2] + xr[b][j][3]);
+            const float mean = sum16(s) * (1.0f / 256.0f);
+            float ss = 0.f;
 #pragma unroll
-                for (int s = 0; s < G; ++s) {
-                    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(hbase + (gr * G + s) * 32);
-                    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(hbase + 32 * PH + (gr * G + s) * 32);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bring[d][s], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bring[d][s], acc[1], 0, 0, 0);
-                }
-                if (g + RING < NG2) load_b(d, (g + RING + rot2) & (NG2 - 1));
+            for (int j = 0; j < 4; ++j) {
+                xr[b][j] -= mean;
+                ss += (xr[b][j][0] * xr[b][j][0] + xr[b][j][1] * xr[b][j][1]) + (xr[b][j][2] * xr[b][j][2] + xr[b][j][3] * xr[b][j][3]);
+            }
+            const float rstd = 1.0f / sqrtf(sum16(ss) * (1.0f / 256.0f) + 1e-5f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf16x4 hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hv[e] = (__bf16)(xr[b][j][e] * rstd);
+                *reinterpret_cast<bf16x4*>(sa + r * PA + (l16 + 16 * j) * 8) = hv;
             }
         }
-        const float bias = p.b2[nt * 32 + fr];
+    }
+
+    // Every workgroup walks the K dimension of each GEMM from a different k-step (rot): otherwise all 256 CUs request
+    // the same weight fragment from the same L2 channel at the same time.
+    const int rot = blockIdx.x & 15;
+    bf16x8 ring[RING];
+    const __bf16* wptr = p.w1 + (size_t)wave * 16 * 512 + lane * 8;      // fc1, half 0: hidden tile `wave`
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+    for (int d = 0; d < RING; ++d) ring[d] = *reinterpret_cast<const bf16x8*>(wptr + ((rot + d) & 15) * 512);
+    __syncthreads();
+
+    f32x16 acc2[RT];                                        // fc2 accumulators: tokens x output channels [32 wave, +32)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int q = (r & 3) + 8 * (r >> 2) + 4 * fk;
-                etile[q * EP + fr] = acc[i][r] + bias;
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[i][r] = 0.f;
+
+    const int et = fr & 3, ecol = (fr >> 2) * 4;
+    f32x4 res[RT][4];
+    const unsigned char* abase = sa + fr * PA + fk * 16;
+    const unsigned char* hbase = sh + fr * PA + fk * 16;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        // ---- 2a. fc1^T for hidden channels [256 half + 32 wave, +32): rows = channels, columns = tokens ----------------
+        f32x16 acc1[RT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[i][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int ks = (rot + s) & 15;
+            const bf16x8 w = ring[s % RING];
+            if (s + RING < 16) ring[s % RING] = *reinterpret_cast<const bf16x8*>(wptr + ((rot + s + RING) & 15) * 512);
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                const bf16x8 t = *reinterpret_cast<const bf16x8*>(abase + i * 32 * PA + ks * 32);
+                acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, t, acc1[i], 0, 0, 0);
             }
+        }
+        // fc2 weight stream of this half starts under the GELU; the last half fetches ALL its fragments here, so that the
+        // residual loads below can queue behind them without any later weight load waiting for those (vmcnt is in order)
+        wptr = p.w2 + (size_t)wave * 32 * 512 + (size_t)half * 16 * 512 + lane * 8;
+        bf16x8 wlast[16];
+        if (half == 0) {
+#pragma unroll
+            for (int d = 0; d < RING; ++d) ring[d] = *reinterpret_cast<const bf16x8*>(wptr + ((rot + d) & 15) * 512);
+        } else {
+#pragma unroll
+            for (int d = 0; d < 16; ++d) wlast[d] = *reinterpret_cast<const bf16x8*>(wptr + ((rot + d) & 15) * 512);
+            __syncthreads();                                // fc2 of half 0 is done reading the hidden slab
+        }
+        // rows c = (r&3) + 8*(r>>2) + 4*fk = 8g + 4fk + e, column = token fr  ->  sh[token][32 wave + c]
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 bv = *reinterpret_cast<const f32x4*>(bias1 + half * 256 + wave * 32 + 8 * g + 4 * fk);
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                const f32x2 g01 = gelu2(f32x2{acc1[i][4 * g] + bv[0], acc1[i][4 * g + 1] + bv[1]});
+                const f32x2 g23 = gelu2(f32x2{acc1[i][4 * g + 2] + bv[2], acc1[i][4 * g + 3] + bv[3]});
+                bf16x4 hv;
+                hv[0] = (__bf16)g01[0]; hv[1] = (__bf16)g01[1]; hv[2] = (__bf16)g23[0]; hv[3] = (__bf16)g23[1];
+                *reinterpret_cast<bf16x4*>(sh + (i * 32 + fr) * PA + (wave * 32 + 8 * g + 4 * fk) * 2) = hv;
+            }
+        }
+        if (half == 1) {
+            // residual x for the epilogue (mostly L2 / MALL hits: this workgroup read the rows at its start)
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int m = min(m0 + i * 32 + 8 * k + 4 * fk + et, p.M - 1);
+                    res[i][k] = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * D + wave * 32 + ecol);
+                }
+        }
+        __syncthreads();
+        // ---- 2b. fc2 partial product over this half of the hidden dim ------------------------------------------------------
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int ks = (rot + s) & 15;
+            bf16x8 w;
+            if (half == 0) {
+                w = ring[s % RING];
+                if (s + RING < 16) ring[s % RING] = *reinterpret_cast<const bf16x8*>(wptr + ((rot + s + RING) & 15) * 512);
+            } else {
+                w = wlast[s];
+            }
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                const bf16x8 t = *reinterpret_cast<const bf16x8*>(hbase + i * 32 * PA + ks * 32);
+                acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t, w, acc2[i], 0, 0, 0);
+            }
+        }
+        if (half == 0) {
+            wptr = p.w1 + (size_t)(8 + wave) * 16 * 512 + lane * 8;      // fc1, half 1
+#pragma unroll
+            for (int d = 0; d < RING; ++d) ring[d] = *reinterpret_cast<const bf16x8*>(wptr + ((rot + d) & 15) * 512);
+        }
+    }
+
+    // ---- 3. + bias + residual, 16-byte stores --------------------------------------------------------------------------------
+    {
+        const float bias = p.b2[wave * 32 + fr];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int q = erow + 8 * k;
-                const int m = m0 + i * 32 + q;
-                if (m < p.M) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(etile + q * EP + ecol);
-                    v += *reinterpret_cast<const f32x4*>(p.x + (size_t)m * D + nt * 32 + ecol);
-                    *reinterpret_cast<f32x4*>(p.out + (size_t)m * D + nt * 32 + ecol) = v;
-                }
+                float a[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = acc2[i][4 * k + e] + bias;
+                quad_transpose4(a[0], a[1], a[2], a[3], et);
+                const int m = m0 + i * 32 + 8 * k + 4 * fk + et;
+                if (m < p.M) *reinterpret_cast<f32x4*>(p.out + (size_t)m * D + wave * 32 + ecol) = f32x4{a[0], a[1], a[2], a[3]} + res[i][k];
             }
         }
     }
@@ -194,7 +235,7 @@ extern "C" int spei_mlp_fused_bf16(const float* x, float* out, const void* w1_fr
     SPEI_REQUIRE(((uintptr_t)x | (uintptr_t)out | (uintptr_t)w1_frag | (uintptr_t)w2_frag) % 16 == 0, "spei_mlp_fused_bf16: 16-byte alignment required");
     MlpParams p;
     p.x = x; p.out = out; p.w1 = (const __bf16*)w1_frag; p.b1 = b1; p.w2 = (const __bf16*)w2_frag; p.b2 = b2; p.M = (int)M;
-    const size_t lds = (size_t)MT * PA + (size_t)MT * PH + (size_t)8 * 32 * EP * sizeof(float);
+    const size_t lds = (size_t)2 * MT * PA + HID * sizeof(float);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

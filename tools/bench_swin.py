@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time the fused attention-branch kernel alone at the 720p lv3 size (180x320 tokens); SPEI_ATTN_DBG skips phases."""
+"""Time the two fused Swin-block kernels (attention branch, MLP branch) alone at the 720p lv3 size (180x320 tokens)."""
 import os
 import sys
 
@@ -28,4 +28,14 @@ for shift in (0, 2):
         ops.attn_fused(x, yhat, bk, H, W, shift, out)
     e1.record()
     torch.cuda.synchronize()
-    print(f"dbg={os.environ.get('SPEI_ATTN_DBG', '0')} shift={shift}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us")
+    print(f"attn_fused shift={shift}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us")
+for _ in range(3):
+    ops.mlp_fused(x, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    ops.mlp_fused(x, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out)
+e1.record()
+torch.cuda.synchronize()
+print(f"mlp_fused: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us")
