@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--corr-precision", choices=["bf16x3", "bf16"], default="bf16",
                     help="correlation arg-max products when --precision is not f32 (bf16x3 = f32-grade scores, 2.4x the kernel time)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying one hipGraph per frame")
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams for the independent neighbour-frame / reference branches of a frame")
     ap.add_argument("--branch", choices=["bs", "b"], default="bs", help="bs: with sharp reference (SearchTransfer); b: SelfTransfer")
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
@@ -118,6 +119,7 @@ def main():
     net = net.to(dev).eval()
     net.precision, net.corr_precision = args.precision, args.corr_precision
     net.use_graph = not args.no_graph
+    net.streams = args.streams
     # each rank deblurs its own frames (clip shard = rank); two distinct windows alternate so nothing is cached
     frames = [synth_frames(1, h, w, seed=1234 + 17 * rank + i, zero_ref=(0,) if args.branch == "b" else ()).to(dev) for i in range(2)]
     routing = [args.branch == "b"]

@@ -152,37 +152,61 @@ def decode(ff: FMap, s: torch.Tensor, t3: FMap, t2: FMap, t1: FMap, P: dict, out
 
 
 # ---- one sample --------------------------------------------------------------------------------------------
-def fused_features(x: torch.Tensor, P: dict, n_seq: int) -> FMap:
-    """f_mid, the neighbour-frame swin fusions and the 1x1 `fusion` conv (speinet.py:75-90,129-134)."""
+# The neighbour-frame branches (2 encoder passes + one swin each) and the reference-frame encoder are independent of
+# each other: with STREAMS > 1 they are issued round-robin on HIP side streams (fork after conv_first(f_mid), join before
+# the `fusion` conv).  Every kernel of the path leaves CUs idle in its last partial round of workgroups and in its
+# load / store phases; a second stream's kernels fill those.  Captured into the frame's hipGraph as parallel branches.
+STREAMS = 1
+_side_streams: dict = {}
+
+
+def _sides(dev, n: int) -> list:
+    key = (dev.index, n)
+    if key not in _side_streams:
+        _side_streams[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+    return _side_streams[key]
+
+
+def forward_sample(x: torch.Tensor, P: dict, n_seq: int, has_ref: bool, out: torch.Tensor) -> torch.Tensor:
+    """x [n_seq+2, 3, H, W] (contiguous, cuda) -> out [3, H, W].
+
+    f_mid, the neighbour-frame swin fusions and the 1x1 `fusion` conv (speinet.py:75-90,129-134), then
+    SearchTransfer / SelfTransfer and the decoder (:92-148)."""
     h, w = x.shape[-2:]
     h3, w3 = h // 4, w // 4
     dev = x.device
+    main = torch.cuda.current_stream(dev)
+    lanes = [main] + (_sides(dev, STREAMS - 1) if STREAMS > 1 else [])
+    for s_ in lanes[1:]:
+        s_.wait_stream(main)                      # fork: the input frames (and anything before them) are ready
+    lv = None
+    if has_ref:                                   # sharp-reference pyramid: last lane, ahead of its neighbour frames
+        with torch.cuda.stream(lanes[-1]):
+            lv1 = in_block(x[n_seq + 1], P["inBlock"])
+            lv2 = enc_stage(lv1, P["encoder_first"])
+            lv = (lv1, lv2, enc_stage(lv2, P["encoder_second"]))
     cat = FMap(torch.empty(h3 * w3, 128 * n_seq, device=dev), h3, w3, 128 * n_seq)
     mid = x[n_seq // 2]
     e0 = enc(mid, P)
     f_mid = enc(ops.rl_prior(mid, 5, 0.01), P, extra=e0, out=cat.view(0, 128))
     sx = SwinX(f_mid, P["swin"])
-    slot = 1
-    for i in range(n_seq):
-        if i == n_seq // 2:
-            continue
-        e = enc(x[i], P)
-        feat = enc(ops.rl_prior(x[i], 1, 0.01), P, extra=e)
-        swin(sx, feat, P["swin"], out=cat.view(128 * slot, 128))
-        slot += 1
+    ready = torch.cuda.Event()
+    ready.record(main)
+    for slot, i in enumerate([i for i in range(n_seq) if i != n_seq // 2], start=1):
+        lane = lanes[(slot - 1) % len(lanes)]
+        if lane is not main:
+            lane.wait_event(ready)
+        with torch.cuda.stream(lane):
+            e = enc(x[i], P)
+            feat = enc(ops.rl_prior(x[i], 1, 0.01), P, extra=e)
+            swin(sx, feat, P["swin"], out=cat.view(128 * slot, 128))
+            del e, feat
+    for s_ in lanes[1:]:
+        main.wait_stream(s_)                      # join
     fw = P["fusion"]
-    return ops.igemm(cat, fw["w"], fw["b"], 128)
-
-
-def forward_sample(x: torch.Tensor, P: dict, n_seq: int, has_ref: bool, out: torch.Tensor) -> torch.Tensor:
-    """x [n_seq+2, 3, H, W] (contiguous, cuda) -> out [3, H, W]."""
+    ff = ops.igemm(cat, fw["w"], fw["b"], 128)
     if has_ref:
-        lv1 = in_block(x[n_seq + 1], P["inBlock"])
-        lv2 = enc_stage(lv1, P["encoder_first"])
-        lv3 = enc_stage(lv2, P["encoder_second"])
-        ff = fused_features(x, P, n_seq)
-        s, t3, t2, t1 = search_transfer(ff, lv1, lv2, lv3)
+        s, t3, t2, t1 = search_transfer(ff, *lv)
     else:
-        ff = fused_features(x, P, n_seq)
         s, t3, t2, t1 = self_transfer(ff, P)
     return decode(ff, s, t3, t2, t1, P, out)

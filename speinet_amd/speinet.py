@@ -218,6 +218,7 @@ class SPEINet(nn.Module):
         self.precision = os.environ.get("SPEINET_PRECISION", "f32")
         self.corr_precision = os.environ.get("SPEINET_CORR_PRECISION", "bf16x3")
         self.use_graph = os.environ.get("SPEINET_GRAPH", "0") == "1"     # hipGraph replay of a whole frame
+        self.streams = int(os.environ.get("SPEINET_STREAMS", "1"))        # HIP streams for the independent frame branches
         self._graphs = {}
 
     # ---- weight packing cache -----------------------------------------------------------------------
@@ -255,6 +256,7 @@ class SPEINet(nn.Module):
             raise RuntimeError("speinet_amd: backward kernels are not built yet; use eval() under torch.no_grad()")
         _lib.lib()
         ops.set_precision(self.precision, self.corr_precision)
+        engine.STREAMS = max(1, int(self.streams))
         x = x.contiguous().float()
         P = self._pack(x.device)
         zero_ref = list(routing) if routing is not None else self._route(x)
@@ -268,7 +270,7 @@ class SPEINet(nn.Module):
     def _forward_graph(self, x: torch.Tensor, P: dict, zero_ref: list) -> torch.Tensor:
         """Replay the ~1500 launches of a frame as ONE hipGraph (captured once per shape / routing / precision):
         the per-launch host cost (ctypes + hipLaunch, ~10 us each) otherwise leaves the GPU idle ~15 % of a frame."""
-        key = (tuple(x.shape), tuple(zero_ref), self.precision, self.corr_precision, str(x.device), self._packed_key)
+        key = (tuple(x.shape), tuple(zero_ref), self.precision, self.corr_precision, self.streams, str(x.device), self._packed_key)
         g = self._graphs.get(key)
         if g is None:
             static_x = x.clone()

@@ -198,3 +198,25 @@ def test_attn_fused_vs_oracle(synth_sd, h, w, shift):
     assert torch.isfinite(out).all() and e < 1.5e-2, f"{h}x{w} shift {shift}: rel err {e:.2e}"
     inplace = ops.attn_fused(xd, yhat, bk, h, w, shift, out=xd)
     assert torch.equal(inplace, out)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_streams_bit_identical(net, mode, graph):
+    """Issuing the neighbour-frame / reference branches on 2 or 3 HIP streams (eagerly or captured into the frame's
+    hipGraph) must not change a single bit: same kernels, same operands, only the schedule differs."""
+    x = synth_frames(2, 100, 120, seed=77, zero_ref=(1,)).to(DEV)       # sample 0 SearchTransfer, sample 1 SelfTransfer
+    net.precision, net.corr_precision = mode, "bf16x3"
+    outs = []
+    try:
+        for streams in (1, 2, 3):
+            net.streams, net.use_graph = streams, graph
+            with torch.no_grad():
+                outs.append(net(x).clone())
+                outs.append(net(x).clone())                                 # second call: graph replay / warm allocator
+    finally:
+        net.streams, net.use_graph, net.precision = 1, False, "f32"
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0]).all()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
