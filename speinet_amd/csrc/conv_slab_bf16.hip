@@ -49,7 +49,7 @@ struct SlabParams {
     int ln;                  // 1: LayerNorm(256) without affine is applied to every input row while it is staged
                              //    (fp32 input, K == 256: one wave-instruction loads exactly one token row)
     int dbg;                 // ablation switches for tools/ablate_slab.py (0 in production): 1 no staging loads,
-                             // 2 no MFMA loop, 4 no epilogue stores
+                             // 4 no epilogue stores
 };
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
@@ -221,9 +221,13 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
     };
 
     f32x16 acc[TM][TN];
+    // The ring is always filled / refilled UNCONDITIONALLY (indices clamped to the last group: a few redundant loads at the
+    // tail).  With conditional loads the compiler cannot count outstanding loads across the branches and falls back to
+    // s_waitcnt vmcnt(0..1) in front of every MFMA group (prefetch distance 1 instead of RING), and the accumulators
+    // bounce between AGPRs and VGPRs at every merge point (64 v_accvgpr moves per RING groups; seen in the ISA).
 #pragma unroll
-    for (int d = 0; d < RING; ++d)
-        if (d < ngroups) load_b(d, rg(d));
+    for (int d = 0; d < RING; ++d) load_b(d, rg(min(d, ngroups - 1)));
+    const int nfull = (ngroups / RING) * RING;
 
     __syncthreads();     // slab + offset table visible; the only barrier of the kernel
 
@@ -293,49 +297,43 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
                     }
                 }
             }
-        } else
-        for (int g0 = 0; g0 < ((p.dbg & 2) ? 0 : ngroups); g0 += RING) {
+        } else {
+            auto group = [&](int d, int g) __attribute__((always_inline)) {
+                const int go_next = goff[rg(min(g + 1, ngroups - 1))];
 #pragma unroll
-            for (int d = 0; d < RING; ++d) {
-                const int g = g0 + d;
-                if (g < ngroups) {
-                    const int go_next = goff[rg(min(g + 1, ngroups - 1))];
+                for (int s = 0; s < G; ++s) {
+                    bf16x8 av[TM];
 #pragma unroll
-                    for (int s = 0; s < G; ++s) {
-                        bf16x8 av[TM], avl[SPLIT ? TM : 1];
+                    for (int i = 0; i < TM; ++i) av[i] = an[i];
+                    load_a(s + 1 < G ? go + (s + 1) * 32 : go_next);     // (the very last prefetch is a harmless re-read)
 #pragma unroll
-                        for (int i = 0; i < TM; ++i) {
-                            av[i] = an[i];
-                            if (SPLIT) avl[i] = anl[i];
-                        }
-                        load_a(s + 1 < G ? go + (s + 1) * 32 : go_next);     // (the very last prefetch is a harmless re-read)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int i = 0; i < TM; ++i)
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bring[d][s][j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+                }
+                go = go_next;
+            };
+            for (int g0 = 0; g0 < nfull; g0 += RING) {               // branch-free body
 #pragma unroll
-                            for (int j = 0; j < TN; ++j) {
-                                if (SPLIT) {
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avl[i], bring[d][s][j], acc[i][j], 0, 0, 0);
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bring_lo[SPLIT ? d : 0][s][j], acc[i][j], 0, 0, 0);
-                                }
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bring[d][s][j], acc[i][j], 0, 0, 0);
-                            }
-                        if constexpr (!SPLIT) {
-                            __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
-                        }
-                    }
-                    go = go_next;
-                    if (g + RING < ngroups) load_b(d, rg(g + RING));
+                for (int d = 0; d < RING; ++d) {
+                    group(d, g0 + d);
+                    load_b(d, rg(min(g0 + d + RING, ngroups - 1)));
                 }
             }
+            // remainder (ngroups % RING groups): their fragments sit in ring slots 0.. from the last refill / the prologue
+#pragma unroll
+            for (int d = 0; d < RING - 1; ++d)
+                if (nfull + d < ngroups) group(d, nfull + d);
         }
         // start the next chunk's weight stream before the epilogue's stores
         const int nbase = (nc * WN + wn) * TN;
         if (nc + 1 < p.n_chunks) {
             set_chunk(nc + 1);
 #pragma unroll
-            for (int d = 0; d < RING; ++d)
-                if (d < ngroups) load_b(d, rg(d));
+            for (int d = 0; d < RING; ++d) load_b(d, rg(min(d, ngroups - 1)));
         }
 
         // ---- epilogue ----------------------------------------------------------------------------------------
