@@ -8,11 +8,16 @@
 // addressing:
 //   * the query block (NI rows x 32 lr positions) and its 1-pixel halo sit in LDS for the whole kernel, all 128
 //     channels (pixel pitch 2*128+16 B);
-//   * the reference map is streamed as 4 x 32 position blocks + halo, KC channels at a time, double buffered
+//   * the reference map is streamed as (2 WJ) x 32 position blocks + halo, KC channels at a time, double buffered
 //     (pixel pitch 2*KC+16 B): one global->LDS stage per 9 taps x KC/16 k-steps = 72..144 MFMAs per wave;
+//   * WJ x 2 waves: WJ along the reference positions (64 each), 2 along the query positions.  The bf16 configuration
+//     runs WJ = 4 (512 threads, 256 reference positions per block, 155 KB of LDS): two waves per SIMD, so one wave's
+//     arg-max fold / stage stores / barrier wait overlap the other's MFMAs (with 4 waves per CU the matrix pipe idled
+//     during all of those);
 //   * the MFMA (v_mfma_f32_32x32x16_bf16) puts reference positions on accumulator rows and query positions on
 //     lanes, so the running (max, argmax) over j is per lane, in registers; R (13.3 GB at 720p) never exists.
 // lo == NULL: single bf16 products; lo != NULL: split products al*bh + ah*bl + ah*bh (bf16x3, f32-grade scores).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -20,7 +25,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int CMAXSPLIT = 8;
-constexpr int RB_H = 4, RB_W = 32;           // reference block (128 positions)
+constexpr int RB_W = 32;                     // reference block: (2 WJ) rows x 32 positions
 constexpr int SLAB_W = RB_W + 2;             // 34 pixels per slab row (1-pixel halo each side)
 
 struct CorrSlabParams {
@@ -40,10 +45,12 @@ struct CorrSlabParams {
 
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 
-// NI: query tile rows (x 32 columns); KC: reference channels per stage; SPLIT: bf16x3
-template <int NI, int KC, bool SPLIT>
-__global__ __launch_bounds__(256) void corr_slab_kernel(const CorrSlabParams p) {
+// NI: query tile rows (x 32 columns); KC: reference channels per stage; SPLIT: bf16x3; WJ: waves along the reference rows
+template <int NI, int KC, bool SPLIT, int WJ>
+__global__ __launch_bounds__(128 * WJ) void corr_slab_kernel(const CorrSlabParams p) {
     constexpr int C = 128;
+    constexpr int NT = 128 * WJ;                       // threads
+    constexpr int RB_H = 2 * WJ;                       // reference block rows
     constexpr int TN = NI / 2;                         // 32-column n-tiles per wave (2 waves along i)
     constexpr int NPART = SPLIT ? 2 : 1;
     constexpr int PITCH_L = 2 * C + 16;                // lr slab pixel pitch (bytes)
@@ -53,14 +60,14 @@ __global__ __launch_bounds__(256) void corr_slab_kernel(const CorrSlabParams p) 
     constexpr int R_BYTES = ((RPIX * PITCH_R + 15) / 16) * 16;
     constexpr int NCH = C / KC;                        // channel chunks per reference block
     constexpr int RCH16 = KC / 8;                      // 16-byte pieces per pixel per stage
-    constexpr int RLOADS = (RPIX * RCH16 + 255) / 256; // staged 16-byte loads per thread
+    constexpr int RLOADS = (RPIX * RCH16 + NT - 1) / NT; // staged 16-byte loads per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* lslab = smem;                                   // [NPART][L_BYTES]
     unsigned char* rslab = smem + NPART * L_BYTES;                 // [2 buffers][NPART][R_BYTES]
-    float* inv_s = reinterpret_cast<float*>(smem + NPART * L_BYTES + 2 * NPART * R_BYTES);   // [2][128] 1/|patch| of the block
+    float* inv_s = reinterpret_cast<float*>(smem + NPART * L_BYTES + 2 * NPART * R_BYTES);   // [2][RB_H*32] 1/|patch| of the block
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;           // 2 waves along j (64 rows each), 2 along i
+    const int wm = wave >> 1, wn = wave & 1;           // WJ waves along j (64 rows each), 2 along i
     const int fr = lane & 31, fk = lane >> 5;
     const int ity = blockIdx.x / p.itiles_x, itx = blockIdx.x - ity * p.itiles_x;
     const int iy0 = ity * NI, ix0 = itx * RB_W;
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(256) void corr_slab_kernel(const CorrSlabParams p) 
     const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
 
     // ---- resident query slab ----------------------------------------------------------------------------
-    for (int idx = tid; idx < LPIX * (C / 8); idx += 256) {
+    for (int idx = tid; idx < LPIX * (C / 8); idx += NT) {
         const int pix = idx >> 4, c16 = idx & 15;      // C/8 == 16 pieces per pixel
         const int sy = pix / SLAB_W, sx = pix - sy * SLAB_W;
         const int gy = iy0 + sy - 1, gx = ix0 + sx - 1;
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(256) void corr_slab_kernel(const CorrSlabParams p) 
         }
 #pragma unroll
         for (int u = 0; u < RLOADS; ++u) {
-            const int idx = tid + u * 256;
+            const int idx = tid + u * NT;
             const int pix = idx / RCH16, c16 = idx - pix * RCH16;
             const int sy = pix / SLAB_W, sx = pix - sy * SLAB_W;
             const int gy = jy0 + sy, gx = jx0 + sx;
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(256) void corr_slab_kernel(const CorrSlabParams p) 
         if (stage % NCH == 0 && tid < RB_H * RB_W) inv_s[((stage / NCH) & 1) * (RB_H * RB_W) + tid] = riv;
 #pragma unroll
         for (int u = 0; u < RLOADS; ++u) {
-            const int idx = tid + u * 256;
+            const int idx = tid + u * NT;
             if (idx < RPIX * RCH16) {
                 const int pix = idx / RCH16, c16 = idx - pix * RCH16;
                 *reinterpret_cast<u32x4*>(base + pix * PITCH_R + c16 * 16) = rh[u];
@@ -214,8 +221,13 @@ __global__ __launch_bounds__(256) void corr_slab_kernel(const CorrSlabParams p) 
                         const float ir = inv_s[((st / NCH) & 1) * (RB_H * RB_W) + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk];
 #pragma unroll
                         for (int j = 0; j < TN; ++j) {
-                            const float v = acc[i][j][r] * ir * il[j];
-                            if (better(v, jj, bestv[j], besti[j])) { bestv[j] = v; besti[j] = jj; }
+                            if (SPLIT) {        // f32-grade scores: the reference's order of the two normalisations, full tie rule
+                                const float v = acc[i][j][r] * ir * il[j];
+                                if (better(v, jj, bestv[j], besti[j])) { bestv[j] = v; besti[j] = jj; }
+                            } else {            // the query's own normaliser (> 0, constant per lane column) is applied at the end
+                                const float v = acc[i][j][r] * ir;
+                                if (better(v, jj, bestv[j], besti[j])) { bestv[j] = v; besti[j] = jj; }
+                            }
                         }
                     }
                 }
@@ -225,8 +237,8 @@ __global__ __launch_bounds__(256) void corr_slab_kernel(const CorrSlabParams p) 
     }
 
     // ---- combine lane halves, then the two waves (wm) sharing the same query columns ---------------------------
-    float* rv = reinterpret_cast<float*>(smem);            // [2 wm][NI*32]
-    int* ri = reinterpret_cast<int*>(smem) + 2 * NI * 32;
+    float* rv = reinterpret_cast<float*>(smem);            // [WJ][NI*32]
+    int* ri = reinterpret_cast<int*>(smem) + WJ * NI * 32;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const float ov = __shfl_xor(bestv[j], 32, 64);
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(256) void corr_slab_kernel(const CorrSlabParams p) 
         if (better(ov, oi, bestv[j], besti[j])) { bestv[j] = ov; besti[j] = oi; }
         if (fk == 0) {
             const int col = (wn * TN + j) * 32 + fr;
-            rv[wm * NI * 32 + col] = bestv[j];
+            rv[wm * NI * 32 + col] = SPLIT ? bestv[j] : bestv[j] * il[j];
             ri[wm * NI * 32 + col] = besti[j];
         }
     }
@@ -244,7 +256,9 @@ __global__ __launch_bounds__(256) void corr_slab_kernel(const CorrSlabParams p) 
         if (qy < p.Hl && qx < p.Wl) {
             float v = rv[tid];
             int ix = ri[tid];
-            if (better(rv[NI * 32 + tid], ri[NI * 32 + tid], v, ix)) { v = rv[NI * 32 + tid]; ix = ri[NI * 32 + tid]; }
+#pragma unroll
+            for (int w = 1; w < WJ; ++w)
+                if (better(rv[w * NI * 32 + tid], ri[w * NI * 32 + tid], v, ix)) { v = rv[w * NI * 32 + tid]; ix = ri[w * NI * 32 + tid]; }
             const int i = qy * p.Wl + qx;
             p.pval[(size_t)blockIdx.y * p.Nl + i] = v;
             p.pidx[(size_t)blockIdx.y * p.Nl + i] = ix;
@@ -267,19 +281,20 @@ __global__ __launch_bounds__(256) void corr_slab_final_kernel(const float* __res
     arg[i] = ix == 0x7fffffff ? 0 : ix;
 }
 
-template <int NI, int KC, bool SPLIT>
+template <int NI, int KC, bool SPLIT, int WJ>
 void launch_corr(const CorrSlabParams& p, int itiles, int splits, hipStream_t st) {
     constexpr int C = 128;
+    constexpr int RB_H = 2 * WJ;
     constexpr int NPART = SPLIT ? 2 : 1;
     constexpr int L_BYTES = ((((NI + 2) * SLAB_W) * (2 * C + 16) + 15) / 16) * 16;
     constexpr int R_BYTES = ((((RB_H + 2) * SLAB_W) * (2 * KC + 16) + 15) / 16) * 16;
     const size_t lds = (size_t)NPART * L_BYTES + (size_t)2 * NPART * R_BYTES + (size_t)2 * RB_H * RB_W * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_slab_kernel<NI, KC, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_slab_kernel<NI, KC, SPLIT, WJ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL((corr_slab_kernel<NI, KC, SPLIT>), dim3(itiles, splits), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((corr_slab_kernel<NI, KC, SPLIT, WJ>), dim3(itiles, splits), dim3(128 * WJ), lds, st, p);
 }
 
 }  // namespace
@@ -302,7 +317,9 @@ extern "C" int spei_corr_slab_bf16(const void* lr_hi, const void* lr_lo, const v
     p.itiles_x = cdiv(Wl, RB_W);
     const int itiles = p.itiles_x * cdiv(Hl, NI);
     p.rblocks_x = cdiv(Wr, RB_W);
-    p.rblocks = p.rblocks_x * cdiv(Hr, RB_H);
+    static const int wj_bf16 = getenv("SPEI_CORR_WJ") ? atoi(getenv("SPEI_CORR_WJ")) : 4;     // A/B knob: 2 = the 256-thread form
+    const int rb_h = split ? 4 : 2 * wj_bf16;
+    p.rblocks = p.rblocks_x * cdiv(Hr, rb_h);
     // split the reference blocks so that the grid fills 256 CUs (one workgroup per CU) with little tail
     int best_s = 1;
     double best_eff = 0.0;
@@ -316,8 +333,9 @@ extern "C" int spei_corr_slab_bf16(const void* lr_hi, const void* lr_lo, const v
     p.pval = ws;
     p.pidx = reinterpret_cast<int32_t*>(ws + (size_t)CMAXSPLIT * p.Nl);
     hipStream_t st = (hipStream_t)stream;
-    if (split) launch_corr<2, 32, true>(p, itiles, splits, st);
-    else launch_corr<4, 64, false>(p, itiles, splits, st);
+    if (split) launch_corr<2, 32, true, 2>(p, itiles, splits, st);
+    else if (wj_bf16 == 4) launch_corr<4, 64, false, 4>(p, itiles, splits, st);
+    else launch_corr<4, 64, false, 2>(p, itiles, splits, st);
     hipLaunchKernelGGL(corr_slab_final_kernel, dim3(cdiv(p.Nl, 256)), dim3(256), 0, st, p.pval, p.pidx, splits, p.Nl, S, arg);
     SPEI_CHECK_LAUNCH("spei_corr_slab_bf16");
     return 0;
