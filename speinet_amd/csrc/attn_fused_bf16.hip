@@ -136,6 +136,19 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const AttnParams p) 
 
     // ---- 2 + 3. the wave's two heads: Q^T, K^T, V, then attention on both windows, all in registers -------------------
     bf16x4 opk[2][2][4];                               // [head][window][4 d-groups]: O^T packed, written to LDS after the barrier
+    // shift mask: bit r of mbits[w] = key (register row r) lies in another region than the lane's query
+    unsigned mbits[2] = {0u, 0u};
+    if (p.shift > 0) {
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const int qreg = tok_reg[w * 32 + (fr < NT ? fr : 0)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (tok_reg[w * 32 + min(key, NT - 1)] != qreg) mbits[w] |= 1u << r;
+            }
+        }
+    }
     const int rot = blockIdx.x & 15;                   // per-workgroup K rotation (spreads the L2 channel load)
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
@@ -194,7 +207,6 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const AttnParams p) 
             // S^T[key][query] = sum_d K^T[d][key] Q^T[d][query]:  A = (K^T)^T from the accumulator, B = Q^T from the accumulator
             st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cvt8<0>(kT[w]), cvt8<0>(qT[w]), st, 0, 0, 0);
             st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cvt8<1>(kT[w]), cvt8<1>(qT[w]), st, 0, 0, 0);
-            const int qreg = tok_reg[w * 32 + qi];
             float mx = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -202,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const AttnParams p) 
                 float v = -INFINITY;
                 if (key < NT) {
                     v = st[r] + rb[r];
-                    if (p.shift > 0 && tok_reg[w * 32 + key] != qreg) v += -100.0f;
+                    if (mbits[w] >> r & 1) v += -100.0f;
                 }
                 st[r] = v;
                 mx = fmaxf(mx, v);

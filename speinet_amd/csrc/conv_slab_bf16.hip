@@ -254,6 +254,9 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        float biasv[TN];                     // fetched ahead of the main loop: the epilogue must not start with a load latency
+#pragma unroll
+        for (int j = 0; j < TN; ++j) biasv[j] = p.bias ? p.bias[((nc * WN + wn) * TN + j) * 32 + fr] : 0.f;
 
         // A fragments are software-pipelined one k-step ahead (two register sets) and sched_group_barrier pins
         // "LDS reads of step s+1, then MFMAs of step s": left alone the compiler waits on each ds_read right before its MFMA.
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int ncol0 = (nbase + j) * 32;
-                const float bias = p.bias ? p.bias[ncol0 + fr] : 0.f;
+                const float bias = biasv[j];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     float a[4];
