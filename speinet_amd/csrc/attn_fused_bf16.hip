@@ -173,30 +173,52 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const AttnParams p) 
             const __bf16* wqp = p.wq + (size_t)h * 16 * 512 + lane * 8;
             const __bf16* wkp = p.wkv + (size_t)h * 16 * 512 + lane * 8;
             const __bf16* wvp = p.wkv + (size_t)(8 + h) * 16 * 512 + lane * 8;
-            bf16x8 wqf[2], wkf[2], wvf[2];
-            int ks = rot;
-            wqf[0] = *reinterpret_cast<const bf16x8*>(wqp + ks * 512);
-            wkf[0] = *reinterpret_cast<const bf16x8*>(wkp + ks * 512);
-            wvf[0] = *reinterpret_cast<const bf16x8*>(wvp + ks * 512);
+            // Software pipeline pinned with full scheduling barriers: weight fragments two k-steps ahead (3-slot ring), token
+            // fragments one step ahead, then the 6 MFMAs of the step.  Left alone the scheduler sinks each global_load to
+            // right before its use (s_waitcnt vmcnt(0) in front of every MFMA group: seen in the ISA).
+            bf16x8 wqf[3], wkf[3], wvf[3];
+#pragma unroll
+            for (int pre = 0; pre < 2; ++pre) {
+                wqf[pre] = *reinterpret_cast<const bf16x8*>(wqp + ((rot + pre) & 15) * 512);
+                wkf[pre] = *reinterpret_cast<const bf16x8*>(wkp + ((rot + pre) & 15) * 512);
+                wvf[pre] = *reinterpret_cast<const bf16x8*>(wvp + ((rot + pre) & 15) * 512);
+            }
+            bf16x8 yn[2], xn[2];
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                yn[w] = *reinterpret_cast<const bf16x8*>(ys + (w * 32 + fr) * PA + rot * 32 + fk * 16);
+                xn[w] = *reinterpret_cast<const bf16x8*>(xs + (w * 32 + fr) * PA + rot * 32 + fk * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int cur = i & 1;
-                const int ksn = (ks + 1) & 15;
+                const int cur = i % 3;
+                bf16x8 yc[2], xc[2];
+#pragma unroll
+                for (int w = 0; w < 2; ++w) { yc[w] = yn[w]; xc[w] = xn[w]; }
                 if (i + 1 < 16) {
-                    wqf[cur ^ 1] = *reinterpret_cast<const bf16x8*>(wqp + ksn * 512);
-                    wkf[cur ^ 1] = *reinterpret_cast<const bf16x8*>(wkp + ksn * 512);
-                    wvf[cur ^ 1] = *reinterpret_cast<const bf16x8*>(wvp + ksn * 512);
+                    const int ko = ((rot + i + 1) & 15) * 32 + fk * 16;
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        yn[w] = *reinterpret_cast<const bf16x8*>(ys + (w * 32 + fr) * PA + ko);
+                        xn[w] = *reinterpret_cast<const bf16x8*>(xs + (w * 32 + fr) * PA + ko);
+                    }
                 }
-                const int ko = ks * 32 + fk * 16;
+                const bf16x8 wqc = wqf[cur], wkc = wkf[cur], wvc = wvf[cur];
+                if (i + 2 < 16) {
+                    const int nxt = (i + 2) % 3, ksn = (rot + i + 2) & 15;
+                    wqf[nxt] = *reinterpret_cast<const bf16x8*>(wqp + ksn * 512);
+                    wkf[nxt] = *reinterpret_cast<const bf16x8*>(wkp + ksn * 512);
+                    wvf[nxt] = *reinterpret_cast<const bf16x8*>(wvp + ksn * 512);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int w = 0; w < 2; ++w) {
-                    const bf16x8 yf = *reinterpret_cast<const bf16x8*>(ys + (w * 32 + fr) * PA + ko);
-                    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xs + (w * 32 + fr) * PA + ko);
-                    qT[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wqf[cur], yf, qT[w], 0, 0, 0);
-                    kT[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wkf[cur], xf, kT[w], 0, 0, 0);
-                    vv[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, wvf[cur], vv[w], 0, 0, 0);
+                    qT[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wqc, yc[w], qT[w], 0, 0, 0);
+                    kT[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wkc, xc[w], kT[w], 0, 0, 0);
+                    vv[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xc[w], wvc, vv[w], 0, 0, 0);
                 }
-                ks = ksn;
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
@@ -282,21 +304,30 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const AttnParams p) 
         for (int pre = 0; pre < 2; ++pre)
 #pragma unroll
             for (int nn = 0; nn < 2; ++nn) wf[pre][nn] = *reinterpret_cast<const bf16x8*>(wpp + (nn * 16 + ((ks + pre) & 15)) * 512);
+        bf16x8 an[2];
+        an[0] = *reinterpret_cast<const bf16x8*>(os + fr * PA + ks * 32 + fk * 16);
+        an[1] = *reinterpret_cast<const bf16x8*>(os + (32 + fr) * PA + ks * 32 + fk * 16);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int cur = i % 3, nxt = (i + 2) % 3;
+            const bf16x8 a0 = an[0], a1 = an[1];
+            if (i + 1 < 16) {
+                const int ko = ((ks + 1) & 15) * 32 + fk * 16;
+                an[0] = *reinterpret_cast<const bf16x8*>(os + fr * PA + ko);
+                an[1] = *reinterpret_cast<const bf16x8*>(os + (32 + fr) * PA + ko);
+            }
+            const bf16x8 w0 = wf[cur][0], w1 = wf[cur][1];
             if (i + 2 < 16) {
 #pragma unroll
                 for (int nn = 0; nn < 2; ++nn) wf[nxt][nn] = *reinterpret_cast<const bf16x8*>(wpp + (nn * 16 + ((ks + 2) & 15)) * 512);
             }
-            const int ko = ks * 32 + fk * 16;
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(os + fr * PA + ko);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(os + (32 + fr) * PA + ko);
-#pragma unroll
-            for (int nn = 0; nn < 2; ++nn) {
-                acc[0][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf[cur][nn], acc[0][nn], 0, 0, 0);
-                acc[1][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[cur][nn], acc[1][nn], 0, 0, 0);
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w0, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w0, acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w1, acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
             ks = (ks + 1) & 15;
         }
 #pragma unroll

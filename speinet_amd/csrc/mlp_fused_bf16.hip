@@ -137,16 +137,28 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams p) {
         for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[i][r] = 0.f;
+        // Software pipeline, pinned with full scheduling barriers: "LDS fragments of step s+1 and the refill of the ring slot,
+        // then the MFMAs of step s".  Left alone the scheduler sinks every load to right before its use (ds_read +
+        // lgkmcnt(0) in front of each MFMA, global_load + vmcnt(0) one step ahead: seen in the ISA) and the loop runs at
+        // LDS / L2 latency; sched_group_barrier groups did not take in this fully unrolled region.
+        bf16x8 tn[RT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) tn[i] = *reinterpret_cast<const bf16x8*>(abase + i * 32 * PA + rot * 32);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const int ks = (rot + s) & 15;
+            bf16x8 tc[RT];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) tc[i] = tn[i];
+            if (s + 1 < 16) {
+#pragma unroll
+                for (int i = 0; i < RT; ++i) tn[i] = *reinterpret_cast<const bf16x8*>(abase + i * 32 * PA + ((rot + s + 1) & 15) * 32);
+            }
             const bf16x8 w = ring[s % RING];
             if (s + RING < 16) ring[s % RING] = *reinterpret_cast<const bf16x8*>(wptr + ((rot + s + RING) & 15) * 512);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < RT; ++i) {
-                const bf16x8 t = *reinterpret_cast<const bf16x8*>(abase + i * 32 * PA + ks * 32);
-                acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, t, acc1[i], 0, 0, 0);
-            }
+            for (int i = 0; i < RT; ++i) acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, tc[i], acc1[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // fc2 weight stream of this half starts under the GELU; the last half fetches ALL its fragments here, so that the
         // residual loads below can queue behind them without any later weight load waiting for those (vmcnt is in order)
@@ -186,20 +198,22 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams p) {
         __syncthreads();
         // ---- 2b. fc2 partial product over this half of the hidden dim ------------------------------------------------------
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int ks = (rot + s) & 15;
-            bf16x8 w;
-            if (half == 0) {
-                w = ring[s % RING];
-                if (s + RING < 16) ring[s % RING] = *reinterpret_cast<const bf16x8*>(wptr + ((rot + s + RING) & 15) * 512);
-            } else {
-                w = wlast[s];
-            }
+        for (int i = 0; i < RT; ++i) tn[i] = *reinterpret_cast<const bf16x8*>(hbase + i * 32 * PA + rot * 32);
 #pragma unroll
-            for (int i = 0; i < RT; ++i) {
-                const bf16x8 t = *reinterpret_cast<const bf16x8*>(hbase + i * 32 * PA + ks * 32);
-                acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t, w, acc2[i], 0, 0, 0);
+        for (int s = 0; s < 16; ++s) {
+            bf16x8 tc[RT];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) tc[i] = tn[i];
+            if (s + 1 < 16) {
+#pragma unroll
+                for (int i = 0; i < RT; ++i) tn[i] = *reinterpret_cast<const bf16x8*>(hbase + i * 32 * PA + ((rot + s + 1) & 15) * 32);
             }
+            const bf16x8 w = half == 0 ? ring[s % RING] : wlast[s];
+            if (half == 0 && s + RING < 16) ring[s % RING] = *reinterpret_cast<const bf16x8*>(wptr + ((rot + s + RING) & 15) * 512);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < RT; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tc[i], w, acc2[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (half == 0) {
             wptr = p.w1 + (size_t)(8 + wave) * 16 * 512 + lane * 8;      // fc1, half 1
