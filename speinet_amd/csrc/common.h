@@ -26,16 +26,41 @@ void spei_set_error(const char* fmt, ...);
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// ---- cross-lane reductions on the VALU (DPP + gfx950 permlane swaps): no LDS-pipe traffic, unlike __shfl_xor -------
+// (ds_bpermute; 12 of them per wave_sum made the LayerNorm / gate-statistics kernels LDS-instruction-bound)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+struct OpSum { static __device__ __forceinline__ float f(float a, float b) { return a + b; } };
+struct OpMax { static __device__ __forceinline__ float f(float a, float b) { return fmaxf(a, b); } };
+// v <- op(v, value of lane ^ M) for M = 8 (row_ror:8), 16 (v_permlane16_swap), 32 (v_permlane32_swap)
+template <int M, typename Op>
+__device__ __forceinline__ float xor_combine(float v) {
+    if constexpr (M == 8) {
+        return Op::f(v, dpp_mov<0x128>(v));
+    } else if constexpr (M == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return Op::f(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    } else {
+        static_assert(M == 32, "xor_combine: M must be 8, 16 or 32");
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return Op::f(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
 }
+// all-reduce over the 64 lanes: xor 1, xor 2 (quad_perm), row_half_mirror, row_mirror (the values are already uniform
+// inside the quads / octets they pair), then the two swaps
+template <typename Op>
+__device__ __forceinline__ float wave_allreduce(float v) {
+    v = Op::f(v, dpp_mov<0xB1>(v));
+    v = Op::f(v, dpp_mov<0x4E>(v));
+    v = Op::f(v, dpp_mov<0x141>(v));
+    v = Op::f(v, dpp_mov<0x140>(v));
+    v = xor_combine<16, Op>(v);
+    return xor_combine<32, Op>(v);
+}
+__device__ __forceinline__ float wave_sum(float v) { return wave_allreduce<OpSum>(v); }
+__device__ __forceinline__ float wave_max(float v) { return wave_allreduce<OpMax>(v); }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -85,11 +85,13 @@ __global__ __launch_bounds__(256) void gate_stats_kernel(const TX* __restrict__ 
             cmax = max4(cmax, vmax);
             csum += vsum;
         }
-        // reduce over the PLW columns of this wave (lanes cq + CQ*j), fixed order => reproducible
+        // reduce over the PLW columns of this wave (lanes cq + CQ*j), fixed order => reproducible; VALU-only butterflies
 #pragma unroll
-        for (int m = CQ; m < 64; m <<= 1) {
-            vmax = max4(vmax, shfl4(vmax, m));
-            vsum += shfl4(vsum, m);
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (CQ <= 8) { vmax[e] = xor_combine<8, OpMax>(vmax[e]); vsum[e] = xor_combine<8, OpSum>(vsum[e]); }
+            if constexpr (CQ <= 16) { vmax[e] = xor_combine<16, OpMax>(vmax[e]); vsum[e] = xor_combine<16, OpSum>(vsum[e]); }
+            vmax[e] = xor_combine<32, OpMax>(vmax[e]);
+            vsum[e] = xor_combine<32, OpSum>(vsum[e]);
         }
         if (lane < CQ) {
             smax[k][wave][cq] = vmax;
