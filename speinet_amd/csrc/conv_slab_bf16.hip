@@ -89,7 +89,8 @@ struct Stage<__bf16, SPLIT> {
 };
 
 template <int WM, int WN, int TM, int TN, bool SPLIT, typename TA, typename TO>
-__global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParams p) {
+    constexpr int NT = 64 * WM * WN;                   // threads: 4 or 8 waves
     typedef Stage<TA, SPLIT> ST;
     typedef typename ST::reg_t sreg_t;
     constexpr int CH = ST::CH;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
     auto rg = [&](int g) __attribute__((always_inline)) { const int r = g + rot; return r >= ngroups ? r - ngroups : r; };
 
     // ---- group -> slab byte offset table ------------------------------------------------------------
-    for (int g = tid; g < ngroups; g += 256) {
+    for (int g = tid; g < ngroups; g += NT) {
         const int t = g / kg_per_tap, kg = g - t * kg_per_tap;
         const int ty = t / p.ks, tx = t - ty * p.ks;
         goff[g] = (ty * p.IW + tx) * pitch + kg * (G * 32);
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
         if (p.cp_shift >= 0) {
             // fixed channel chunk per thread, pixels walked with a constant step: no divisions in the loop
             const int c = (tid & (cpn - 1)) * CH;
-            const int step = 256 >> p.cp_shift;
+            const int step = NT >> p.cp_shift;
             const int step_y = (int)(((unsigned)step * (unsigned)p.iw_magic) >> 20), step_x = step - step_y * p.IW;
             int pix = tid >> p.cp_shift;
             int iy = (int)(((unsigned)pix * (unsigned)p.iw_magic) >> 20), ix = pix - iy * p.IW;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void conv_slab_kernel(const SlabParams p) {
             }
         } else {
             const int total = npix * cpn;
-            for (int idx = tid; idx < total; idx += 256) {
+            for (int idx = tid; idx < total; idx += NT) {
                 const int pix = idx / cpn, c = (idx - pix * cpn) * CH;
                 const int iy = pix / p.IW, ix = pix - iy * p.IW;
                 const int gy = gy0 + iy, gx = gx0 + ix;
@@ -402,7 +403,7 @@ int launch(const SlabParams& p, size_t lds, hipStream_t s) {
     static const int dbg = getenv("SPEI_SLAB_DBG") ? atoi(getenv("SPEI_SLAB_DBG")) : 0;
     q.dbg = dbg;
     dim3 grid(p.tiles_x * cdiv(p.Hout, p.TH), 1);
-    hipLaunchKernelGGL((conv_slab_kernel<WM, WN, TM, TN, SPLIT, TA, TO>), grid, dim3(256), lds, s, q);
+    hipLaunchKernelGGL((conv_slab_kernel<WM, WN, TM, TN, SPLIT, TA, TO>), grid, dim3(64 * WM * WN), lds, s, q);
     SPEI_CHECK_LAUNCH("spei_conv_slab_bf16");
     return 0;
 }
@@ -433,8 +434,17 @@ int dispatch(SlabParams& p, hipStream_t s) {
     };
     const size_t budget = 96 * 1024;
     const size_t hard = 160 * 1024 - 512;
+    // 8-wave workgroups (two waves per SIMD share one slab) for the non-split mode; knobs for tools/ablate_slab.py:
+    // SPEI_SLAB_W8=<bitmask> 1: N%128 layers, 2: N%64 layers, 4: N=32 layers
+    static const int w8 = getenv("SPEI_SLAB_W8") ? atoi(getenv("SPEI_SLAB_W8")) : 0;
     size_t lds;
     if (p.N % 128 == 0) {
+        if (!SPLIT && (w8 & 1)) {
+            lds = setup(256);
+            if (lds <= hard && p.IH * p.IW < 2048 && !linear) return launch<2, 4, 4, 1, SPLIT, TA, TO>(p, lds, s);
+            lds = setup(128);
+            if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 4, 2, 1, SPLIT, TA, TO>(p, lds, s);
+        }
         lds = setup(128);
         const int64_t tiles128 = (int64_t)p.tiles_x * cdiv(p.Hout, p.TH);
         static const int min_tiles = getenv("SPEI_SLAB_MIN_TILES128") ? atoi(getenv("SPEI_SLAB_MIN_TILES128")) : 0;
@@ -442,9 +452,17 @@ int dispatch(SlabParams& p, hipStream_t s) {
         lds = setup(64);
         if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 4, 2, 1, SPLIT, TA, TO>(p, lds, s);
     } else if (p.N % 64 == 0) {
+        if (!SPLIT && (w8 & 2)) {
+            lds = setup(256);
+            if (lds <= hard && p.IH * p.IW < 2048) return launch<4, 2, 2, 1, SPLIT, TA, TO>(p, lds, s);
+        }
         lds = setup(128);
         if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 2, 2, 1, SPLIT, TA, TO>(p, lds, s);
     } else {
+        if (!SPLIT && (w8 & 4)) {
+            lds = setup(512);
+            if (lds <= hard && p.IH * p.IW < 2048) return launch<8, 1, 2, 1, SPLIT, TA, TO>(p, lds, s);
+        }
         static const int n32_tile = getenv("SPEI_SLAB_N32_TILE") ? atoi(getenv("SPEI_SLAB_N32_TILE")) : 256;
         lds = setup(256);
         if (n32_tile == 256 && lds <= budget && p.IH * p.IW < 2048) return launch<4, 1, 2, 1, SPLIT, TA, TO>(p, lds, s);

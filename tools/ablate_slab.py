@@ -16,12 +16,13 @@ shapes = [  # name, H, W, Cin, Cout, ks, stride, residual
     ("linear 256->256 +res", 57600, 1, 256, 256, 1, 1, True),
     ("linear 512->256 +res", 57600, 1, 512, 256, 1, 1, True),
 ]
+IN_BF16 = os.environ.get("IN_BF16", "0") == "1"      # ResBlock conv2: bf16 in, bf16 out
 for name, h, w, ci, co, ks, st, res in shapes:
-    x = FMap(torch.randn(h * w, ci, device=dev), h, w, ci)
+    x = FMap(torch.randn(h * w, ci, device=dev).to(torch.bfloat16 if (IN_BF16 and ks == 5) else torch.float32), h, w, ci)
     wt = pack.PackedW(torch.randn(ks * ks, co, ci) * 0.05, dev)
     b = torch.randn(co, device=dev)
     r = FMap(torch.randn(h * w, co, device=dev), h, w, co) if res else None
-    out = FMap.empty(h, w, co, dev)
+    out = FMap(torch.empty(h * w, co, device=dev, dtype=torch.bfloat16 if ks == 5 else torch.float32), h, w, co)   # as in the ResBlocks
     for _ in range(3):
         ops.igemm(x, wt, b, co, ksize=ks, stride=st, residual=r, out=out)
     torch.cuda.synchronize()
