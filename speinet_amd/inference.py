@@ -5,15 +5,21 @@ selection logic, uint8 round trip, PSNR/SSIM and log-line format — with the fo
     <data_path>/{blur,gt}/<clip>/<frame>.png       [<data_path>/label/<clip>.npy  (0/1 per frame, 1 = sharp)]
 
 Without a label file the LD detector (speinet_amd.detector, row a11) labels the frames on the GPU.
+File I/O is off the critical path (the authors' logs show ~0.2 s of pre/post time per frame, a 5 frames/s cap): every
+frame file is decoded once (windows overlap by n_sequence-1 frames) by a pool of prefetch threads that runs `--prefetch`
+windows ahead of the GPU, and uint8 conversion, PSNR/SSIM and the PNG encode of a finished frame run on worker threads
+while the GPU deblurs the next one; log lines are still written in frame order.
 Reference: inference_SPEINet.py:193-237 (__init__), :338-429 (infer), :484-543 (metrics), :610-700 (flags / presets).
 SSIM is restated with numpy (cv2 is absent): Gaussian 11x11, sigma 1.5, valid region — parity unpinned.
 """
 from __future__ import annotations
 
 import argparse
+import collections
 import glob
 import os
 import time
+from concurrent.futures import Future, ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -34,23 +40,58 @@ def _imwrite(path: str, img: np.ndarray) -> None:
 
 
 def calc_ssim(img1: np.ndarray, img2: np.ndarray) -> float:
-    """inference_SPEINet.py:502-543: the reference averages the same 3-channel value three times."""
+    """inference_SPEINet.py:502-543: the reference averages the same 3-channel value three times.  The 11x11 Gaussian
+    window is outer(k, k): applied as two 1-D passes (scipy.ndimage, float64, GIL released), valid region only."""
+    from scipy.ndimage import correlate1d
     ax = np.arange(11) - 5
     k = np.exp(-(ax ** 2) / (2 * 1.5 ** 2))
     k /= k.sum()
-    win = np.outer(k, k)
     c1, c2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
     a, b = img1.astype(np.float64), img2.astype(np.float64)
 
     def filt(x):   # valid region only ([5:-5, 5:-5] of the reference's same-size filter2D)
-        from numpy.lib.stride_tricks import sliding_window_view
-        v = sliding_window_view(x, (11, 11), axis=(0, 1))
-        return np.einsum("ijc...kl,kl->ijc...", v, win) if x.ndim == 3 else np.einsum("ijkl,kl->ij", v, win)
+        y = correlate1d(correlate1d(x, k, axis=0, mode="constant"), k, axis=1, mode="constant")
+        return y[5:-5, 5:-5]
 
     mu1, mu2 = filt(a), filt(b)
     s1, s2, s12 = filt(a * a) - mu1 ** 2, filt(b * b) - mu2 ** 2, filt(a * b) - mu1 * mu2
     m = ((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 ** 2 + mu2 ** 2 + c1) * (s1 + s2 + c2))
     return float(m.mean())
+
+
+_BANDS: dict = {}
+
+
+def _gauss_band(n: int, device) -> torch.Tensor:
+    """[n-10, n] float64 band matrix of the 11-tap Gaussian (sigma 1.5): valid-region filtering along one axis as a matmul."""
+    key = (n, str(device))
+    if key not in _BANDS:
+        ax = torch.arange(11, dtype=torch.float64) - 5
+        k = torch.exp(-(ax ** 2) / (2 * 1.5 ** 2))
+        k /= k.sum()
+        m = torch.zeros(n - 10, n, dtype=torch.float64)
+        for i in range(n - 10):
+            m[i, i:i + 11] = k
+        _BANDS[key] = m.to(device)
+    return _BANDS[key]
+
+
+def metrics_gpu(out_u8: torch.Tensor, gt_u8: torch.Tensor):
+    """PSNR and SSIM of two uint8 [H,W,3] frames on the GPU in float64 (same formulas as calc_psnr / calc_ssim; the
+    separable Gaussian is two band-matrix products).  Returns two 0-d device tensors: no host sync here."""
+    a, b = out_u8.to(torch.float64), gt_u8.to(torch.float64)
+    mse = ((a - b) ** 2).mean()
+    psnr = 20.0 * torch.log10(255.0 / torch.sqrt(mse))
+    kh, kw = _gauss_band(a.shape[0], a.device), _gauss_band(a.shape[1], a.device)
+
+    def filt(x):
+        return torch.einsum("jw,iwc->ijc", kw, torch.einsum("ih,hwc->iwc", kh, x))
+
+    c1, c2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    mu1, mu2 = filt(a), filt(b)
+    s1, s2, s12 = filt(a * a) - mu1 ** 2, filt(b * b) - mu2 ** 2, filt(a * b) - mu1 * mu2
+    ssim = (((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 ** 2 + mu2 ** 2 + c1) * (s1 + s2 + c2))).mean()
+    return psnr, ssim
 
 
 class Logger:
@@ -64,6 +105,28 @@ class Logger:
             print(line)
         self.f.write(line + "\n")
         self.f.flush()
+
+
+class FrameCache:
+    """Decode-once cache of frame files, filled by a thread pool: `request(paths)` schedules decodes, `get(path)` blocks
+    until that file is decoded.  Bounded LRU (a 720p RGB frame is 2.8 MB)."""
+
+    def __init__(self, pool: ThreadPoolExecutor, capacity: int = 96):
+        self.pool, self.capacity = pool, capacity
+        self.items: "collections.OrderedDict[str, Future]" = collections.OrderedDict()
+
+    def request(self, paths) -> None:
+        for p in paths:
+            if p in self.items:
+                self.items.move_to_end(p)
+            else:
+                self.items[p] = self.pool.submit(_imread, p)
+        while len(self.items) > self.capacity:
+            self.items.popitem(last=False)
+
+    def get(self, path: str) -> np.ndarray:
+        self.request([path])
+        return self.items[path].result()
 
 
 class Inference:
@@ -85,6 +148,12 @@ class Inference:
         self.net = self.net.to(self.device).eval()
         self.net.precision = args.precision
         self.net.corr_precision = args.precision if args.precision != "f32" else "bf16x3"
+        self.net.use_graph = bool(getattr(args, "graph", True))      # one hipGraph per frame shape / routing
+        self.net.streams = int(getattr(args, "streams", 2))
+        workers = max(2, min(8, (os.cpu_count() or 4) // max(1, self.world)))
+        self.io_pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="speinet-io")
+        self.post_pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="speinet-post")
+        self.prefetch = max(1, int(getattr(args, "prefetch", 4)))
 
     def labels_for(self, clip: str, frames: list) -> np.ndarray:
         p = os.path.join(self.args.data_path, "label", clip + ".npy")
@@ -94,12 +163,21 @@ class Inference:
         feats = torch.cat([detector.focus_measures(imgs[i:i + 16].to(self.device), 11) for i in range(0, len(imgs), 16)])
         return detector.predict(feats)
 
+    def _post(self, out_u8: torch.Tensor, psnr: torch.Tensor, ssim: torch.Tensor, save_to: str):
+        """Worker thread: fetch the frame and its two metrics from the GPU, encode the PNG."""
+        t0 = time.time()
+        psnr, ssim = float(psnr.item()), float(ssim.item())
+        if save_to:
+            _imwrite(save_to, out_u8.cpu().numpy())
+        return (float("inf") if psnr != psnr or psnr == float("inf") else psnr), ssim, time.time() - t0
+
     def infer(self):
         a = self.args
         clips = sorted(os.listdir(os.path.join(a.data_path, "blur")))
         lengths = [len(glob.glob(os.path.join(a.data_path, "blur", c, "*"))) for c in clips]
         mine = shard_clips_by_length(lengths, self.world)[self.rank]
         stats = torch.zeros(3, dtype=torch.float64)             # sum psnr, sum ssim, frames
+        cache = FrameCache(self.io_pool)
         with torch.no_grad():
             for ci in mine:
                 clip = clips[ci]
@@ -107,35 +185,45 @@ class Inference:
                 gts = sorted(glob.glob(os.path.join(a.data_path, "gt", clip, "*")))
                 wins = selection.assemble_windows(blur, self.labels_for(clip, blur), self.n_seq, a.border)
                 gt_seqs, _ = selection.gene_seq(gts, self.n_seq, a.border)
+                needs = [w["window"] + [w["pre"], w["sub"], g[self.n_seq // 2]] for w, g in zip(wins, gt_seqs)]
+                if a.save_image:
+                    os.makedirs(os.path.join(a.result_path, clip), exist_ok=True)
                 vp, vs = [], []
-                for w, gseq in zip(wins, gt_seqs):
+                pending = collections.deque()                   # (name, future, pre_time, forward_time, t_start), frame order
+
+                def flush(block: bool):
+                    while pending and (block or pending[0][1].done()):
+                        name, fut, t_pre, t_fwd, t_start = pending.popleft()
+                        psnr, ssim, t_post = fut.result()
+                        vp.append(psnr)
+                        vs.append(ssim)
+                        self.logger.write_log('> {}-{} PSNR={:.5}, SSIM={:.4} pre_time:{:.3}s, forward_time:{:.3}s, post_time:{:.3}s, total_time:{:.3}s'
+                                              .format(clip, name, psnr, ssim, t_pre, t_fwd, t_post, t_pre + t_fwd + t_post))
+
+                for k, (w, gseq) in enumerate(zip(wins, gt_seqs)):
                     t0 = time.time()
-                    imgs = [_imread(p) for p in w["window"] + [w["pre"], w["sub"]]]
-                    gt = _imread(gseq[self.n_seq // 2])
+                    for ahead in needs[k:k + 1 + self.prefetch]:
+                        cache.request(ahead)
+                    imgs = [cache.get(p) for p in needs[k]]
+                    gt = imgs.pop()
                     h, wd = imgs[self.n_seq // 2].shape[:2]
                     nh, nw = h - h % 20, wd - wd % 20           # the model needs multiples of 20 (reference crops to 4)
                     imgs = [im[:nh, :nw] for im in imgs]
-                    gt = gt[:nh, :nw]
                     if w["zero_pre"]:
                         imgs[-2] = np.zeros_like(imgs[-2])
                     if w["zero_sub"]:
                         imgs[-1] = np.zeros_like(imgs[-1])
-                    x = selection.numpy2tensor(imgs).to(self.device)
+                    x = selection.numpy2tensor_device(imgs, self.device)
                     t1 = time.time()
                     out = self.net(x, routing=[bool(w["zero_pre"])])
-                    torch.cuda.synchronize()
+                    out_u8 = out.mul(255.0).clamp(0, 255).round()[0].to(torch.uint8).permute(1, 2, 0).contiguous()   # = tensor2numpy, on the GPU
+                    gt_u8 = torch.from_numpy(gt[:nh, :nw].copy()).to(self.device, non_blocking=True)
+                    psnr, ssim = metrics_gpu(out_u8[4:-4, 4:-4], gt_u8[4:-4, 4:-4])     # border crop: inference_SPEINet.py:405-410
                     t2 = time.time()
-                    out_img = selection.tensor2numpy(out)
-                    psnr = selection.calc_psnr(gt[4:-4, 4:-4], out_img[4:-4, 4:-4])
-                    ssim = calc_ssim(gt[4:-4, 4:-4], out_img[4:-4, 4:-4])
-                    vp.append(psnr)
-                    vs.append(ssim)
-                    if a.save_image:
-                        os.makedirs(os.path.join(a.result_path, clip), exist_ok=True)
-                        _imwrite(os.path.join(a.result_path, clip, w["name"] + ".png"), out_img)
-                    t3 = time.time()
-                    self.logger.write_log('> {}-{} PSNR={:.5}, SSIM={:.4} pre_time:{:.3}s, forward_time:{:.3}s, post_time:{:.3}s, total_time:{:.3}s'
-                                          .format(clip, w["name"], psnr, ssim, t1 - t0, t2 - t1, t3 - t2, t3 - t0))
+                    save_to = os.path.join(a.result_path, clip, w["name"] + ".png") if a.save_image else ""
+                    pending.append((w["name"], self.post_pool.submit(self._post, out_u8, psnr, ssim, save_to), t1 - t0, t2 - t1, t0))
+                    flush(block=len(pending) > 2 * self.prefetch)
+                flush(block=True)
                 self.logger.write_log("# Video:{} AVG-PSNR={:.5}, AVG-SSIM={:.4}".format(clip, sum(vp) / len(vp), sum(vs) / len(vs)))
                 stats += torch.tensor([sum(vp), sum(vs), float(len(vp))], dtype=torch.float64)
         dist = None
@@ -167,6 +255,9 @@ def build_args(argv=None):
     p.add_argument("--result_path", type=str, default=None)
     p.add_argument("--device", type=str, default="cuda")
     p.add_argument("--precision", choices=["f32", "bf16x3", "bf16"], default="f32")
+    p.add_argument("--prefetch", type=int, default=4, help="windows decoded ahead of the GPU")
+    p.add_argument("--streams", type=int, default=2, help="HIP streams for the independent branches of a frame")
+    p.add_argument("--no_graph", dest="graph", action="store_false", default=True, help="launch kernels eagerly (no hipGraph replay)")
     a = p.parse_args(argv)
     for k, v in PRESETS.get(a.default_data, {}).items():
         if getattr(a, k) is None:

@@ -119,6 +119,13 @@ def numpy2tensor(images: Sequence[np.ndarray], rgb_range: float = 1.0) -> torch.
     return torch.stack(ts).unsqueeze(0)
 
 
+def numpy2tensor_device(images: Sequence[np.ndarray], device, rgb_range: float = 1.0) -> torch.Tensor:
+    """Same values as `numpy2tensor`, but the uint8 frames cross PCIe (4x fewer bytes) and are converted on the device:
+    uint8 -> float32 is exact and the one float32 multiply rounds identically."""
+    u8 = torch.from_numpy(np.stack([np.asarray(im) for im in images])).to(device, non_blocking=True)      # [n, H, W, 3]
+    return u8.permute(0, 3, 1, 2).float().mul_(rgb_range / 255).unsqueeze(0).contiguous()
+
+
 def tensor2numpy(t: torch.Tensor, rgb_range: float = 1.0) -> np.ndarray:
     img = t.mul(255 / rgb_range).clamp(0, 255).round()[0]
     return np.transpose(img.cpu().numpy(), (1, 2, 0)).astype(np.uint8)

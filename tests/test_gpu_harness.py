@@ -49,6 +49,7 @@ def test_harness_two_clips(tmp_path):
         imgs[-2] = np.zeros_like(imgs[-2])
     if w["zero_sub"]:
         imgs[-1] = np.zeros_like(imgs[-1])
+    assert torch.equal(selection.numpy2tensor_device(imgs, "cuda:0").cpu(), selection.numpy2tensor(imgs))
     with torch.no_grad():
         out = inf.net(selection.numpy2tensor(imgs).cuda())
     saved = inference._imread(os.path.join(res, "clipA", w["name"] + ".png"))

@@ -1,5 +1,7 @@
 """CPU suite: host-side logic and the C-ABI surface (no compute calls without a GPU)."""
 import ctypes
+
+import numpy as np
 import os
 
 import pytest
@@ -82,3 +84,16 @@ def test_packing_algebra(synth_sd):
     assert torch.equal(pack.conv_w(w)[2 * 5 + 3], w[:, :, 2, 3])
     wt = torch.randn(3, 7, 3, 3)
     assert torch.equal(pack.convT_w(wt)[1 * 3 + 2], wt[:, :, 1, 2].t())
+
+
+def test_harness_metrics_match_cpu_formulas():
+    """The harness computes PSNR / SSIM on the device (float64 band-matrix Gaussian); same numbers as the numpy/scipy forms."""
+    from speinet_amd import inference, selection
+    rng = np.random.RandomState(3)
+    for h, w in ((32, 40), (57, 33)):
+        a = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        b = np.clip(a.astype(int) + rng.randint(-25, 25, a.shape), 0, 255).astype(np.uint8)
+        p, s = inference.metrics_gpu(torch.from_numpy(a), torch.from_numpy(b))
+        assert abs(p.item() - selection.calc_psnr(a, b)) < 1e-9 and abs(s.item() - inference.calc_ssim(a, b)) < 1e-12
+    p, _ = inference.metrics_gpu(torch.from_numpy(a), torch.from_numpy(a))
+    assert p.item() == float("inf")
