@@ -24,7 +24,7 @@ from concurrent.futures import Future, ThreadPoolExecutor
 import numpy as np
 import torch
 
-from . import detector, selection
+from . import checkpoint, detector, selection
 from .dist import gather_metrics, shard_clips_by_length
 from .speinet import SPEINet, default_args
 
@@ -141,7 +141,7 @@ class Inference:
             self.logger.write_log(f"{k}: {getattr(args, k)}")
         self.net = SPEINet(in_channels=3, n_sequence=self.n_seq, out_channels=3, n_resblock=3, n_feat=32, device=str(self.device), args=args)
         if args.model_path and args.model_path != "synthetic":
-            self.net.load_state_dict(torch.load(args.model_path, map_location="cpu", weights_only=True))      # strict, like :232
+            checkpoint.load_into(self.net, args.model_path, strict=True)                                      # strict, like :232
         else:
             from .synth import state_dict_template, synth_state_dict
             self.net.load_state_dict(synth_state_dict(state_dict_template(), seed=0))

@@ -97,3 +97,26 @@ def test_harness_metrics_match_cpu_formulas():
         assert abs(p.item() - selection.calc_psnr(a, b)) < 1e-9 and abs(s.item() - inference.calc_ssim(a, b)) < 1e-12
     p, _ = inference.metrics_gpu(torch.from_numpy(a), torch.from_numpy(a))
     assert p.item() == float("inf")
+
+
+def test_checkpoint_tooling(tmp_path, synth_sd):
+    """Export -> check -> strict load round trip; DataParallel `module.` prefix; derived buffers optional; mismatches reported."""
+    from speinet_amd import checkpoint
+    net = SPEINet(args=default_args())
+    net.load_state_dict(synth_sd, strict=True)
+    path = str(tmp_path / "model_best.pt")
+    checkpoint.export(net, path)
+    assert checkpoint.main(["check", path]) == 0
+    other = SPEINet(args=default_args())
+    checkpoint.load_into(other, path)
+    assert all(torch.equal(v, other.state_dict()[k]) for k, v in net.state_dict().items())
+    sd = {"module." + k: v for k, v in checkpoint.read(path).items() if not k.endswith(checkpoint.DERIVED)}
+    torch.save(sd, path)
+    checkpoint.load_into(SPEINet(args=default_args()), path)                 # prefixed, without the derived buffers
+    sd.pop("module.fusion.weight")
+    sd["module.recons_net.inBlock.0.0.weight"] = torch.zeros(32, 3, 3, 3)
+    torch.save(sd, path)
+    missing, unexpected, bad = checkpoint.validate(checkpoint.read(path))
+    assert missing == ["fusion.weight"] and not unexpected and len(bad) == 1 and checkpoint.main(["check", path]) == 1
+    with pytest.raises(RuntimeError):
+        checkpoint.load_into(SPEINet(args=default_args()), path)
