@@ -47,11 +47,12 @@ def corr_flops(h: int, w: int) -> float:
     return 2.0 * 1152.0 * n3 * n3     # [N3 x 1152] x [1152 x N3]
 
 
-def traffic_bytes(precision: str, corr_precision: str):
-    """HBM bytes per launch of the roofline kernel, measured offline with rocprofv3 --pmc (see profiles/)."""
+def traffic_bytes(precision: str, corr_precision: str, key: str = "hbm_bytes_per_launch"):
+    """HBM bytes per launch of the roofline kernel (or per frame of the whole path), measured offline with rocprofv3 --pmc
+    (tools/pmc_traffic.py, profiles/r01_traffic.json)."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        return d.get(f"{precision}/{corr_precision if precision != 'f32' else 'f32'}", {}).get("hbm_bytes_per_launch")
+        return d.get(f"{precision}/{corr_precision if precision != 'f32' else 'f32'}", {}).get(key)
     except (OSError, ValueError):
         return None
 
@@ -167,6 +168,7 @@ def main():
         ach = corr_flops(h, w) / (corr_ms * 1e-3) / 1e12 if corr_ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.precision]
         dtype = args.precision if args.precision == "f32" or args.corr_precision == args.precision else f"{args.precision} (correlation {args.corr_precision})"
+        path_hbm = traffic_bytes(args.precision, args.corr_precision, "path_hbm_bytes_per_frame") if (h, w) == (H, W) else None
         line = {
             "metric": "deblurred 720p frames/sec", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * tmax / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -178,7 +180,9 @@ def main():
                          "frac": ach / peak, "traffic": traffic_bytes(args.precision, args.corr_precision), "launch_ms": corr_ms,
                          "algorithmic_flops_per_launch": corr_flops(h, w),
                          "path_flops_per_frame": path_flops(h, w),
-                         "path_frac": path_flops(h, w) * fps / world / 1e12 / peak},
+                         "path_frac": path_flops(h, w) * fps / world / 1e12 / peak,
+                         "path_hbm_bytes_per_frame": path_hbm,
+                         "path_hbm_frac": (path_hbm * fps / world / 8e12) if path_hbm else None},
             "checksum": float(gathered[:, 0].sum().item()),
         }
         if world == 1 and not args.no_cpu_baseline:

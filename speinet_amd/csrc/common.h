@@ -26,6 +26,21 @@ void spei_set_error(const char* fmt, ...);
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Raise a kernel's dynamic-LDS limit before its first launch with `lds` bytes ON THE CURRENT DEVICE.  The attribute is
+// per device: a process that drives several GPUs (the reference's nn.DataParallel calls forward from one thread per
+// device) must set it on each.  One table per kernel instantiation (the template parameter), keyed by device; the races
+// are benign (the call is idempotent).
+template <typename K>
+inline void ensure_dyn_lds(K kernel, size_t lds) {
+    static size_t have[32] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 32 || lds > have[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (dev >= 0 && dev < 32) have[dev] = lds;
+    }
+}
+
 // ---- cross-lane reductions on the VALU (DPP + gfx950 permlane swaps): no LDS-pipe traffic, unlike __shfl_xor -------
 // (ds_bpermute; 12 of them per wave_sum made the LayerNorm / gate-statistics kernels LDS-instruction-bound)
 template <int CTRL>

@@ -54,7 +54,6 @@ struct SlabParams {
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
-constexpr int EP = 36;      // epilogue tile row pitch (floats): 16-byte aligned rows, write conflict-free
 constexpr int G = 2;        // k-steps (of 16) per group
 constexpr int RING = 4;     // groups of B fragments in flight
 
@@ -392,12 +391,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
 
 template <int WM, int WN, int TM, int TN, bool SPLIT, typename TA, typename TO>
 int launch(const SlabParams& p, size_t lds, hipStream_t s) {
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_slab_kernel<WM, WN, TM, TN, SPLIT, TA, TO>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_lds = lds;
-    }
+    ensure_dyn_lds(&conv_slab_kernel<WM, WN, TM, TN, SPLIT, TA, TO>, lds);
     SlabParams q = p;
     q.n_chunks = p.N / (WN * TN * 32);
     static const int dbg = getenv("SPEI_SLAB_DBG") ? atoi(getenv("SPEI_SLAB_DBG")) : 0;

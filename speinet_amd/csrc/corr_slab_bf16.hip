@@ -289,11 +289,7 @@ void launch_corr(const CorrSlabParams& p, int itiles, int splits, hipStream_t st
     constexpr int L_BYTES = ((((NI + 2) * SLAB_W) * (2 * C + 16) + 15) / 16) * 16;
     constexpr int R_BYTES = ((((RB_H + 2) * SLAB_W) * (2 * KC + 16) + 15) / 16) * 16;
     const size_t lds = (size_t)NPART * L_BYTES + (size_t)2 * NPART * R_BYTES + (size_t)2 * RB_H * RB_W * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_slab_kernel<NI, KC, SPLIT, WJ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    ensure_dyn_lds(&corr_slab_kernel<NI, KC, SPLIT, WJ>, lds);
     hipLaunchKernelGGL((corr_slab_kernel<NI, KC, SPLIT, WJ>), dim3(itiles, splits), dim3(128 * WJ), lds, st, p);
 }
 

@@ -285,11 +285,7 @@ extern "C" int spei_corr_argmax(const float* lr, int ldl, const float* ref, int 
     p.pval = ws;
     p.pidx = reinterpret_cast<int32_t*>(ws + (size_t)CMAXSPLIT * p.Nl);
     const size_t lds = (size_t)2 * (CBM + CBN) * CLD * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_argmax_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    ensure_dyn_lds(&corr_argmax_kernel, lds);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(corr_argmax_kernel, dim3(itiles, splits), dim3(256), lds, st, p);
     hipLaunchKernelGGL(corr_final_kernel, dim3(cdiv(p.Nl, 256)), dim3(256), 0, st, p.pval, p.pidx, splits, p.Nl, S, arg);

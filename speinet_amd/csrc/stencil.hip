@@ -30,7 +30,7 @@ __global__ void any_nonzero_kernel(const float* __restrict__ x, int64_t n, int32
 extern "C" int spei_any_nonzero(const float* x, int64_t n, int32_t* flag, spei_stream_t stream) {
     SPEI_REQUIRE(x && flag && n > 0, "spei_any_nonzero: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    hipMemsetAsync(flag, 0, sizeof(int32_t), s);
+    (void)hipMemsetAsync(flag, 0, sizeof(int32_t), s);
     const int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
     hipLaunchKernelGGL(any_nonzero_kernel, dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, s, x, n, flag);
     SPEI_CHECK_LAUNCH("spei_any_nonzero");
@@ -214,11 +214,7 @@ extern "C" int spei_conv5_out(const float* in_hwc, int ldi, const float* w, cons
     SPEI_REQUIRE(in_hwc && w && bias && out_chw && H > 0 && W > 0, "spei_conv5_out: bad arguments");
     SPEI_REQUIRE(Cin == 32 && ldi % 4 == 0 && ldi >= 32, "spei_conv5_out: Cin=%d ldi=%d (only n_feat=32 is built)", Cin, ldi);
     const size_t lds = ((size_t)(CO_TH + 4) * (CO_TW + 4) * CO_P + 3 * 25 * 32) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_out_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    ensure_dyn_lds(&conv5_out_kernel, lds);
     hipLaunchKernelGGL(conv5_out_kernel, dim3(cdiv(W, CO_TW), cdiv(H, CO_TH)), dim3(256), lds, (hipStream_t)stream,
                        in_hwc, ldi, w, bias, out_chw, H, W);
     SPEI_CHECK_LAUNCH("spei_conv5_out");
