@@ -95,7 +95,8 @@ __global__ __launch_bounds__(128 * WJ) void corr_slab_kernel(const CorrSlabParam
         const int jy0 = rby * RB_H - 1, jx0 = rbx * RB_W - 1;
         if (ch == 0 && tid < RB_H * RB_W) {              // the block's normalisers ride along with its first stage
             const int jy = rby * RB_H + (tid >> 5), jx = rbx * RB_W + (tid & 31);
-            riv = (jy < p.Hr && jx < p.Wr) ? p.inv_ref[jy * p.Wr + jx] : 0.f;
+            // positions outside the map get a NaN normaliser: their scores become NaN and lose every `>` of the fold
+            riv = (jy < p.Hr && jx < p.Wr) ? p.inv_ref[jy * p.Wr + jx] : __builtin_nanf("");
         }
 #pragma unroll
         for (int u = 0; u < RLOADS; ++u) {
@@ -207,31 +208,39 @@ __global__ __launch_bounds__(128 * WJ) void corr_slab_kernel(const CorrSlabParam
         }
         if (st + 1 < nstages) store_stage(buf ^ 1, st + 1);
         if (ch == NCH - 1) {
-            // reference block finished: fold its 128 rows into the running (max, argmax) of this lane's columns
+            // Reference block finished: fold its rows into the running (max, argmax) of this lane's columns.  Branch-free and
+            // latency-free: all 32 normalisers are fetched from LDS first (the fragment registers are dead here), the rows
+            // of a block are visited in increasing j, so inside the block a strict `>` keeps the lowest maximising index;
+            // only the block winner meets the running best under the full (value, lowest index) rule.  This fold used to
+            // take a quarter of the kernel (in-kernel stamps): a dependent LDS read and two branches per row.
             const int rb = rb0 + st / NCH;
             const int rby = rb / p.rblocks_x, rbx = rb - rby * p.rblocks_x;
+            const float* pinv = inv_s + ((st / NCH) & 1) * (RB_H * RB_W) + (wm * 2) * 32 + 4 * fk;
+            float irv[32];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int jy = rby * RB_H + wm * 2 + i;
+            for (int row = 0; row < 32; ++row) irv[row] = pinv[(row >> 4) * 32 + (row & 3) + 8 * ((row & 15) >> 2)];
+            const int jj0 = (rby * RB_H + wm * 2) * p.Wr + rbx * RB_W + 4 * fk;
+            float lbv[TN];
+            int lbi[TN];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int jx = rbx * RB_W + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                    if (jy < p.Hr && jx < p.Wr) {
-                        const int jj = jy * p.Wr + jx;
-                        const float ir = inv_s[((st / NCH) & 1) * (RB_H * RB_W) + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk];
+            for (int j = 0; j < TN; ++j) { lbv[j] = -INFINITY; lbi[j] = 0; }
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) {
-                            if (SPLIT) {        // f32-grade scores: the reference's order of the two normalisations, full tie rule
-                                const float v = acc[i][j][r] * ir * il[j];
-                                if (better(v, jj, bestv[j], besti[j])) { bestv[j] = v; besti[j] = jj; }
-                            } else {            // the query's own normaliser (> 0, constant per lane column) is applied at the end
-                                const float v = acc[i][j][r] * ir;
-                                if (better(v, jj, bestv[j], besti[j])) { bestv[j] = v; besti[j] = jj; }
-                            }
-                        }
-                    }
+            for (int row = 0; row < 32; ++row) {
+                const int i = row >> 4, r = row & 15;
+                const int jj = jj0 + i * p.Wr + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    // SPLIT: f32-grade scores in the reference's order of the two normalisations; otherwise the query's own
+                    // normaliser (> 0, constant per lane column) is applied once at the end
+                    const float v = SPLIT ? acc[i][j][r] * irv[row] * il[j] : acc[i][j][r] * irv[row];
+                    const bool take = v > lbv[j];
+                    lbv[j] = take ? v : lbv[j];
+                    lbi[j] = take ? jj : lbi[j];
                 }
             }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (lbv[j] > -INFINITY && better(lbv[j], lbi[j], bestv[j], besti[j])) { bestv[j] = lbv[j]; besti[j] = lbi[j]; }
         }
         __syncthreads();
     }
