@@ -222,14 +222,16 @@ def test_streams_bit_identical(net, mode, graph):
         assert torch.equal(o, outs[0])
 
 
-def test_forward_bsd_size_modes_agree(net):
+@pytest.mark.parametrize("h,w,b,zero_ref", [(480, 640, 2, (1,)), (720, 1280, 1, ())])
+def test_forward_large_sizes_modes_agree(net, h, w, b, zero_ref):
     """480x640 (the BSD frame size, BASELINE.json configs[3]; 768 windows, lv3 map 120x160 -> partial tiles in every tiled
-    kernel): no oracle run at this size, so the three arithmetic modes are checked against each other.  bf16x3 must stay
-    within the f32-grade bound of the f32 path, bf16 within its documented bound, both routing branches."""
-    x = synth_frames(2, 480, 640, seed=4242, zero_ref=(1,)).to(DEV)
+    kernel, both routing branches) and 720x1280 (the bench configuration): no oracle run at these sizes, so the three
+    arithmetic modes are checked against each other.  bf16x3 must stay within the f32-grade bound of the f32 path, bf16
+    (with the bench's bf16 correlation at 720p) within its documented bound."""
+    x = synth_frames(b, h, w, seed=4242, zero_ref=zero_ref).to(DEV)
     outs = {}
     try:
-        for mode, corr in (("f32", "bf16x3"), ("bf16x3", "bf16x3"), ("bf16", "bf16x3")):
+        for mode, corr in (("f32", "bf16x3"), ("bf16x3", "bf16x3"), ("bf16", "bf16" if h == 720 else "bf16x3")):
             net.precision, net.corr_precision = mode, corr
             with torch.no_grad():
                 outs[mode] = net(x).cpu()
@@ -238,5 +240,5 @@ def test_forward_bsd_size_modes_agree(net):
     assert all(torch.isfinite(o).all() for o in outs.values())
     e3 = (outs["bf16x3"] - outs["f32"]).abs().max().item()
     e1 = (outs["bf16"] - outs["f32"]).abs().max().item()
-    print(f"480x640: max |bf16x3 - f32| {e3:.2e}, max |bf16 - f32| {e1:.2e}")
-    assert e3 < 1e-3 and e1 < 0.05
+    print(f"{h}x{w}: max |bf16x3 - f32| {e3:.2e}, max |bf16 - f32| {e1:.2e}")
+    assert e3 < (1e-3 if h < 720 else 2e-3) and e1 < 0.05      # 720p: the max is over 2.8 M values (9.3e-4 measured)
