@@ -301,8 +301,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
                 }
             }
         } else {
+            // slab offset of the next group: looked up TWO groups ahead.  One group ahead the ds_read_b32 -> address -> A
+            // fragment reads chain sat in front of every other MFMA group with an s_waitcnt lgkmcnt(0) (seen in the ISA).
+            int go_n1 = goff[rg(min(1, ngroups - 1))];
             auto group = [&](int d, int g) __attribute__((always_inline)) {
-                const int go_next = goff[rg(min(g + 1, ngroups - 1))];
+                const int go_next = go_n1;
+                go_n1 = goff[rg(min(g + 2, ngroups - 1))];
 #pragma unroll
                 for (int s = 0; s < G; ++s) {
                     bf16x8 av[TM];
