@@ -6,9 +6,10 @@
 //   g2[w][c]  = BN(conv5x5([max_h x1, mean_h x1]))   on the (C, W) plane, zero pad 2, no sigmoid
 //   out       = x + (x1*s + (x1*g1 + x1*g2))
 //
-// Three global reductions force a grid-wide dependency, so the gates take three small launches
-// (tile stats -> combine partials -> gate maps + SE) and the application one elementwise launch.  All partial sums are
-// combined in a fixed order: results are bitwise reproducible run to run.
+// Three global reductions force a grid-wide dependency, so the gates take two launches (tile statistics; then the gate
+// maps + SE, whose blocks first combine the tile partials of the rows / columns they need, 7x7 / 5x5 halo included) and
+// the application one elementwise launch.  All partial sums are combined in a fixed order: results are bitwise
+// reproducible run to run.
 #include "common.h"
 
 namespace {
@@ -22,10 +23,7 @@ struct GateWs {
     float* rowpsum;  // [ntx][H][C]
     float* colpmax;  // [nty][W][C]
     float* colpsum;  // [nty][W][C]
-    float* rowmax;   // [H][C]
-    float* rowmean;  // [H][C]
-    float* colmax;   // [W][C]
-    float* colmean;  // [W][C]
+    float* tilesum;  // [nty*ntx][C]  per-tile channel sums (for the SE mean)
     int ntx, nty;
 };
 __host__ __device__ inline GateWs carve(float* ws, int H, int W, int C) {
@@ -37,10 +35,7 @@ __host__ __device__ inline GateWs carve(float* ws, int H, int W, int C) {
     g.rowpsum = g.rowpmax + (size_t)g.ntx * H * C;
     g.colpmax = g.rowpsum + (size_t)g.ntx * H * C;
     g.colpsum = g.colpmax + (size_t)g.nty * W * C;
-    g.rowmax = g.colpsum + (size_t)g.nty * W * C;
-    g.rowmean = g.rowmax + (size_t)H * C;
-    g.colmax = g.rowmean + (size_t)H * C;
-    g.colmean = g.colmax + (size_t)W * C;
+    g.tilesum = g.colpsum + (size_t)g.nty * W * C;
     return g;
 }
 
@@ -58,9 +53,6 @@ __device__ __forceinline__ f32x4 ld4<__bf16>(const __bf16* p) {
 __device__ __forceinline__ f32x4 max4(f32x4 a, f32x4 b) {
     return f32x4{fmaxf(a[0], b[0]), fmaxf(a[1], b[1]), fmaxf(a[2], b[2]), fmaxf(a[3], b[3])};
 }
-__device__ __forceinline__ f32x4 shfl4(f32x4 v, int mask) {
-    return f32x4{__shfl_xor(v[0], mask, 64), __shfl_xor(v[1], mask, 64), __shfl_xor(v[2], mask, 64), __shfl_xor(v[3], mask, 64)};
-}
 
 // ---- launch 1: tile statistics -----------------------------------------------------------------------------
 template <int C, typename TX>
@@ -69,6 +61,7 @@ __global__ __launch_bounds__(256) void gate_stats_kernel(const TX* __restrict__ 
     constexpr int T = 1024 / C;          // tile rows == tile columns
     constexpr int PLW = 64 / CQ;         // tile columns held by one wave
     __shared__ f32x4 smax[T][4][CQ], ssum[T][4][CQ];
+    __shared__ f32x4 stot[4][CQ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cq = tid % CQ, pl = tid / CQ;
     const int tx = blockIdx.x % g.ntx, ty = blockIdx.x / g.ntx;
@@ -102,7 +95,21 @@ __global__ __launch_bounds__(256) void gate_stats_kernel(const TX* __restrict__ 
         *reinterpret_cast<f32x4*>(g.colpmax + ((size_t)ty * W + x) * C + cq * 4) = cmax;
         *reinterpret_cast<f32x4*>(g.colpsum + ((size_t)ty * W + x) * C + cq * 4) = csum;
     }
+    {   // tile total per channel: the column sums of this wave's columns, then the four waves (fixed order)
+        f32x4 tsum = xok ? csum : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (CQ <= 8) tsum[e] = xor_combine<8, OpSum>(tsum[e]);
+            if constexpr (CQ <= 16) tsum[e] = xor_combine<16, OpSum>(tsum[e]);
+            tsum[e] = xor_combine<32, OpSum>(tsum[e]);
+        }
+        if (lane < CQ) stot[wave][cq] = tsum;
+    }
     __syncthreads();
+    if (tid < CQ) {
+        const f32x4 t = (stot[0][tid] + stot[1][tid]) + (stot[2][tid] + stot[3][tid]);
+        *reinterpret_cast<f32x4*>(g.tilesum + (size_t)blockIdx.x * C + tid * 4) = t;
+    }
     for (int i = tid; i < T * CQ; i += 256) {
         const int k = i / CQ, q = i - k * CQ;
         const int y = y0 + k;
@@ -120,31 +127,45 @@ __global__ __launch_bounds__(256) void gate_stats_kernel(const TX* __restrict__ 
     (void)PLW;
 }
 
-// ---- launch 2: combine the tile partials -> row / column statistics ---------------------------------------------
-__global__ __launch_bounds__(256) void gate_reduce_kernel(int H, int W, int C, GateWs g) {
-    const int64_t nrow = (int64_t)H * C, ncol = (int64_t)W * C;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < nrow) {
-        float mx = -INFINITY, sm = 0.f;
-        for (int k = 0; k < g.ntx; ++k) {
-            mx = fmaxf(mx, g.rowpmax[(size_t)k * nrow + i]);
-            sm += g.rowpsum[(size_t)k * nrow + i];
+// Reduce the `nt` tile partials of `cnt` rows (or columns) starting at line `l0` (lines outside [0, L) give -inf / 0) into
+// zmax / zmean in LDS.  A thread owns up to 4 (line, channel) items and walks the tiles with all of them in flight: the
+// loads of one step are independent, only the per-item max / sum chains are serial (fixed tile order => reproducible).
+__device__ __forceinline__ void reduce_partials(const float* __restrict__ pmax, const float* __restrict__ psum, int nt, int64_t stride,
+                                                int l0, int cnt, int L, int C, float, float denom, float* zmax, float* zmean) {
+    float mx[4], sm[4];
+    int64_t off[4];
+    bool ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int it = threadIdx.x + 256 * j;
+        const int line = l0 + it / C;
+        ok[j] = it < cnt * C && line >= 0 && line < L;
+        off[j] = ok[j] ? (int64_t)line * C + it % C : 0;
+        mx[j] = -INFINITY;
+        sm[j] = 0.f;
+    }
+    for (int k = 0; k < nt; ++k) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = pmax[(size_t)k * stride + off[j]], b = psum[(size_t)k * stride + off[j]];     // clamped address when !ok
+            mx[j] = fmaxf(mx[j], a);
+            sm[j] += b;
         }
-        g.rowmax[i] = mx;
-        g.rowmean[i] = sm / (float)W;
-    } else if (i < nrow + ncol) {
-        const int64_t j = i - nrow;
-        float mx = -INFINITY, sm = 0.f;
-        for (int k = 0; k < g.nty; ++k) {
-            mx = fmaxf(mx, g.colpmax[(size_t)k * ncol + j]);
-            sm += g.colpsum[(size_t)k * ncol + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int it = threadIdx.x + 256 * j;
+        if (it < cnt * C) {
+            zmax[it] = ok[j] ? mx[j] : -INFINITY;
+            zmean[it] = ok[j] ? sm[j] / denom : 0.f;
         }
-        g.colmax[j] = mx;
-        g.colmean[j] = sm / (float)H;
     }
 }
 
-// ---- launch 3: the two 2->1 channel convolutions + eval BatchNorm(1); last block = SE vector ---------------------
+// ---- launch 2: combine the tile partials, then the two 2->1 channel convolutions + eval BatchNorm(1); last block = SE ----
+// A block owns 256 consecutive (row, channel) or (column, channel) outputs; it first reduces the tile partials of every
+// row / column its 7x7 / 5x5 window touches into LDS (the reduction used to be a launch of its own: ~13 us of a tiny grid
+// on the critical chain of every ResBlock), in the same fixed order over the tiles.
 __global__ __launch_bounds__(256) void gate_maps_kernel(int H, int W, int C, GateWs g, const float* __restrict__ cw_w,
                                                         const float* __restrict__ cw_bn, const float* __restrict__ hc_w,
                                                         const float* __restrict__ hc_bn, float* __restrict__ g1,
@@ -152,28 +173,34 @@ __global__ __launch_bounds__(256) void gate_maps_kernel(int H, int W, int C, Gat
                                                         const float* __restrict__ b1, const float* __restrict__ w2,
                                                         const float* __restrict__ b2, float* __restrict__ s) {
     __shared__ float wk[98];
+    __shared__ float zmax[1024], zmean[1024];          // (256/C + 6) * C <= 1024 reduced rows / columns incl. halo
     const int64_t n1 = (int64_t)H * C;
     const int nb1 = (int)((n1 + 255) / 256);
     const int nb2 = (int)(((int64_t)W * C + 255) / 256);
     if ((int)blockIdx.x == nb1 + nb2) {
-        __shared__ float mean[128], hid[32];
+        // SE: channel means from the per-tile sums.  thread = (channel quad, part): 1024 / C interleaved tile subsets, eight
+        // independent 16-byte loads in flight per thread (one block walks ~900 tiles: latency, not bandwidth, is the cost)
         __shared__ f32x4 part[256];
-        // rowmean is [H][C]; 1024 % C == 0, so float4 index t + 256*k always covers the same 4 channels for thread t
-        const int n4 = H * C / 4;
-        f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-        const f32x4* rm = reinterpret_cast<const f32x4*>(g.rowmean);
-        int i = threadIdx.x;
-        for (; i + 768 < n4; i += 1024) {
-            s0 += rm[i]; s1 += rm[i + 256]; s2 += rm[i + 512]; s3 += rm[i + 768];
+        __shared__ float mean[128], hid[32];
+        const int ntiles = g.ntx * g.nty, cq = C / 4, parts = 256 / cq;
+        const int q = threadIdx.x % cq, pt = threadIdx.x / cq;
+        const f32x4* ts = reinterpret_cast<const f32x4*>(g.tilesum) + q;
+        f32x4 acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int t = pt;
+        for (; t + 7 * parts < ntiles; t += 8 * parts) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += ts[(size_t)(t + u * parts) * cq];
         }
-        for (; i < n4; i += 256) s0 += rm[i];
-        part[threadIdx.x] = (s0 + s1) + (s2 + s3);
+        for (; t < ntiles; t += parts) acc[0] += ts[(size_t)t * cq];
+        part[threadIdx.x] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
         __syncthreads();
         if ((int)threadIdx.x < C) {
-            const int c = threadIdx.x, q = c >> 2, e = c & 3, nq = C / 4;      // threads q, q+nq, q+2nq, ... share the quad
-            float sm = 0.f;
-            for (int t = q; t < 256; t += nq) sm += part[t][e];
-            mean[c] = sm / (float)H;
+            const int c = threadIdx.x;
+            float a = 0.f;
+            for (int k = 0; k < parts; ++k) a += part[k * cq + (c >> 2)][c & 3];
+            mean[c] = a / ((float)H * (float)W);
         }
         __syncthreads();
         const int mid = C / 4;
@@ -192,44 +219,51 @@ __global__ __launch_bounds__(256) void gate_maps_kernel(int H, int W, int C, Gat
     }
     if ((int)blockIdx.x < nb1) {
         if (threadIdx.x < 98) wk[threadIdx.x] = cw_w[threadIdx.x];
+        const int64_t i0 = (int64_t)blockIdx.x * 256;
+        const int y0 = (int)(i0 / C) - 3, rows = 256 / C + 6;           // 256 % C == 0: the block covers whole rows
+        reduce_partials(g.rowpmax, g.rowpsum, g.ntx, n1, y0, rows, H, C, 1.0f, (float)W, zmax, zmean);
         __syncthreads();
-        const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        const int64_t i = i0 + threadIdx.x;
         if (i >= n1) return;
         const int c = (int)(i % C), y = (int)(i / C);
         float acc = 0.f;
         // conv "height" axis = H, "width" axis = C  (x.permute(0,3,2,1) -> [B,W,H,C], ZPool over dim 1)
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
-            const float* z = ch == 0 ? g.rowmax : g.rowmean;
+            const float* z = ch == 0 ? zmax : zmean;
             for (int dy = 0; dy < 7; ++dy) {
                 const int yy = y + dy - 3;
                 if (yy < 0 || yy >= H) continue;
                 for (int dc = 0; dc < 7; ++dc) {
                     const int cc = c + dc - 3;
                     if (cc < 0 || cc >= C) continue;
-                    acc = fmaf(wk[ch * 49 + dy * 7 + dc], z[(size_t)yy * C + cc], acc);
+                    acc = fmaf(wk[ch * 49 + dy * 7 + dc], z[(yy - y0) * C + cc], acc);
                 }
             }
         }
         g1[i] = fmaf(acc, cw_bn[0], cw_bn[1]);
     } else {
         if (threadIdx.x < 50) wk[threadIdx.x] = hc_w[threadIdx.x];
+        const int64_t n2 = (int64_t)W * C;
+        const int64_t i0 = (int64_t)(blockIdx.x - nb1) * 256;
+        const int x0 = (int)(i0 / C) - 2, cols = 256 / C + 4;
+        reduce_partials(g.colpmax, g.colpsum, g.nty, n2, x0, cols, W, C, 1.0f, (float)H, zmax, zmean);
         __syncthreads();
-        const int64_t i = (int64_t)(blockIdx.x - nb1) * 256 + threadIdx.x;
-        if (i >= (int64_t)W * C) return;
+        const int64_t i = i0 + threadIdx.x;
+        if (i >= n2) return;
         const int c = (int)(i % C), x = (int)(i / C);
         float acc = 0.f;
         // conv "height" axis = C, "width" axis = W  (x.permute(0,2,1,3) -> [B,H,C,W], ZPool over dim 1)
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
-            const float* z = ch == 0 ? g.colmax : g.colmean;
+            const float* z = ch == 0 ? zmax : zmean;
             for (int dc = 0; dc < 5; ++dc) {
                 const int cc = c + dc - 2;
                 if (cc < 0 || cc >= C) continue;
                 for (int dx = 0; dx < 5; ++dx) {
                     const int xx = x + dx - 2;
                     if (xx < 0 || xx >= W) continue;
-                    acc = fmaf(wk[ch * 25 + dc * 5 + dx], z[(size_t)xx * C + cc], acc);
+                    acc = fmaf(wk[ch * 25 + dc * 5 + dx], z[(xx - x0) * C + cc], acc);
                 }
             }
         }
@@ -275,7 +309,7 @@ extern "C" int64_t spei_gate_ws_floats(int H, int W, int C) {
     if (C != 32 && C != 64 && C != 128) return 0;
     const int T = 1024 / C;
     const int64_t ntx = (W + T - 1) / T, nty = (H + T - 1) / T;
-    return 2 * ntx * H * C + 2 * nty * W * C + 2 * (int64_t)H * C + 2 * (int64_t)W * C;
+    return 2 * ntx * H * C + 2 * nty * W * C + ntx * nty * C;
 }
 
 extern "C" int spei_resblock_gates(const void* x1, int x1_bf16, int H, int W, int C, const float* se_w1, const float* se_b1,
@@ -301,7 +335,6 @@ extern "C" int spei_resblock_gates(const void* x1, int x1_bf16, int H, int W, in
         else if (C == 64) hipLaunchKernelGGL((gate_stats_kernel<64, float>), grid1, dim3(256), 0, st, xp, H, W, g);
         else hipLaunchKernelGGL((gate_stats_kernel<128, float>), grid1, dim3(256), 0, st, xp, H, W, g);
     }
-    hipLaunchKernelGGL(gate_reduce_kernel, dim3(cdiv((int64_t)(H + W) * C, 256)), dim3(256), 0, st, H, W, C, g);
     hipLaunchKernelGGL(gate_maps_kernel, dim3(cdiv((int64_t)H * C, 256) + cdiv((int64_t)W * C, 256) + 1), dim3(256), 0, st, H, W, C, g,
                        cw_w, cw_bn, hc_w, hc_bn, g1, g2, se_w1, se_b1, se_w2, se_b2, s);
     SPEI_CHECK_LAUNCH("spei_resblock_gates");
