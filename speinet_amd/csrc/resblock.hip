@@ -18,6 +18,8 @@ namespace {
 // thread = (channel quad cq, tile column pl).  Column partials accumulate in registers down the tile's rows; row
 // partials are reduced across the tile's columns with wave shuffles + a small LDS combine.  Every level launches
 // ~900 blocks (C*pixels is constant), so the pass streams at HBM rate instead of one row per block.
+constexpr int GATE_NCOL = 2;     // pixel columns per thread of the statistics pass: tile = (1024/C) rows x (NCOL * 1024/C) columns
+
 struct GateWs {
     float* rowpmax;  // [ntx][H][C]
     float* rowpsum;  // [ntx][H][C]
@@ -29,7 +31,7 @@ struct GateWs {
 __host__ __device__ inline GateWs carve(float* ws, int H, int W, int C) {
     GateWs g;
     const int T = 1024 / C;
-    g.ntx = (W + T - 1) / T;
+    g.ntx = (W + GATE_NCOL * T - 1) / (GATE_NCOL * T);
     g.nty = (H + T - 1) / T;
     g.rowpmax = ws;
     g.rowpsum = g.rowpmax + (size_t)g.ntx * H * C;
@@ -65,18 +67,27 @@ __global__ __launch_bounds__(256) void gate_stats_kernel(const TX* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cq = tid % CQ, pl = tid / CQ;
     const int tx = blockIdx.x % g.ntx, ty = blockIdx.x / g.ntx;
-    const int x = tx * T + pl, y0 = ty * T;
-    const bool xok = x < W;
-    f32x4 cmax = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY}, csum = f32x4{0.f, 0.f, 0.f, 0.f};
+    // a thread owns NCOL pixel columns (x0 + j*T): NCOL independent loads per row, and the cross-lane row reduction below
+    // is paid once per NCOL pixels
+    const int x0 = tx * (T * GATE_NCOL) + pl, y0 = ty * T;
+    const f32x4 ninf = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY}, zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 cmax[GATE_NCOL], csum[GATE_NCOL];
+#pragma unroll
+    for (int j = 0; j < GATE_NCOL; ++j) { cmax[j] = ninf; csum[j] = zero; }
 #pragma unroll 4
     for (int k = 0; k < T; ++k) {
         const int y = y0 + k;
-        f32x4 vmax = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY}, vsum = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (xok && y < H) {
-            vsum = ld4<TX>(x1 + ((size_t)y * W + x) * C + cq * 4);
-            vmax = vsum;
-            cmax = max4(cmax, vmax);
-            csum += vsum;
+        f32x4 vmax = ninf, vsum = zero;
+#pragma unroll
+        for (int j = 0; j < GATE_NCOL; ++j) {
+            const int x = x0 + j * T;
+            if (x < W && y < H) {
+                const f32x4 v = ld4<TX>(x1 + ((size_t)y * W + x) * C + cq * 4);
+                cmax[j] = max4(cmax[j], v);
+                csum[j] += v;
+                vmax = max4(vmax, v);
+                vsum += v;
+            }
         }
         // reduce over the PLW columns of this wave (lanes cq + CQ*j), fixed order => reproducible; VALU-only butterflies
 #pragma unroll
@@ -91,12 +102,17 @@ __global__ __launch_bounds__(256) void gate_stats_kernel(const TX* __restrict__ 
             ssum[k][wave][cq] = vsum;
         }
     }
-    if (xok) {
-        *reinterpret_cast<f32x4*>(g.colpmax + ((size_t)ty * W + x) * C + cq * 4) = cmax;
-        *reinterpret_cast<f32x4*>(g.colpsum + ((size_t)ty * W + x) * C + cq * 4) = csum;
+    f32x4 tsum = zero;
+#pragma unroll
+    for (int j = 0; j < GATE_NCOL; ++j) {
+        const int x = x0 + j * T;
+        if (x < W) {
+            *reinterpret_cast<f32x4*>(g.colpmax + ((size_t)ty * W + x) * C + cq * 4) = cmax[j];
+            *reinterpret_cast<f32x4*>(g.colpsum + ((size_t)ty * W + x) * C + cq * 4) = csum[j];
+            tsum += csum[j];
+        }
     }
     {   // tile total per channel: the column sums of this wave's columns, then the four waves (fixed order)
-        f32x4 tsum = xok ? csum : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if constexpr (CQ <= 8) tsum[e] = xor_combine<8, OpSum>(tsum[e]);
@@ -308,7 +324,7 @@ __global__ __launch_bounds__(256) void resblock_apply_kernel(const float* __rest
 extern "C" int64_t spei_gate_ws_floats(int H, int W, int C) {
     if (C != 32 && C != 64 && C != 128) return 0;
     const int T = 1024 / C;
-    const int64_t ntx = (W + T - 1) / T, nty = (H + T - 1) / T;
+    const int64_t ntx = (W + GATE_NCOL * T - 1) / (GATE_NCOL * T), nty = (H + T - 1) / T;
     return 2 * ntx * H * C + 2 * nty * W * C + ntx * nty * C;
 }
 
