@@ -270,37 +270,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
             }
         };
         int go = goff[rg(0)];
-        if constexpr (!SPLIT) load_a(go);
-        if constexpr (SPLIT) {
-            // split mode keeps the plain loop (the pipelined form produced wrong lanes there; not yet understood)
-            for (int g0 = 0; g0 < ngroups; g0 += RING) {
-#pragma unroll
-                for (int d = 0; d < RING; ++d) {
-                    const int g = g0 + d;
-                    if (g < ngroups) {
-                        const int gs = goff[rg(g)];
-#pragma unroll
-                        for (int s = 0; s < G; ++s) {
-                            bf16x8 av[TM], avl[TM];
-#pragma unroll
-                            for (int i = 0; i < TM; ++i) {
-                                av[i] = *reinterpret_cast<const bf16x8*>(slab + abase[i] + gs + s * 32);
-                                avl[i] = *reinterpret_cast<const bf16x8*>(slab + p.slab_bytes + abase[i] + gs + s * 32);
-                            }
-#pragma unroll
-                            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                                for (int j = 0; j < TN; ++j) {
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avl[i], bring[d][s][j], acc[i][j], 0, 0, 0);
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bring_lo[SPLIT ? d : 0][s][j], acc[i][j], 0, 0, 0);
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bring[d][s][j], acc[i][j], 0, 0, 0);
-                                }
-                        }
-                        if (g + RING < ngroups) load_b(d, rg(g + RING));
-                    }
-                }
-            }
-        } else {
+        load_a(go);
+        {
             // slab offset of the next group: looked up TWO groups ahead.  One group ahead the ds_read_b32 -> address -> A
             // fragment reads chain sat in front of every other MFMA group with an s_waitcnt lgkmcnt(0) (seen in the ISA).
             int go_n1 = goff[rg(min(1, ngroups - 1))];
@@ -309,15 +280,23 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
                 go_n1 = goff[rg(min(g + 2, ngroups - 1))];
 #pragma unroll
                 for (int s = 0; s < G; ++s) {
-                    bf16x8 av[TM];
+                    bf16x8 av[TM], avl[SPLIT ? TM : 1];
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) av[i] = an[i];
+                    for (int i = 0; i < TM; ++i) {
+                        av[i] = an[i];
+                        if (SPLIT) avl[i] = anl[i];
+                    }
                     load_a(s + 1 < G ? go + (s + 1) * 32 : go_next);     // (the very last prefetch is a harmless re-read)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
+                        for (int j = 0; j < TN; ++j) {
+                            if (SPLIT) {
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avl[i], bring[d][s][j], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bring_lo[SPLIT ? d : 0][s][j], acc[i][j], 0, 0, 0);
+                            }
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bring[d][s][j], acc[i][j], 0, 0, 0);
+                        }
                     __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
                 }
