@@ -96,65 +96,86 @@ extern "C" int spei_rl_prior(const float* img, float* out, float* scratch, int C
 
 // ------------------------------------------------------------------------------------------------
 // first conv: 5x5 pad 2, 3 NCHW planes -> NHWC [H][W][32], bias + ReLU  (model/recons_video_ori.py:28-32)
-// 16x16 pixel tile; thread = one pixel x 32 output channels; input halo and the 75x32 weights live in LDS
-// (weight reads are wave-uniform broadcasts).
+// An implicit GEMM on the f32 matrix pipe (v_mfma_f32_32x32x2_f32, exact fp32 products and accumulation): M = pixels,
+// N = 32, K = 75 (tap, channel) padded to 76.  8 x 32 pixel tile per 256-thread workgroup, a wave owns two tile rows;
+// the input halo (3 planes) sits in LDS, the A operand of k-step kk is ONE ds_read_b32 per lane at a per-lane
+// precomputed (channel, dy, dx) offset, the 38 B operands (the whole 75 x 32 weight matrix) stay in registers.
+// As 75 x 32 VALU FMAs per pixel this layer was bound by the vector ALU at 96 us per 720p frame (7 per frame).
 // ------------------------------------------------------------------------------------------------
-constexpr int CI_T = 16;
+constexpr int CI_TH = 8, CI_TW = 32, CI_P = CI_TW + 4 + 1;     // tile, LDS row pitch (floats)
 __global__ __launch_bounds__(256) void conv5_in_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ out,
-                                                       int H, int W) {
-    __shared__ float tin[3][CI_T + 4][CI_T + 4 + 1];
-    __shared__ __attribute__((aligned(16))) float wl[75][32];   // [tap*3+ci][co]
-    __shared__ float bl[32];
-    const int x0 = blockIdx.x * CI_T, y0 = blockIdx.y * CI_T;
-    for (int i = threadIdx.x; i < 3 * (CI_T + 4) * (CI_T + 4); i += 256) {
-        const int c = i / ((CI_T + 4) * (CI_T + 4));
-        const int r = i - c * (CI_T + 4) * (CI_T + 4);
-        const int ly = r / (CI_T + 4), lx = r - ly * (CI_T + 4);
-        const int gy = y0 + ly - 2, gx = x0 + lx - 2;
-        tin[c][ly][lx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[((size_t)c * H + gy) * W + gx] : 0.0f;
+                                                       int H, int W, int tiles_x, int ntiles) {
+    __shared__ float tin[3 * (CI_TH + 4) * CI_P];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fk = lane >> 5;
+    // per-lane constants: k = 2 kk + fk -> (tap, ci); packed weights are [tap][co][ci].  The workgroup is persistent (it
+    // walks tiles blockIdx.x, + gridDim.x, ...) so that this 38-load gather is paid once, not per tile.
+    int koff[38];
+    float bw[38];
+#pragma unroll
+    for (int kk = 0; kk < 38; ++kk) {
+        const int k = 2 * kk + fk;
+        const int t = k / 3, ci = k - 3 * t;
+        const int dy = t / 5, dx = t - 5 * dy;
+        koff[kk] = k < 75 ? (ci * (CI_TH + 4) + dy) * CI_P + dx : 0;
+        bw[kk] = k < 75 ? w[(t * 32 + fr) * 3 + ci] : 0.0f;
     }
-    // packed weights are [tap][co][ci]; transpose to [tap*3+ci][co]
-    for (int i = threadIdx.x; i < 75 * 32; i += 256) {
-        const int t = i / 96, r = i - t * 96, co = r / 3, ci = r - co * 3;
-        wl[t * 3 + ci][co] = w[i];
-    }
-    if (threadIdx.x < 32) bl[threadIdx.x] = bias[threadIdx.x];
-    __syncthreads();
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-    const int gy = y0 + ly, gx = x0 + lx;
-    float acc[32];
+    const float bv = bias[fr];
+    const float* a0 = tin + (wave * 2) * CI_P + fr;
+    const int et = fr & 3, ecol = (fr >> 2) * 4;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int x0 = tx * CI_TW, y0 = ty * CI_TH;
+        for (int i = tid; i < 3 * (CI_TH + 4) * (CI_TW + 4); i += 256) {
+            const int c = i / ((CI_TH + 4) * (CI_TW + 4));
+            const int r = i - c * (CI_TH + 4) * (CI_TW + 4);
+            const int ly = r / (CI_TW + 4), lx = r - ly * (CI_TW + 4);
+            const int gy = y0 + ly - 2, gx = x0 + lx - 2;
+            tin[(c * (CI_TH + 4) + ly) * CI_P + lx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[((size_t)c * H + gy) * W + gx] : 0.0f;
+        }
+        __syncthreads();
+        // all 76 A operands are requested from LDS before the first MFMA
+        float av[2][38];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) acc[c] = bl[c];
-    for (int t = 0; t < 25; ++t) {
-        const int dy = t / 5, dx = t - dy * 5;
+        for (int kk = 0; kk < 38; ++kk) {
+            av[0][kk] = a0[koff[kk]];
+            av[1][kk] = a0[koff[kk] + CI_P];
+        }
+        __syncthreads();                                  // the tile may be overwritten by the next iteration's staging
+        f32x16 acc[2];
 #pragma unroll
-        for (int ci = 0; ci < 3; ++ci) {
-            const float v = tin[ci][ly + dy][lx + dx];
-            const float4* wr = reinterpret_cast<const float4*>(wl[t * 3 + ci]);
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float4 ww = wr[q];
-                acc[q * 4 + 0] = fmaf(v, ww.x, acc[q * 4 + 0]);
-                acc[q * 4 + 1] = fmaf(v, ww.y, acc[q * 4 + 1]);
-                acc[q * 4 + 2] = fmaf(v, ww.z, acc[q * 4 + 2]);
-                acc[q * 4 + 3] = fmaf(v, ww.w, acc[q * 4 + 3]);
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 38; ++kk) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][kk], bw[kk], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][kk], bw[kk], acc[1], 0, 0, 0);
+        }
+        // accumulator: column (channel) fr, rows (pixels) (r&3) + 8*(r>>2) + 4*fk; 4x4 quad transpose -> 16-byte stores
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int gy = y0 + wave * 2 + i;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float a[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = fmaxf(acc[i][4 * k + e] + bv, 0.f);
+                quad_transpose4(a[0], a[1], a[2], a[3], et);
+                const int gx = x0 + 8 * k + 4 * fk + et;
+                if (gy < H && gx < W) *reinterpret_cast<f32x4*>(out + ((size_t)gy * W + gx) * 32 + ecol) = f32x4{a[0], a[1], a[2], a[3]};
             }
         }
-    }
-    if (gy < H && gx < W) {
-        float4* o = reinterpret_cast<float4*>(out + ((size_t)gy * W + gx) * 32);
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            o[q] = make_float4(fmaxf(acc[q * 4], 0.f), fmaxf(acc[q * 4 + 1], 0.f), fmaxf(acc[q * 4 + 2], 0.f), fmaxf(acc[q * 4 + 3], 0.f));
     }
 }
 extern "C" int spei_conv5_in(const float* img_chw, const float* w, const float* bias, float* out_hwc, int H, int W,
                              int Cout, spei_stream_t stream) {
     SPEI_REQUIRE(img_chw && w && bias && out_hwc && H > 0 && W > 0, "spei_conv5_in: bad arguments");
     SPEI_REQUIRE(Cout == 32, "spei_conv5_in: Cout=%d (only n_feat=32 is built)", Cout);
-    hipLaunchKernelGGL(conv5_in_kernel, dim3(cdiv(W, CI_T), cdiv(H, CI_T)), dim3(256), 0, (hipStream_t)stream,
-                       img_chw, w, bias, out_hwc, H, W);
+    const int tiles_x = cdiv(W, CI_TW), ntiles = tiles_x * cdiv(H, CI_TH);
+    hipLaunchKernelGGL(conv5_in_kernel, dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, (hipStream_t)stream,
+                       img_chw, w, bias, out_hwc, H, W, tiles_x, ntiles);
     SPEI_CHECK_LAUNCH("spei_conv5_in");
     return 0;
 }
