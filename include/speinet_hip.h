@@ -90,6 +90,14 @@ int spei_conv_slab_bf16(const void* a0, int lda0, int k0, const void* a1, int ld
 int spei_mlp_fused_bf16(const float* x, float* out, const void* w1_frag, const float* b1, const void* w2_frag,
                         const float* b2, int64_t M, spei_stream_t stream);
 
+/* ConvTranspose2d(k = 3, stride 2, padding 1, output_padding 1) on the slab kernel (reference model/recons_video_ori.py:58-71,
+ * the tails of decoder_second / decoder_first): the four output-parity classes are stride-1 convolutions over the input
+ * grid with 1 / 2 / 2 / 4 taps, written with pixel stride 2.  wfrag<py><px>: fragment-ordered bf16 weights of class
+ * (oy % 2, ox % 2) (speinet_amd/pack.py).  a0 [Hin*Win][lda0] fp32 or bf16, out [2Hin*2Win][ldo] fp32 or bf16. */
+int spei_convt2_slab_bf16(const void* a0, int lda0, int k0, int a_bf16, const void* wfrag00, const void* wfrag01,
+                          const void* wfrag10, const void* wfrag11, const float* bias, void* out, int ldo, int out_bf16,
+                          int Hin, int Win, int N, int act, spei_stream_t stream);
+
 /* Fused attention branch of a Swin block (model/swinir.py:238-278 + :115-149): out = x + proj(W-MSA(q = yhat Wq,
  * [k,v] = LayerNorm(x) Wkv)) with cyclic shift `shift`, 5x5 windows, 8 heads; x,out [H*W][256] fp32 (may alias), yhat
  * [H*W][256] bf16 (LayerNorm of y without affine); w*_frag in MFMA fragment order with the LayerNorm affine and the q

@@ -46,6 +46,11 @@ struct SlabParams {
     int iw_magic;            // ceil(2^20 / IW): pix / IW == (pix * iw_magic) >> 20 for pix < 2048
     int goff_bytes;          // bytes reserved for the group offset table (multiple of 16)
     int n_chunks;            // 32*WN*TN-column chunks looped inside the workgroup
+    // Tap list form (ntap > 0, used for the parity classes of a stride-2 transposed conv): the taps are the (dy, dx) >= 0
+    // offsets below instead of the ks x ks square, and output pixel (y, x) of the tile grid is written to pixel
+    // (y * o_mul + o_row_add, x * o_mul + o_col_add) of a map that is Wfull pixels wide.
+    int ntap, tap_dy[4], tap_dx[4];
+    int o_mul, o_row_add, o_col_add, Wfull;
     int ln;                  // 1: LayerNorm(256) without affine is applied to every input row while it is staged
                              //    (fp32 input, K == 256: one wave-instruction loads exactly one token row)
     int dbg;                 // ablation switches for tools/ablate_slab.py (0 in production): 1 no staging loads,
@@ -105,7 +110,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
     const int oy0 = tile_y * p.TH, ox0 = tile_x * p.TW;
     const int ks16 = p.K / 16;
     const int kg_per_tap = ks16 / G;
-    const int ngroups = p.ks * p.ks * kg_per_tap;
+    const int T = p.ntap ? p.ntap : p.ks * p.ks;
+    const int ngroups = T * kg_per_tap;
     // every workgroup walks the (tap, K group) sequence from a different start: otherwise all CUs stream the same weight
     // fragment from the same L2 channel at the same time
     const int rot = (blockIdx.x * 7) % ngroups;
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
     // ---- group -> slab byte offset table ------------------------------------------------------------
     for (int g = tid; g < ngroups; g += NT) {
         const int t = g / kg_per_tap, kg = g - t * kg_per_tap;
-        const int ty = t / p.ks, tx = t - ty * p.ks;
+        const int ty = p.ntap ? p.tap_dy[t] : t / p.ks, tx = p.ntap ? p.tap_dx[t] : t - (t / p.ks) * p.ks;
         goff[g] = (ty * p.IW + tx) * pitch + kg * (G * 32);
     }
 
@@ -193,7 +199,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
         const int py = pt >> p.tw_shift, px = pt - (py << p.tw_shift);
         abase[i] = ((py * p.stride) * p.IW + px * p.stride) * pitch + fk * 16;
     }
-    const int T = p.ks * p.ks;
     const size_t frag_per_nt = (size_t)T * ks16 * 64 * 8;        // bf16 elements per 32-column n-tile
     const __bf16* bptr[TN];
     const __bf16* bptr_lo[TN];
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
         const int pt0 = (wm * TM + i) * 32;
         if (p.tw_shift == 5) {
             const int oy = oy0 + (pt0 >> 5);
-            mbase[i] = oy * p.Wout + ox0;
+            mbase[i] = (oy * p.o_mul + p.o_row_add) * p.Wfull + ox0 * p.o_mul + p.o_col_add;
             qlim[i] = oy < p.Hout ? p.Wout - ox0 : 0;
         } else {
             mbase[i] = oy0 + pt0;
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
                     quad_transpose4(a[0], a[1], a[2], a[3], et);
                     const int q = 8 * k + 4 * fk_e + et;         // accumulator row (r&3) + 8*(r>>2) + 4*fk with r = 4k + et
                     if (q < qlim[i] && !(p.dbg & 4)) {
-                        const unsigned m = (unsigned)(mbase[i] + q);
+                        const unsigned m = (unsigned)(mbase[i] + q * p.o_mul);
                         f32x4 v = f32x4{a[0], a[1], a[2], a[3]};
                         if (p.rowscale) { const float rs = p.rowscale[m]; v *= rs; }
                         if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * (unsigned)p.ldr + ncol0 + ecol);
@@ -389,16 +394,24 @@ template <bool SPLIT, typename TA, typename TO>
 int dispatch(SlabParams& p, hipStream_t s) {
     const int pitch = 2 * p.K + 16;
     const int nparts = SPLIT ? 2 : 1;
-    const int T = p.ks * p.ks;
+    const int T = p.ntap ? p.ntap : p.ks * p.ks;
     const int ngroups = T * (p.K / 32);
-    const bool linear = (p.Wout == 1 && p.ks == 1);
+    const bool linear = (p.Wout == 1 && p.ks == 1 && !p.ntap);
+    int ext_y = p.ks, ext_x = p.ks;                           // slab extent beyond the (strided) tile
+    if (p.ntap) {
+        ext_y = ext_x = 1;
+        for (int t = 0; t < p.ntap; ++t) {
+            ext_y = p.tap_dy[t] + 1 > ext_y ? p.tap_dy[t] + 1 : ext_y;
+            ext_x = p.tap_dx[t] + 1 > ext_x ? p.tap_dx[t] + 1 : ext_x;
+        }
+    }
     constexpr int CH = sizeof(TA) == 4 ? 4 : 8;
     // tile rows x 32 pixels (2-D maps) or rows x 1 (token lists); pick the largest tile whose slab(s) fit ~96 KB
     auto setup = [&](int mtile) {
         if (linear) { p.TH = mtile; p.TW = 1; }
         else { p.TH = mtile / 32; p.TW = 32; }
-        p.IH = (p.TH - 1) * p.stride + p.ks;
-        p.IW = (p.TW - 1) * p.stride + p.ks;
+        p.IH = (p.TH - 1) * p.stride + ext_y;
+        p.IW = (p.TW - 1) * p.stride + ext_x;
         p.slab_bytes = ((p.IH * p.IW * pitch + 15) / 16) * 16;
         p.tiles_x = cdiv(p.Wout, p.TW);
         p.tw_shift = linear ? 0 : 5;
@@ -485,8 +498,46 @@ extern "C" int spei_conv_slab_bf16(const void* a0, int lda0, int k0, const void*
     p.ks = ksize; p.stride = stride; p.pad = pad; p.act = act;
     SPEI_REQUIRE(!ln_input || (!a_bf16 && k0 == 256 && k1 == 0 && ksize == 1), "spei_conv_slab_bf16: ln_input needs a 256-wide fp32 linear");
     p.ln = ln_input;
+    p.ntap = 0; p.o_mul = 1; p.o_row_add = 0; p.o_col_add = 0; p.Wfull = Wout;
     hipStream_t st = (hipStream_t)stream;
     if (wfrag_lo) return dispatch<true, float, float>(p, st);
     if (a_bf16) return out_bf16 ? dispatch<false, __bf16, __bf16>(p, st) : dispatch<false, __bf16, float>(p, st);
     return out_bf16 ? dispatch<false, float, __bf16>(p, st) : dispatch<false, float, float>(p, st);
+}
+
+extern "C" int spei_convt2_slab_bf16(const void* a0, int lda0, int k0, int a_bf16, const void* wfrag00, const void* wfrag01,
+                                     const void* wfrag10, const void* wfrag11, const float* bias, void* out, int ldo, int out_bf16,
+                                     int Hin, int Win, int N, int act, spei_stream_t stream) {
+    SPEI_REQUIRE(a0 && wfrag00 && wfrag01 && wfrag10 && wfrag11 && out, "spei_convt2_slab_bf16: null pointer");
+    SPEI_REQUIRE(k0 > 0 && k0 % 32 == 0 && N > 0 && N % 32 == 0, "spei_convt2_slab_bf16: K=%d N=%d must be multiples of 32", k0, N);
+    SPEI_REQUIRE(lda0 % (a_bf16 ? 8 : 4) == 0 && lda0 >= k0 && ldo >= N && ldo % 4 == 0, "spei_convt2_slab_bf16: bad row strides");
+    SPEI_REQUIRE(Hin > 0 && Win > 0 && (int64_t)Hin * Win * 4 * ldo < (1ll << 32), "spei_convt2_slab_bf16: bad map size");
+    SPEI_REQUIRE(((uintptr_t)a0 | (uintptr_t)out | (uintptr_t)wfrag00 | (uintptr_t)wfrag01 | (uintptr_t)wfrag10 | (uintptr_t)wfrag11) % 16 == 0,
+                 "spei_convt2_slab_bf16: operands must be 16-byte aligned");
+    const void* wf[2][2] = {{wfrag00, wfrag01}, {wfrag10, wfrag11}};
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            SlabParams p;
+            p.a0 = a0; p.a1 = nullptr; p.wh = (const __bf16*)wf[py][px]; p.wl = nullptr; p.bias = bias; p.out = out;
+            p.res = nullptr; p.rowscale = nullptr;
+            p.lda0 = lda0; p.lda1 = 0; p.k0 = k0; p.k1 = 0; p.ldo = ldo; p.ldr = 0;
+            p.N = N; p.K = k0;
+            p.Hin = Hin; p.Win = Win; p.Hout = Hin; p.Wout = Win;          // the tile grid is the input grid
+            p.ks = 1; p.stride = 1; p.pad = 0; p.act = act; p.ln = 0;
+            // out[2y+py][2x+px] = sum over (ky, kx) with in[y+dy][x+dx]: parity 0 -> k = 1 (d = 0); parity 1 -> k = 0 (d = 1), k = 2 (d = 0)
+            p.ntap = 0;
+            for (int iy = 0; iy < (py ? 2 : 1); ++iy)
+                for (int ix = 0; ix < (px ? 2 : 1); ++ix) {
+                    p.tap_dy[p.ntap] = py ? 1 - iy : 0;
+                    p.tap_dx[p.ntap] = px ? 1 - ix : 0;
+                    ++p.ntap;
+                }
+            p.o_mul = 2; p.o_row_add = py; p.o_col_add = px; p.Wfull = 2 * Win;
+            hipStream_t st = (hipStream_t)stream;
+            int rc;
+            if (a_bf16) rc = out_bf16 ? dispatch<false, __bf16, __bf16>(p, st) : dispatch<false, __bf16, float>(p, st);
+            else rc = out_bf16 ? dispatch<false, float, __bf16>(p, st) : dispatch<false, float, float>(p, st);
+            if (rc) return rc;
+        }
+    return 0;
 }

@@ -162,7 +162,8 @@ def igemm(a0: FMap, w: torch.Tensor, bias: Optional[torch.Tensor], N: int, ksize
     assert out.H == ho and out.W == wo and out.C == N
     k0, k1 = a0.C, (a1.C if a1 is not None else 0)
     slab = PRECISION != "f32" and USE_SLAB and mode == CONV
-    assert slab or not (a0.bf16 or out.bf16), "bf16 activations are only supported by the slab kernel"
+    assert slab or (mode == CONV_T and PRECISION == "bf16" and USE_SLAB) or not (a0.bf16 or out.bf16), \
+        "bf16 activations are only supported by the slab kernel"
     assert a1 is None or a1.bf16 == a0.bf16
     assert residual is None or not residual.bf16
     assert not ln_input or (slab and w.fhi is not None), "ln_input is a feature of the slab kernel"
@@ -179,7 +180,14 @@ def igemm(a0: FMap, w: torch.Tensor, bias: Optional[torch.Tensor], N: int, ksize
               residual.ld if residual is not None else 0, _tp(rowscale), a0.H, a0.W, ho, wo, N, ksize, stride, pad, mode, act,
               _stream())
     srcs = (_vp(a0.ptr), a0.ld, k0, _vp(a1.ptr if a1 is not None else 0), a1.ld if a1 is not None else 0, k1)
-    if PRECISION == "f32":
+    if (mode == CONV_T and PRECISION == "bf16" and USE_SLAB and ksize == 3 and stride == 2 and a1 is None and residual is None
+            and rowscale is None and N % 32 == 0 and k0 % 32 == 0):
+        # stride-2 transposed conv = four stride-1 convs (one per output parity) on the slab kernel
+        cf = w.convT_class_frags()
+        _lib.check(_lib.lib().spei_convt2_slab_bf16(_vp(a0.ptr), a0.ld, k0, int(a0.bf16), _tp(cf[(0, 0)]), _tp(cf[(0, 1)]), _tp(cf[(1, 0)]),
+                                                   _tp(cf[(1, 1)]), _tp(bias), _vp(out.ptr), out.ld, int(out.bf16), a0.H, a0.W, N, act,
+                                                   _stream()), "spei_convt2_slab_bf16")
+    elif PRECISION == "f32":
         _lib.check(_lib.lib().spei_igemm_f32(*srcs, _tp(w.f32), _tp(bias), *common), "spei_igemm_f32")
     elif slab and w.fhi is not None:
         dims = (a0.H * a0.W, 1, ho * wo, 1) if (ksize == 1 and stride == 1) else (a0.H, a0.W, ho, wo)

@@ -29,7 +29,7 @@ class GemmW:
 
 class PackedW:
     """Device copies of one GEMM weight: f32 for the exact path, bf16 hi / lo (= bf16(w - hi)) for the bf16 pipe."""
-    __slots__ = ("f32", "hi", "lo", "shape", "fhi", "flo")
+    __slots__ = ("f32", "hi", "lo", "shape", "fhi", "flo", "_ct")
 
     def __init__(self, t: torch.Tensor, device):
         self.f32 = t.detach().to(device=device, dtype=torch.float32).contiguous()
@@ -40,9 +40,30 @@ class PackedW:
         # (t, n, k) with k = 16*ks + 8*h + j  ->  one coalesced 1 KiB load per B fragment
         t, n, k = self.shape
         self.fhi = self.flo = None
+        self._ct = None
         if n % 32 == 0 and k % 32 == 0:
             frag = lambda w: w.view(t, n // 32, 32, k // 16, 2, 8).permute(1, 0, 3, 4, 2, 5).contiguous()
             self.fhi, self.flo = frag(self.hi), frag(self.lo)
+
+
+def _convT_class_frags(self) -> dict:
+    """Fragment-ordered weights of the four output-parity classes of a 3x3 stride-2 transposed conv (this pack holds
+    [ky*3+kx][Cout][Cin]): out[2y+py][2x+px] = sum_taps in[y+dy][x+dx] W[ky][kx] with parity 0 -> k = 1 (d = 0), parity
+    1 -> k = 0 (d = 1), k = 2 (d = 0) — the tap order spei_convt2_slab_bf16 assumes."""
+    if self._ct is None:
+        assert self.shape[0] == 9
+        ct = {}
+        for py in (0, 1):
+            for px in (0, 1):
+                kys, kxs = ([0, 2] if py else [1]), ([0, 2] if px else [1])
+                w = torch.stack([self.hi[ky * 3 + kx] for ky in kys for kx in kxs])
+                t, n, k = w.shape
+                ct[(py, px)] = w.view(t, n // 32, 32, k // 16, 2, 8).permute(1, 0, 3, 4, 2, 5).contiguous()
+        self._ct = ct
+    return self._ct
+
+
+PackedW.convT_class_frags = _convT_class_frags
 
 
 def conv_w(w: torch.Tensor) -> torch.Tensor:

@@ -81,6 +81,12 @@ def test_igemm_concat_transpose_epilogue(mode):
     ref = F.relu(F.conv_transpose2d(x, wtt, bt, stride=2, padding=1, output_padding=1))
     out = ops.igemm(fm(x), pack.convT_w(wtt).to(DEV), bt.to(DEV), 64, ksize=3, stride=2, mode=ops.CONV_T, act=ops.ACT_RELU)
     assert relerr(out.nchw(), ref) < TOL[mode]
+    # second decoder tail shape (64 -> 32), odd map, no activation; in "bf16" mode both run as four parity-class convs on the slab kernel
+    x = rnd(15, 1, 64, 21, 19)
+    wtt, bt = rnd(16, 64, 32, 3, 3, scale=0.05), rnd(17, 32, scale=0.1)
+    ref = F.conv_transpose2d(x, wtt, bt, stride=2, padding=1, output_padding=1)
+    out = ops.igemm(fm(x), pack.convT_w(wtt).to(DEV), bt.to(DEV), 32, ksize=3, stride=2, mode=ops.CONV_T)
+    assert relerr(out.nchw(), ref) < TOL[mode]
 
 
 @pytest.mark.parametrize("name", ["g07_search", "g07_search_tie"])
