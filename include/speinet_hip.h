@@ -98,6 +98,11 @@ int spei_convt2_slab_bf16(const void* a0, int lda0, int k0, int a_bf16, const vo
                           const void* wfrag10, const void* wfrag11, const float* bias, void* out, int ldo, int out_bf16,
                           int Hin, int Win, int N, int act, spei_stream_t stream);
 
+/* Last conv (model/recons_video_ori.py:75-77: 5x5, 32 -> 3 channels, NHWC in, three NCHW fp32 planes out) on the bf16
+ * slab kernel: wfrag = fragment-ordered weights zero-padded to 32 output channels, bias32 = bias padded to 32. */
+int spei_conv5_out_slab_bf16(const void* in, int ldi, int in_bf16, const void* wfrag, const float* bias32, float* out_chw,
+                             int H, int W, spei_stream_t stream);
+
 /* Fused attention branch of a Swin block (model/swinir.py:238-278 + :115-149): out = x + proj(W-MSA(q = yhat Wq,
  * [k,v] = LayerNorm(x) Wkv)) with cyclic shift `shift`, 5x5 windows, 8 heads; x,out [H*W][256] fp32 (may alias), yhat
  * [H*W][256] bf16 (LayerNorm of y without affine); w*_frag in MFMA fragment order with the LayerNorm affine and the q

@@ -51,6 +51,7 @@ struct SlabParams {
     // (y * o_mul + o_row_add, x * o_mul + o_col_add) of a map that is Wfull pixels wide.
     int ntap, tap_dy[4], tap_dx[4];
     int o_mul, o_row_add, o_col_add, Wfull;
+    int64_t planes;          // > 0: write output channels 0..2 as three fp32 NCHW planes of this many pixels (last conv)
     int ln;                  // 1: LayerNorm(256) without affine is applied to every input row while it is staged
                              //    (fp32 input, K == 256: one wave-instruction loads exactly one token row)
     int dbg;                 // ablation switches for tools/ablate_slab.py (0 in production): 1 no staging loads,
@@ -363,7 +364,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
                         f32x4 v = f32x4{a[0], a[1], a[2], a[3]};
                         if (p.rowscale) { const float rs = p.rowscale[m]; v *= rs; }
                         if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * (unsigned)p.ldr + ncol0 + ecol);
-                        if (sizeof(TO) == 4) {
+                        if (p.planes) {                       // 32 -> 3 channel tail: only the lanes holding channels 0..3 store
+                            if (ncol0 + ecol == 0) {
+                                float* po = reinterpret_cast<float*>(outp) + m;
+                                po[0] = v[0]; po[p.planes] = v[1]; po[2 * p.planes] = v[2];
+                            }
+                        } else if (sizeof(TO) == 4) {
                             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + m * (unsigned)p.ldo + ncol0 + ecol) = v;
                         } else {
                             bf16x4 h;
@@ -498,7 +504,7 @@ extern "C" int spei_conv_slab_bf16(const void* a0, int lda0, int k0, const void*
     p.ks = ksize; p.stride = stride; p.pad = pad; p.act = act;
     SPEI_REQUIRE(!ln_input || (!a_bf16 && k0 == 256 && k1 == 0 && ksize == 1), "spei_conv_slab_bf16: ln_input needs a 256-wide fp32 linear");
     p.ln = ln_input;
-    p.ntap = 0; p.o_mul = 1; p.o_row_add = 0; p.o_col_add = 0; p.Wfull = Wout;
+    p.ntap = 0; p.o_mul = 1; p.o_row_add = 0; p.o_col_add = 0; p.Wfull = Wout; p.planes = 0;
     hipStream_t st = (hipStream_t)stream;
     if (wfrag_lo) return dispatch<true, float, float>(p, st);
     if (a_bf16) return out_bf16 ? dispatch<false, __bf16, __bf16>(p, st) : dispatch<false, __bf16, float>(p, st);
@@ -532,7 +538,7 @@ extern "C" int spei_convt2_slab_bf16(const void* a0, int lda0, int k0, int a_bf1
                     p.tap_dx[p.ntap] = px ? 1 - ix : 0;
                     ++p.ntap;
                 }
-            p.o_mul = 2; p.o_row_add = py; p.o_col_add = px; p.Wfull = 2 * Win;
+            p.o_mul = 2; p.o_row_add = py; p.o_col_add = px; p.Wfull = 2 * Win; p.planes = 0;
             hipStream_t st = (hipStream_t)stream;
             int rc;
             if (a_bf16) rc = out_bf16 ? dispatch<false, __bf16, __bf16>(p, st) : dispatch<false, __bf16, float>(p, st);
@@ -540,4 +546,22 @@ extern "C" int spei_convt2_slab_bf16(const void* a0, int lda0, int k0, int a_bf1
             if (rc) return rc;
         }
     return 0;
+}
+
+extern "C" int spei_conv5_out_slab_bf16(const void* in, int ldi, int in_bf16, const void* wfrag, const float* bias32, float* out_chw,
+                                        int H, int W, spei_stream_t stream) {
+    SPEI_REQUIRE(in && wfrag && bias32 && out_chw && H > 0 && W > 0, "spei_conv5_out_slab_bf16: bad arguments");
+    SPEI_REQUIRE(ldi >= 32 && ldi % (in_bf16 ? 8 : 4) == 0 && ((uintptr_t)in | (uintptr_t)wfrag | (uintptr_t)out_chw) % 16 == 0,
+                 "spei_conv5_out_slab_bf16: alignment / stride");
+    SPEI_REQUIRE((int64_t)H * W < (1ll << 30), "spei_conv5_out_slab_bf16: map too large");
+    SlabParams p;
+    p.a0 = in; p.a1 = nullptr; p.wh = (const __bf16*)wfrag; p.wl = nullptr; p.bias = bias32; p.out = out_chw;
+    p.res = nullptr; p.rowscale = nullptr;
+    p.lda0 = ldi; p.lda1 = 0; p.k0 = 32; p.k1 = 0; p.ldo = 1; p.ldr = 0;
+    p.N = 32; p.K = 32;
+    p.Hin = H; p.Win = W; p.Hout = H; p.Wout = W;
+    p.ks = 5; p.stride = 1; p.pad = 2; p.act = SPEI_ACT_NONE; p.ln = 0;
+    p.ntap = 0; p.o_mul = 1; p.o_row_add = 0; p.o_col_add = 0; p.Wfull = W; p.planes = (int64_t)H * W;
+    hipStream_t st = (hipStream_t)stream;
+    return in_bf16 ? dispatch<false, __bf16, float>(p, st) : dispatch<false, float, float>(p, st);
 }

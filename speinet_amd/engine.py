@@ -148,7 +148,7 @@ def decode(ff: FMap, s: torch.Tensor, t3: FMap, t2: FMap, t1: FMap, P: dict, out
     ops.igemm(s23, *c("search33"), 32, ksize=3, a1=s33, act=ACT_RELU, residual=acc, out=acc)
     ob = P["outBlock"]
     f = _resblocks(acc, ob["blocks"])
-    return ops.conv5_out(f, ob["tail_w"], ob["tail_b"], out)
+    return ops.conv5_out(f, ob["tail_w"], ob["tail_b"], out, ob.get("tail_w32"), ob.get("tail_b32"))
 
 
 # ---- one sample --------------------------------------------------------------------------------------------

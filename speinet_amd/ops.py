@@ -142,8 +142,15 @@ def conv5_in(img: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> FMap:
     return out
 
 
-def conv5_out(f: FMap, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-    assert out.shape == (3, f.H, f.W) and out.is_contiguous()
+def conv5_out(f: FMap, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, w32=None, b32: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Last conv, NHWC 32 channels -> three NCHW planes.  w32 / b32 (weights zero-padded to 32 output channels, packed):
+    the "bf16" mode runs the layer on the slab kernel."""
+    assert out.shape == (3, f.H, f.W) and out.is_contiguous() and out.dtype == torch.float32
+    if PRECISION == "bf16" and USE_SLAB and w32 is not None and f.C == 32:
+        _lib.check(_lib.lib().spei_conv5_out_slab_bf16(_vp(f.ptr), f.ld, int(f.bf16), _tp(w32.fhi), _tp(b32), _tp(out), f.H, f.W, _stream()),
+                   "spei_conv5_out_slab_bf16")
+        return out
+    assert not f.bf16
     _lib.check(_lib.lib().spei_conv5_out(_vp(f.ptr), f.ld, _tp(w), _tp(b), _tp(out), f.H, f.W, f.C, _stream()), "spei_conv5_out")
     return out
 

@@ -153,6 +153,9 @@ def pack_all(sd: SD, cfg, device) -> dict:
     d = stage("outBlock", None, nrb, 0)
     d["tail_w"] = conv_w(sd[f"recons_net.outBlock.{nrb}.weight"])
     d["tail_b"] = sd[f"recons_net.outBlock.{nrb}.bias"]
+    # the same 32 -> 3 conv zero-padded to 32 output channels: the bf16 mode runs it on the slab kernel
+    d["tail_w32"] = G(torch.cat((d["tail_w"], torch.zeros(25, 29, d["tail_w"].shape[2], dtype=d["tail_w"].dtype, device=d["tail_w"].device)), 1))
+    d["tail_b32"] = torch.cat((d["tail_b"], torch.zeros(29, dtype=d["tail_b"].dtype, device=d["tail_b"].device)))
     out["outBlock"] = d
 
     for name in ("conv_lv1", "conv_lv2", "conv_lv3", "fusion", "search1", "search2", "search3", "search13", "search33", "search43"):

@@ -248,3 +248,16 @@ def test_forward_large_sizes_modes_agree(net, h, w, b, zero_ref):
     e1 = (outs["bf16"] - outs["f32"]).abs().max().item()
     print(f"{h}x{w}: max |bf16x3 - f32| {e3:.2e}, max |bf16 - f32| {e1:.2e}")
     assert e3 < (1e-3 if h < 720 else 2e-3) and e1 < 0.05      # 720p: the max is over 2.8 M values (9.3e-4 measured)
+
+
+def test_conv5_out_slab():
+    """Last conv (32 -> 3 channels, NCHW planes out) on the slab kernel in "bf16" mode; odd sizes -> partial tiles."""
+    ops.set_precision("bf16")
+    f = rnd(21, 1, 32, 27, 45)
+    wo, bo = rnd(22, 3, 32, 5, 5, scale=0.05), rnd(23, 3, scale=0.1)
+    w = pack.conv_w(wo)
+    w32 = pack.PackedW(torch.cat((w, torch.zeros(25, 29, 32)), 1), DEV)
+    b32 = torch.cat((bo, torch.zeros(29))).to(DEV)
+    o = torch.full((3, 27, 45), float("nan"), device=DEV)
+    ops.conv5_out(fm(f), w.to(DEV), bo.to(DEV), o, w32, b32)
+    assert relerr(o, F.conv2d(f, wo, bo, padding=2)[0]) < TOL["bf16"]
