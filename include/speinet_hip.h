@@ -170,8 +170,10 @@ int spei_gather_fold(const float* ref, int ldr, const int32_t* arg, float* out, 
 int spei_rot90(const float* in, int ldi, float* out, int H, int W, int C, spei_stream_t stream);
 
 /* K13 — F.interpolate(mode='bicubic', align_corners=False), A=-0.75, scale s in {2,4}
- * (model/speinet.py:96,99,108,111,113; model/SearchTransfer.py:73,75). */
-int spei_upsample_bicubic(const float* in, int ldi, float* out, int ldo, int H, int W, int C, int s,
+ * (model/speinet.py:96,99,108,111,113; model/SearchTransfer.py:73,75).  act: SPEI_ACT_NONE, or SPEI_ACT_RELU applied to
+ * the interpolated value — relu(conv1x1(up(x))) == relu(up(conv1x1(x) + b)) (both maps are linear, the bicubic weights
+ * sum to 1), which the throughput mode uses to run those 1x1 convs at a quarter of the pixels. */
+int spei_upsample_bicubic(const float* in, int ldi, float* out, int ldo, int H, int W, int C, int s, int act,
                           spei_stream_t stream);
 
 /* K14 — out = a + b over n floats. */

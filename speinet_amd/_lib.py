@@ -48,7 +48,7 @@ SIGNATURES = {
     "spei_corr_argmax": (I, [P, I, P, I, P, P, I, I, I, I, I, P, P, P, P]),
     "spei_gather_fold": (I, [P, I, P, P, I, I, I, I, I, I, I, P]),
     "spei_rot90": (I, [P, I, P, I, I, I, P]),
-    "spei_upsample_bicubic": (I, [P, I, P, I, I, I, I, I, P]),
+    "spei_upsample_bicubic": (I, [P, I, P, I, I, I, I, I, I, P]),
     "spei_add": (I, [P, P, P, L, P]),
     "spei_det_gray": (I, [P, P, I, I, I, P]),
     "spei_det_ws_floats": (L, [I, I, I, I]),

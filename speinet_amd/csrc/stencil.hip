@@ -259,7 +259,7 @@ __device__ __forceinline__ void cubic_coeffs(float t, float c[4]) {
 }
 template <int VEC>
 __global__ __launch_bounds__(256) void bicubic_kernel(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo,
-                                                      int H, int W, int C, int s) {
+                                                      int H, int W, int C, int s, int relu) {
     const int cg = C / VEC;
     const int64_t total = (int64_t)H * s * W * s * cg;
     const float scale = 1.0f / (float)s;
@@ -294,20 +294,25 @@ __global__ __launch_bounds__(256) void bicubic_kernel(const float* __restrict__ 
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc[e] = (a == 0) ? row[e] * cy[0] : fmaf(row[e], cy[a], acc[e]);
         }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = fmaxf(acc[e], 0.f);
+        }
         float* o = out + ((size_t)oy * (W * s) + ox) * ldo + c;
         if (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         else o[0] = acc[0];
     }
 }
-extern "C" int spei_upsample_bicubic(const float* in, int ldi, float* out, int ldo, int H, int W, int C, int s,
+extern "C" int spei_upsample_bicubic(const float* in, int ldi, float* out, int ldo, int H, int W, int C, int s, int act,
                                      spei_stream_t stream) {
     SPEI_REQUIRE(in && out && H > 0 && W > 0 && C > 0 && (s == 2 || s == 4), "spei_upsample_bicubic: bad arguments");
+    SPEI_REQUIRE(act == SPEI_ACT_NONE || act == SPEI_ACT_RELU, "spei_upsample_bicubic: act=%d", act);
     SPEI_REQUIRE(ldi >= C && ldo >= C, "spei_upsample_bicubic: bad row strides");
     const bool v4 = (C % 4 == 0) && (ldi % 4 == 0) && (ldo % 4 == 0);
     const int64_t total = (int64_t)H * s * W * s * (v4 ? C / 4 : C);
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    if (v4) hipLaunchKernelGGL(bicubic_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, ldi, out, ldo, H, W, C, s);
-    else    hipLaunchKernelGGL(bicubic_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, ldi, out, ldo, H, W, C, s);
+    if (v4) hipLaunchKernelGGL(bicubic_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, ldi, out, ldo, H, W, C, s, act == SPEI_ACT_RELU);
+    else    hipLaunchKernelGGL(bicubic_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, ldi, out, ldo, H, W, C, s, act == SPEI_ACT_RELU);
     SPEI_CHECK_LAUNCH("spei_upsample_bicubic");
     return 0;
 }

@@ -119,8 +119,8 @@ def self_transfer(f_fusion: FMap, P: dict):
     ref = ops.rot90(f_fusion)
     s, _ = ops.corr_argmax(f_fusion, ref, ops.patch_invnorm(f_fusion), ops.patch_invnorm(ref))
     p1, p2 = P["SelfTransfer.search1"], P["SelfTransfer.search2"]
-    t2 = ops.igemm(ops.upsample(f_fusion, 2), p1["w"], p1["b"], 64, act=ACT_RELU)
-    t1 = ops.igemm(ops.upsample(t2, 2), p2["w"], p2["b"], 32, act=ACT_RELU)
+    t2 = ops.up_conv1x1_relu(f_fusion, p1["w"], p1["b"], 64)
+    t1 = ops.up_conv1x1_relu(t2, p2["w"], p2["b"], 32)
     return s, f_fusion, t2, t1
 
 
@@ -133,14 +133,14 @@ def decode(ff: FMap, s: torch.Tensor, t3: FMap, t2: FMap, t1: FMap, P: dict, out
     dec2 = dec_stage(f_lv3, P["decoder_second"])
     s2 = ops.upsample(smap, 2).t.view(-1)
     f_lv2 = ops.igemm(dec2, *c("conv_lv2"), 64, a1=t2, rowscale=s2, residual=dec2)
-    s1 = ops.igemm(ops.upsample(f_lv3, 2), *c("search1"), 64, act=ACT_RELU)
+    s1 = ops.up_conv1x1_relu(f_lv3, *c("search1"), 64)
     sr2 = ops.igemm(f_lv2, *c("search3"), 64, ksize=3, act=ACT_RELU)
     f_v3 = ops.igemm(dec2, *c("search2"), 64, a1=s1, act=ACT_RELU, residual=dec2)
     f_lv2 = ops.igemm(f_lv2, *c("search2"), 64, a1=sr2, act=ACT_RELU, residual=f_lv2)
     dec1 = dec_stage(f_lv2, P["decoder_first"])
     s4 = ops.upsample(smap, 4).t.view(-1)
     f_lv1 = ops.igemm(dec1, *c("conv_lv1"), 32, a1=t1, rowscale=s4, residual=dec1)
-    s13 = ops.igemm(ops.upsample(f_v3, 2), *c("search13"), 32, act=ACT_RELU)
+    s13 = ops.up_conv1x1_relu(f_v3, *c("search13"), 32)
     s23 = ops.igemm(ops.upsample(f_lv2, 2), *c("search33"), 32, ksize=3, act=ACT_RELU)
     s33 = ops.igemm(f_lv1, *c("search43"), 32, ksize=3, act=ACT_RELU)
     acc = ops.igemm(s13, *c("search33"), 32, ksize=3, a1=s23, act=ACT_RELU, residual=f_lv1)

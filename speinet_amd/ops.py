@@ -360,10 +360,20 @@ def rot90(f: FMap) -> FMap:
     return out
 
 
-def upsample(f: FMap, s: int) -> FMap:
+def upsample(f: FMap, s: int, act: int = ACT_NONE) -> FMap:
     out = FMap.empty(f.H * s, f.W * s, f.C, f.t.device)
-    _lib.check(_lib.lib().spei_upsample_bicubic(_vp(f.ptr), f.ld, _vp(out.ptr), out.ld, f.H, f.W, f.C, s, _stream()), "spei_upsample_bicubic")
+    _lib.check(_lib.lib().spei_upsample_bicubic(_vp(f.ptr), f.ld, _vp(out.ptr), out.ld, f.H, f.W, f.C, s, act, _stream()),
+               "spei_upsample_bicubic")
     return out
+
+
+def up_conv1x1_relu(f: FMap, w, b: torch.Tensor, n: int, s: int = 2) -> FMap:
+    """relu(conv1x1(bicubic_up(f))) (reference model/speinet.py:96-97,108-109, model/SearchTransfer.py:73-76).  Both maps
+    are linear and the bicubic weights sum to 1, so the "bf16" mode runs the conv first, at 1/s^2 of the pixels and with
+    half the bytes through the upsampler; the f32-grade modes keep the reference's order of operations."""
+    if PRECISION == "bf16":
+        return upsample(igemm(f, w, b, n), s, act=ACT_RELU)
+    return igemm(upsample(f, s), w, b, n, act=ACT_RELU)
 
 
 def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:

@@ -261,3 +261,15 @@ def test_conv5_out_slab():
     o = torch.full((3, 27, 45), float("nan"), device=DEV)
     ops.conv5_out(fm(f), w.to(DEV), bo.to(DEV), o, w32, b32)
     assert relerr(o, F.conv2d(f, wo, bo, padding=2)[0]) < TOL["bf16"]
+
+
+def test_up_conv1x1_relu_commuted():
+    """relu(conv1x1(bicubic_up(x))): the "bf16" mode runs the conv before the upsampling (ReLU fused into the upsampler);
+    same function up to the bf16 products, checked against the reference's order in fp32."""
+    x = rnd(31, 1, 128, 9, 13)
+    wt, b = rnd(32, 64, 128, 1, 1, scale=0.08), rnd(33, 64, scale=0.2)
+    ref = F.relu(F.conv2d(F.interpolate(x, scale_factor=2, mode="bicubic"), wt, b))
+    for mode in ("bf16x3", "bf16"):
+        ops.set_precision(mode)
+        out = ops.up_conv1x1_relu(fm(x), pack.conv_w(wt).to(DEV), b.to(DEV), 64)
+        assert relerr(out.nchw(), ref) < TOL[mode], mode
