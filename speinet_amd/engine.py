@@ -210,3 +210,53 @@ def forward_sample(x: torch.Tensor, P: dict, n_seq: int, has_ref: bool, out: tor
     else:
         s, t3, t2, t1 = self_transfer(ff, P)
     return decode(ff, s, t3, t2, t1, P, out)
+
+
+# ---- cross-window reuse --------------------------------------------------------------------
+# A clip is deblurred with stride-1 sliding windows, so most encoder passes of a window repeat work of the previous
+# ones: frame t is the right neighbour of window t-1, the middle of window t and the left neighbour of window t+1, and a
+# sharp reference serves several windows.  The per-frame pieces below are exactly the sub-graphs `forward_sample` runs
+# (same kernels, same operands => bit-identical results); `fuse_and_decode` is everything after them.
+def encode_raw(frame: torch.Tensor, P: dict) -> FMap:
+    """enc(frame): shared by the frame's RL-1 (neighbour) and RL-5 (middle) sums."""
+    return enc(frame, P)
+
+
+def encode_sum(frame: torch.Tensor, iters: int, e_raw: FMap, P: dict) -> FMap:
+    """enc(RL_iters(frame)) + enc(frame)  (speinet.py:82-84 with iters = 5 for the middle frame, :129-132 with 1)."""
+    return enc(ops.rl_prior(frame, iters, 0.01), P, extra=e_raw)
+
+
+def reference_pyramid(frame: torch.Tensor, P: dict):
+    lv1 = in_block(frame, P["inBlock"])
+    lv2 = enc_stage(lv1, P["encoder_first"])
+    return lv1, lv2, enc_stage(lv2, P["encoder_second"])
+
+
+def fuse_and_decode(f_mid: FMap, feats: list, lv, P: dict, n_seq: int, out: torch.Tensor) -> torch.Tensor:
+    """Everything after the encoders: the neighbour-frame fusions (on the side lanes), `fusion`, SearchTransfer (lv = the
+    reference pyramid) or SelfTransfer (lv = None), decoder.  f_mid / feats: [H/4*W/4, 128] maps."""
+    h3, w3 = f_mid.H, f_mid.W
+    dev = f_mid.t.device
+    main = torch.cuda.current_stream(dev)
+    lanes = [main] + (_sides(dev, STREAMS - 1) if STREAMS > 1 else [])
+    cat = FMap(torch.empty(h3 * w3, 128 * n_seq, device=dev), h3, w3, 128 * n_seq)
+    cat.t[:, :128].copy_(f_mid.t)
+    sx = SwinX(f_mid, P["swin"])
+    ready = torch.cuda.Event()
+    ready.record(main)
+    for slot, feat in enumerate(feats, start=1):
+        lane = lanes[(slot - 1) % len(lanes)]
+        if lane is not main:
+            lane.wait_event(ready)
+        with torch.cuda.stream(lane):
+            swin(sx, feat, P["swin"], out=cat.view(128 * slot, 128))
+    for s_ in lanes[1:]:
+        main.wait_stream(s_)
+    fw = P["fusion"]
+    ff = ops.igemm(cat, fw["w"], fw["b"], 128)
+    if lv is not None:
+        s, t3, t2, t1 = search_transfer(ff, *lv)
+    else:
+        s, t3, t2, t1 = self_transfer(ff, P)
+    return decode(ff, s, t3, t2, t1, P, out)

@@ -26,7 +26,7 @@ import torch
 
 from . import checkpoint, detector, selection
 from .dist import gather_metrics, shard_clips_by_length
-from .speinet import SPEINet, default_args
+from .speinet import EncoderCache, SPEINet, default_args
 
 
 def _imread(path: str) -> np.ndarray:
@@ -189,6 +189,7 @@ class Inference:
                 if a.save_image:
                     os.makedirs(os.path.join(a.result_path, clip), exist_ok=True)
                 vp, vs = [], []
+                enc_cache = EncoderCache()                      # per-clip: encoder results of frames shared by overlapping windows
                 pending = collections.deque()                   # (name, future, pre_time, forward_time, t_start), frame order
 
                 def flush(block: bool):
@@ -215,7 +216,12 @@ class Inference:
                         imgs[-1] = np.zeros_like(imgs[-1])
                     x = selection.numpy2tensor_device(imgs, self.device)
                     t1 = time.time()
-                    out = self.net(x, routing=[bool(w["zero_pre"])])
+                    if a.reuse:
+                        keys = list(needs[k][:self.n_seq]) + [("zero", nh, nw) if w["zero_pre"] else w["pre"],
+                                                              ("zero", nh, nw) if w["zero_sub"] else w["sub"]]
+                        out = self.net.forward_window(x, keys, enc_cache, zero_ref=bool(w["zero_pre"]))
+                    else:
+                        out = self.net(x, routing=[bool(w["zero_pre"])])
                     out_u8 = out.mul(255.0).clamp(0, 255).round()[0].to(torch.uint8).permute(1, 2, 0).contiguous()   # = tensor2numpy, on the GPU
                     gt_u8 = torch.from_numpy(gt[:nh, :nw].copy()).to(self.device, non_blocking=True)
                     psnr, ssim = metrics_gpu(out_u8[4:-4, 4:-4], gt_u8[4:-4, 4:-4])     # border crop: inference_SPEINet.py:405-410
@@ -256,6 +262,8 @@ def build_args(argv=None):
     p.add_argument("--device", type=str, default="cuda")
     p.add_argument("--precision", choices=["f32", "bf16x3", "bf16"], default="f32")
     p.add_argument("--prefetch", type=int, default=4, help="windows decoded ahead of the GPU")
+    p.add_argument("--no_reuse", dest="reuse", action="store_false", default=True,
+                   help="recompute every encoder pass per window instead of reusing the per-frame results of overlapping windows")
     p.add_argument("--streams", type=int, default=2, help="HIP streams for the independent branches of a frame")
     p.add_argument("--no_graph", dest="graph", action="store_false", default=True, help="launch kernels eagerly (no hipGraph replay)")
     a = p.parse_args(argv)

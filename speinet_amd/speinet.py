@@ -267,6 +267,73 @@ class SPEINet(nn.Module):
             engine.forward_sample(x[b], P, self.n_sequence, not zero_ref[b], out[b])
         return out
 
+    def forward_window(self, x: torch.Tensor, keys: Sequence, cache: "EncoderCache", zero_ref: bool) -> torch.Tensor:
+        """One window of a clip with cross-window reuse of the per-frame encoder work (not part of the
+        reference API).  x [1, n_sequence+2, 3, H, W]; keys: one hashable id per frame of x (e.g. its file name) — frames
+        with equal ids MUST have equal pixels; cache: an `EncoderCache` the caller keeps per clip.  Bit-identical to
+        `forward(x)`: the same kernels run on the same operands, only less often.  The encoder passes that are missing
+        run eagerly; everything after them replays as one hipGraph when `use_graph` is set."""
+        if x.dim() != 5 or x.shape[0] != 1 or x.shape[1] != self.n_sequence + 2 or len(keys) != self.n_sequence + 2:
+            raise ValueError(f"expected x [1,{self.n_sequence + 2},3,H,W] and {self.n_sequence + 2} keys")
+        h, w = x.shape[-2:]
+        if h % 20 or w % 20:
+            raise ValueError(f"H and W must be multiples of 20; got {h}x{w}")
+        if not x.is_cuda:
+            raise RuntimeError("speinet_amd.SPEINet runs on MI355X only (HIP kernels); there is no CPU path")
+        _lib.lib()
+        ops.set_precision(self.precision, self.corr_precision)
+        engine.STREAMS = max(1, int(self.streams))
+        x = x.contiguous().float()
+        P = self._pack(x.device)
+        n, mid = self.n_sequence, self.n_sequence // 2
+        tag = (self.precision, self.corr_precision, h, w, self._packed_key)
+
+        def raw(i):
+            return cache.get((tag, keys[i], "raw")) or cache.put((tag, keys[i], "raw"), engine.encode_raw(x[0, i], P))
+
+        def summed(i, iters):
+            k = (tag, keys[i], iters)
+            return cache.get(k) or cache.put(k, engine.encode_sum(x[0, i], iters, raw(i), P))
+
+        f_mid = summed(mid, 5)
+        feats = [summed(i, 1) for i in range(n) if i != mid]
+        lv = None
+        if not zero_ref:
+            k = (tag, keys[n + 1], "ref")
+            lv = cache.get(k) or cache.put(k, engine.reference_pyramid(x[0, n + 1], P))
+        out = torch.empty(1, 3, h, w, device=x.device, dtype=torch.float32)
+        if not self.use_graph:
+            engine.fuse_and_decode(f_mid, feats, lv, P, n, out[0])
+            return out
+        gkey = ("window", h, w, bool(zero_ref), self.precision, self.corr_precision, self.streams, str(x.device), self._packed_key)
+        g = self._graphs.get(gkey)
+        if g is None:
+            from .ops import FMap
+            clone = lambda f: FMap(f.t.clone(), f.H, f.W, f.C)
+            s_mid, s_feats = clone(f_mid), [clone(f) for f in feats]
+            s_lv = tuple(clone(f) for f in lv) if lv is not None else None
+            s_out = torch.empty_like(out)
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):           # warm-up off the capture
+                engine.fuse_and_decode(s_mid, s_feats, s_lv, P, n, s_out[0])
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                engine.fuse_and_decode(s_mid, s_feats, s_lv, P, n, s_out[0])
+            if len(self._graphs) >= 4:
+                self._graphs.clear()
+            g = self._graphs[gkey] = (graph, s_mid, s_feats, s_lv, s_out)
+        graph, s_mid, s_feats, s_lv, s_out = g
+        s_mid.t.copy_(f_mid.t)
+        for d, f in zip(s_feats, feats):
+            d.t.copy_(f.t)
+        if lv is not None:
+            for d, f in zip(s_lv, lv):
+                d.t.copy_(f.t)
+        graph.replay()
+        return s_out.clone()
+
     def _forward_graph(self, x: torch.Tensor, P: dict, zero_ref: list) -> torch.Tensor:
         """Replay the ~1500 launches of a frame as ONE hipGraph (captured once per shape / routing / precision):
         the per-launch host cost (ctypes + hipLaunch, ~10 us each) otherwise leaves the GPU idle ~15 % of a frame."""
@@ -292,6 +359,36 @@ class SPEINet(nn.Module):
         static_x.copy_(x)
         graph.replay()
         return static_out.clone()
+
+
+class EncoderCache:
+    """Per-clip LRU store of per-frame encoder results for `SPEINet.forward_window` (device tensors; a 720p entry is
+    30 MB, a reference pyramid 207 MB)."""
+
+    def __init__(self, capacity: int = 24):
+        import collections
+        self.capacity = capacity
+        self.items = collections.OrderedDict()
+        self.hits = self.misses = 0
+
+    def get(self, key):
+        v = self.items.get(key)
+        if v is None:
+            self.misses += 1
+            return None
+        self.items.move_to_end(key)
+        self.hits += 1
+        return v
+
+    def put(self, key, value):
+        self.items[key] = value
+        self.items.move_to_end(key)
+        while len(self.items) > self.capacity:
+            self.items.popitem(last=False)
+        return value
+
+    def clear(self):
+        self.items.clear()
 
 
 def make_model(args):

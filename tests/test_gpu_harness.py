@@ -54,3 +54,32 @@ def test_harness_two_clips(tmp_path):
         out = inf.net(selection.numpy2tensor(imgs).cuda())
     saved = inference._imread(os.path.join(res, "clipA", w["name"] + ".png"))
     assert np.array_equal(selection.tensor2numpy(out), saved)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_forward_window_reuse_bit_identical(graph):
+    """Cross-window reuse of the per-frame encoder passes (SURVEY.md plan step 8): sliding windows over a clip through
+    `forward_window` give exactly the bits of the stateless `forward`, with most encoder passes served from the cache;
+    both routing branches, a zeroed reference frame, eager and hipGraph tails."""
+    from speinet_amd.speinet import EncoderCache, SPEINet, default_args
+    from speinet_amd.synth import state_dict_template, synth_state_dict
+    net = SPEINet(args=default_args())
+    net.load_state_dict(synth_state_dict(state_dict_template(), seed=0))
+    net = net.cuda().eval()
+    net.precision, net.corr_precision, net.streams, net.use_graph = "bf16", "bf16", 2, graph
+    frames = synth_frames(2, 60, 80, seed=11).reshape(10, 3, 60, 80)[:8].cuda()       # an 8-frame "clip"
+    zero = torch.zeros_like(frames[0])
+    cache = EncoderCache()
+    with torch.no_grad():
+        for t in range(1, 7):
+            pre_zero, sub_zero = t == 3, t == 5                                          # window 3 -> SelfTransfer branch
+            pre, sub = (zero if pre_zero else frames[0]), (zero if sub_zero else frames[7])
+            x = torch.stack([frames[t - 1], frames[t], frames[t + 1], pre, sub]).unsqueeze(0)
+            keys = [t - 1, t, t + 1, "zero" if pre_zero else 0, "zero" if sub_zero else 7]
+            out_w = net.forward_window(x, keys, cache, zero_ref=pre_zero)
+            net.use_graph = False
+            ref = net(x, routing=[pre_zero])
+            net.use_graph = graph
+            assert torch.equal(out_w, ref), f"window {t}"
+    # 8 raw + 6 RL-5 + 8 RL-1 encoder passes and 2 reference pyramids were computed, instead of 36 + 5 without the cache
+    assert cache.misses == 24 and cache.hits >= 10, (cache.hits, cache.misses)
