@@ -13,6 +13,14 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _f32_mode():
+    """These tests check the exact-fp32 path; the arithmetic mode is a process-global that other test modules change."""
+    from speinet_amd import ops as _ops
+    _ops.set_precision("f32", "bf16x3")
+    yield
+
 from oracle import speinet_oracle as O           # noqa: E402
 from speinet_amd import engine, ops, pack        # noqa: E402
 from speinet_amd.ops import FMap                 # noqa: E402
