@@ -120,3 +120,18 @@ def test_checkpoint_tooling(tmp_path, synth_sd):
     assert missing == ["fusion.weight"] and not unexpected and len(bad) == 1 and checkpoint.main(["check", path]) == 1
     with pytest.raises(RuntimeError):
         checkpoint.load_into(SPEINet(args=default_args()), path)
+
+
+def test_encoder_cache_lru():
+    """EncoderCache: LRU eviction, hit / miss counters (the values are opaque to it)."""
+    from speinet_amd.speinet import EncoderCache
+    c = EncoderCache(capacity=3)
+    assert c.get("a") is None and c.misses == 1
+    for k in "abc":
+        c.put(k, k.upper())
+    assert c.get("a") == "A"                      # refreshes "a"
+    c.put("d", "D")                               # evicts the least recently used entry: "b"
+    assert c.get("b") is None and c.get("a") == "A" and c.get("c") == "C" and c.get("d") == "D"
+    assert (c.hits, c.misses) == (4, 2)
+    c.clear()
+    assert c.get("a") is None
