@@ -273,3 +273,94 @@ def test_up_conv1x1_relu_commuted():
         ops.set_precision(mode)
         out = ops.up_conv1x1_relu(fm(x), pack.conv_w(wt).to(DEV), b.to(DEV), 64)
         assert relerr(out.nchw(), ref) < TOL[mode], mode
+
+
+@pytest.mark.parametrize("mode,corr", [("f32", "bf16x3"), ("bf16", "bf16x3"), ("bf16", "bf16")])
+def test_full_size_search_properties(mode, corr):
+    """Size-independent properties at the 720p map size (180 x 320 positions, 128 channels; no oracle run at this size):
+    a map correlated with itself finds every position at itself with a normalised score of 1, a shifted copy is found at the
+    shift, and gathering with the identity indices reproduces the map (fold(unfold(x)) / 9: exactly x away from the border)."""
+    ops.set_precision(mode, corr)
+    h, w = 180, 320
+    gen = torch.Generator().manual_seed(5)
+    f = FMap(torch.randn(h * w, 128, generator=gen).to(DEV), h, w, 128)
+    inv = ops.patch_invnorm(f)
+    s, arg = ops.corr_argmax(f, f, inv, inv)
+    ident = torch.arange(h * w, device=DEV, dtype=torch.int32)
+    assert torch.equal(arg, ident)
+    assert (s - 1).abs().max().item() < (1e-5 if mode == "f32" else 2e-2 if corr == "bf16" else 1e-4)
+    # query = reference shifted by (3, 5) pixels: interior positions (whose whole 3x3 patch moved along) point back by the shift
+    g = FMap(torch.roll(f.t.view(h, w, 128), shifts=(3, 5), dims=(0, 1)).reshape(h * w, 128).contiguous(), h, w, 128)
+    _, arg2 = ops.corr_argmax(g, f, ops.patch_invnorm(g), inv)
+    yy, xx = torch.meshgrid(torch.arange(5, h - 1, device=DEV), torch.arange(7, w - 1, device=DEV), indexing="ij")
+    assert torch.equal(arg2.view(h, w)[5:h - 1, 7:w - 1].long(), (yy - 3) * w + (xx - 5))
+    for scale, c in ((1, 128), (2, 64), (4, 32)):
+        ref = FMap(torch.randn(h * scale * w * scale, c, generator=gen).to(DEV), h * scale, w * scale, c)
+        t = ops.gather_fold(ref, ident, h, w, h, w, scale)
+        a, b = t.t.view(h * scale, w * scale, c)[scale:-scale, scale:-scale], ref.t.view(h * scale, w * scale, c)[scale:-scale, scale:-scale]
+        assert (a - b).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_full_size_conv_identity(mode):
+    """Identity kernels at the 720p layer sizes (no oracle run at these sizes): a centre-tap identity convolution must return
+    its input exactly (bf16-rounded in "bf16" mode: x * 1 + zeros is exact) at every pixel incl. the map border and every
+    partial tile; stride 2 returns the even pixels; the transposed conv writes the input to the even output pixels."""
+    ops.set_precision(mode)
+    gen = torch.Generator().manual_seed(9)
+    rnd_in = lambda x: x.bfloat16().float() if mode == "bf16" else x
+    for c, h, w, ks in ((32, 720, 1280, 5), (64, 360, 640, 5), (128, 180, 320, 5), (256, 180, 320, 3)):
+        x = torch.randn(h * w, c, generator=gen).to(DEV)
+        wt = torch.zeros(ks * ks, c, c)
+        wt[ks * ks // 2] = torch.eye(c)
+        out = ops.igemm(FMap(x, h, w, c), pack.PackedW(wt, DEV), torch.zeros(c, device=DEV), c, ksize=ks)
+        assert torch.equal(out.t, rnd_in(x)), (c, h, w, ks)
+    for c, n, h, w in ((32, 64, 720, 1280), (64, 128, 360, 640)):                    # stride-2 heads: out[y][x] = in[2y][2x], channels 0..c-1
+        x = torch.randn(h * w, c, generator=gen).to(DEV)
+        wt = torch.zeros(25, n, c)
+        wt[12, :c] = torch.eye(c)
+        out = ops.igemm(FMap(x, h, w, c), pack.PackedW(wt, DEV), torch.zeros(n, device=DEV), n, ksize=5, stride=2)
+        assert torch.equal(out.t.view(h // 2, w // 2, n)[:, :, :c], rnd_in(x).view(h, w, c)[::2, ::2])
+        assert out.t.view(h // 2, w // 2, n)[:, :, c:].abs().max().item() == 0
+    for c, n, h, w in ((128, 64, 180, 320), (64, 32, 360, 640)):                     # decoder tails
+        x = torch.randn(h * w, c, generator=gen).to(DEV)
+        wt = torch.zeros(9, n, c)
+        wt[4] = torch.eye(c)[:n]
+        out = ops.igemm(FMap(x, h, w, c), pack.PackedW(wt, DEV), torch.zeros(n, device=DEV), n, ksize=3, stride=2, mode=ops.CONV_T)
+        o = out.t.view(2 * h, 2 * w, n)
+        assert torch.equal(o[::2, ::2], rnd_in(x).view(h, w, c)[:, :, :n])
+        assert o[1::2].abs().max().item() == 0 and o[:, 1::2].abs().max().item() == 0
+
+
+def test_full_size_swin_properties(synth_sd):
+    """Size-independent properties of the fused Swin kernels at the 720p token count (180 x 320 = 57600 tokens, 2304
+    windows): (i) MLP with fc2 = 0 returns x exactly; (ii) attention with proj = 0 returns x exactly; (iii) with V = a
+    constant vector c (zero V weights, bias c) and proj = identity, softmax rows summing to 1 give x + c for every token
+    of every (shifted, masked) window, up to the bf16 rounding of the probabilities."""
+    ops.set_precision("bf16")
+    h, w = 180, 320
+    m = h * w
+    gen = torch.Generator().manual_seed(13)
+    x = (torch.randn(m, 256, generator=gen) * 1.2 + 0.3).to(DEV)
+    yhat = ops.layernorm(torch.randn(m, 256, generator=gen).to(DEV), out_dtype=torch.bfloat16)
+    p = "swin.layers.3.residual_group.blocks.1."
+    raw = pack.swin_block(synth_sd, p, 8, 5)
+    bk = {k: (v.to(DEV) if torch.is_tensor(v) else pack.PackedW(v.t, DEV)) for k, v in raw.items()}
+    # (i)
+    out = ops.mlp_fused(x, bk["w1"], bk["b1"], pack.PackedW(torch.zeros(1, 256, 512), DEV), torch.zeros(256, device=DEV), out=torch.empty_like(x))
+    assert torch.equal(out, x)
+    for shift in (0, 2):
+        # (ii)
+        b0 = dict(bk, wproj=pack.PackedW(torch.zeros(1, 256, 256), DEV), bproj=torch.zeros(256, device=DEV))
+        assert torch.equal(ops.attn_fused(x, yhat, b0, h, w, shift, out=torch.empty_like(x)), x)
+        # (iii)
+        c = torch.linspace(-1.5, 2.0, 256)
+        wkv = raw["wkv"].t.clone()
+        wkv[0, 256:] = 0
+        bkv = raw["bkv"].clone()
+        bkv[256:] = c
+        b1 = dict(bk, wkv=pack.PackedW(wkv, DEV), bkv=bkv.to(DEV), wproj=pack.PackedW(torch.eye(256).unsqueeze(0), DEV),
+                  bproj=torch.zeros(256, device=DEV))
+        out = ops.attn_fused(x, yhat, b1, h, w, shift, out=torch.empty_like(x))
+        err = (out - x - c.to(DEV)).abs().max().item()
+        assert err < 2e-2, (shift, err)
