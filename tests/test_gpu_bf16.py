@@ -164,7 +164,7 @@ def test_mlp_fused_vs_oracle(synth_sd):
     p = "swin.layers.1.residual_group.blocks.2."
     bk = pack.swin_block(synth_sd, p, 8, 5)
     w1, w2 = pack.PackedW(bk["w1"].t, DEV), pack.PackedW(bk["w2"].t, DEV)
-    for m in (64, 1000, 2500):                     # whole tile, ragged tail, many tiles
+    for m in (64, 1000, 2500, 57600):              # whole tile, ragged tail, many tiles, the 720p token count
         x = rnd(40 + m, m, 256, scale=1.5) + 0.3
         ref = x + F.linear(F.gelu(F.linear(F.layer_norm(x, (256,), synth_sd[p + "norm2.weight"], synth_sd[p + "norm2.bias"], 1e-5),
                                            synth_sd[p + "mlp.fc1.weight"], synth_sd[p + "mlp.fc1.bias"])),
@@ -177,7 +177,8 @@ def test_mlp_fused_vs_oracle(synth_sd):
         assert torch.equal(inplace, out)
 
 
-@pytest.mark.parametrize("h,w,shift", [(5, 5, 0), (5, 5, 2), (10, 15, 0), (10, 15, 2), (15, 25, 2), (20, 35, 0), (20, 35, 2)])
+@pytest.mark.parametrize("h,w,shift", [(5, 5, 0), (5, 5, 2), (10, 15, 0), (10, 15, 2), (15, 25, 2), (20, 35, 0), (20, 35, 2),
+                                       (180, 320, 2)])       # last: the 720p token map (2304 windows), oracle on the CPU
 def test_attn_fused_vs_oracle(synth_sd, h, w, shift):
     """Fused LN -> q/kv -> shifted-window attention -> proj -> +x kernel against the oracle's attention branch
     (model/swinir.py:238-278); odd window counts leave the second window slot of the last workgroup empty."""

@@ -312,3 +312,58 @@ def test_forward_routing_argument(net):
         c = net(x, routing=[True])          # force the no-reference branch on the same pixels
     assert torch.equal(a, b)
     assert not torch.equal(a, c)
+
+
+@pytest.mark.parametrize("key,c,h,w", [("recons_net.inBlock.2.", 32, 720, 1280), ("recons_net.encoder_first.1.", 64, 360, 640),
+                                       ("recons_net.encoder_second.3.", 128, 180, 320)])
+def test_resblock_gates_full_size_vs_oracle(synth_sd, key, c, h, w):
+    """The gate path (tile statistics -> row / column reductions -> 7x7 / 5x5 gate maps, SE vector) at the three 720p level
+    sizes against the ORACLE itself: the reductions are cheap enough for the CPU at full size.  Also the gated residual sum."""
+    gen = torch.Generator().manual_seed(41)
+    x1 = torch.randn(1, c, h, w, generator=gen) * 0.7 + 0.1
+    pk = {k: v.to(DEV).contiguous() for k, v in pack.resblock(synth_sd, key).items() if torch.is_tensor(v)}
+    s_ref, g1_ref, g2_ref = O.resblock_gates(x1, synth_sd, key)
+    f1 = fm(x1)
+    s, g1, g2 = ops.resblock_gates(f1, pk)
+    close(s, s_ref.view(c), 1e-5, 1e-5, "SE vector")
+    close(g1, g1_ref[0, :, :, 0].t(), 1e-4, 1e-5, "row gate map")          # ours [H][C]
+    close(g2, g2_ref[0, :, 0, :].t(), 1e-4, 1e-5, "column gate map")       # ours [W][C]
+
+
+def test_stencil_kernels_full_size_vs_oracle():
+    """The HBM-bound kernels at the 720p sizes against the oracle / plain PyTorch on the CPU (cheap enough at full size): RL
+    prior (1 and 5 iterations), first conv (f32-MFMA implicit GEMM, persistent tiles), last conv, LayerNorm(256) over the
+    57600 tokens, bicubic x2 of the lv3 map, rot90, patch normalisers."""
+    gen = torch.Generator().manual_seed(51)
+    x = torch.rand(3, 720, 1280, generator=gen)
+    x[1, 100:140, 200:300] = 0
+    for iters in (1, 5):
+        close(ops.rl_prior(x.to(DEV), iters), O.rl_prior(x[None], iters)[0], 1e-5, 1e-6, f"rl_prior {iters}")
+    wt, b = rnd(52, 32, 3, 5, 5, scale=0.1), rnd(53, 32, scale=0.1)
+    close(ops.conv5_in(x.to(DEV), pack.conv_w(wt).to(DEV), b.to(DEV)).nchw(), F.relu(F.conv2d(x[None], wt, b, padding=2)), 1e-5, 1e-5, "conv5_in")
+    f = torch.randn(1, 32, 720, 1280, generator=gen)
+    wo, bo = rnd(54, 3, 32, 5, 5, scale=0.05), rnd(55, 3, scale=0.1)
+    o = torch.empty(3, 720, 1280, device=DEV)
+    ops.conv5_out(fm(f), pack.conv_w(wo).to(DEV), bo.to(DEV), o)
+    close(o, F.conv2d(f, wo, bo, padding=2)[0], 1e-5, 1e-5, "conv5_out")
+    t = torch.randn(57600, 256, generator=gen) * 2 + 0.5
+    gm, bt = rnd(56, 256) * 0.1 + 1, rnd(57, 256) * 0.1
+    close(ops.layernorm(t.to(DEV), gm.to(DEV), bt.to(DEV)), F.layer_norm(t, (256,), gm, bt, 1e-5), 1e-5, 1e-5, "layernorm")
+    m = torch.randn(1, 128, 180, 320, generator=gen)
+    close(ops.upsample(fm(m), 2).nchw(), F.interpolate(m, scale_factor=2, mode="bicubic"), 1e-5, 1e-5, "bicubic x2")
+    close(ops.rot90(fm(m)).nchw(), m.transpose(2, 3).flip(2), 0, 0, "rot90")
+    un = F.unfold(m, kernel_size=3, padding=1)
+    close(ops.patch_invnorm(fm(m)), 1.0 / un.norm(dim=1).clamp_min(1e-12).view(-1), 1e-5, 1e-6, "patch normalisers")
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,h,w", [(32, 32, 5, 1, 720, 1280), (64, 64, 5, 1, 360, 640), (128, 128, 5, 1, 180, 320),
+                                                   (256, 256, 3, 1, 180, 320), (32, 64, 5, 2, 720, 1280)])
+def test_igemm_conv_full_size_vs_cpu(cin, cout, k, stride, h, w):
+    """The exact-fp32 implicit GEMM at the 720p layer sizes against F.conv2d on the host (47-68 GFLOP each: about a second)."""
+    gen = torch.Generator().manual_seed(61)
+    x = torch.randn(1, cin, h, w, generator=gen)
+    wt = torch.randn(cout, cin, k, k, generator=gen) / np.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=gen) * 0.1
+    ref = F.conv2d(x, wt, b, stride=stride, padding=k // 2)
+    out = ops.igemm(fm(x), pack.conv_w(wt).to(DEV), b.to(DEV), cout, ksize=k, stride=stride)
+    close(out.nchw(), ref, 2e-5, 2e-5, "conv full size")
