@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""G14: the REFERENCE's own forward pass at the bench configuration (1 x 5 x 3 x 720 x 1280, `_forwardbs`, synthetic weights
-seed 0) — about five minutes and ~20 GB on the build container's CPU.  Only a subsampled view of the output is committed:
-every 8th pixel (3 x 90 x 160 floats) plus the per-channel mean / standard deviation of the full frame; the input is
-regenerated from its seed by the test.
+"""G14-G16: the REFERENCE's own forward pass at the full sizes (synthetic weights seed 0): the bench configuration
+(1 x 5 x 3 x 720 x 1280, `_forwardbs`), the same with a zeroed reference frame (`_forwardb`), and a mixed-routing batch of
+two at 480 x 640 (the BSD frame size) — minutes and ~20 GB on the build container's CPU.  Only a subsampled view of each
+output is committed: every 8th pixel plus the per-channel mean / standard deviation of the full frame; the inputs are
+regenerated from their seeds by the tests.
 
-Run:  python tests/golden/make_golden_720p.py        (needs /root/reference; writes tests/golden/g14_fwd_720p.npz)
+Run:  python tests/golden/make_golden_720p.py [case ...]     (needs /root/reference; writes tests/golden/g1[456]_*.npz)
 """
 import os
 import sys
@@ -26,14 +27,19 @@ def main():
     net = ms.SPEINet(in_channels=3, n_sequence=3, out_channels=3, n_resblock=3, n_feat=32, device="cpu", args=template_args())
     net.load_state_dict(synth_state_dict(net.state_dict(), seed=0), strict=True)
     net.eval()
-    seed = 1401
-    x = synth_frames(1, 720, 1280, seed=seed)
-    t0 = time.time()
-    with torch.no_grad():
-        out = net(x)[0]
-    print(f"reference forward at 720p: {time.time() - t0:.0f} s, output range [{out.min():.3f}, {out.max():.3f}]")
-    np.savez_compressed(os.path.join(HERE, "g14_fwd_720p.npz"), seed=seed, sub=out[:, ::8, ::8].numpy(),
-                        mean=out.mean(dim=(1, 2)).numpy(), std=out.std(dim=(1, 2)).numpy())
+    cases = [("g14_fwd_720p", 1401, 1, 720, 1280, ()), ("g15_fwd_720p_noref", 1501, 1, 720, 1280, (0,)),
+             ("g16_fwd_480x640_mixed", 1601, 2, 480, 640, (1,))]
+    only = sys.argv[1:]
+    for name, seed, b, h, w, zero_ref in cases:
+        if only and name not in only:
+            continue
+        x = synth_frames(b, h, w, seed=seed, zero_ref=zero_ref)
+        t0 = time.time()
+        with torch.no_grad():
+            out = net(x)
+        print(f"{name}: reference forward {time.time() - t0:.0f} s, output range [{out.min():.3f}, {out.max():.3f}]")
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), seed=seed, zero_ref=np.array(zero_ref, dtype=np.int64),
+                            sub=out[:, :, ::8, ::8].numpy(), mean=out.mean(dim=(2, 3)).numpy(), std=out.std(dim=(2, 3)).numpy())
 
 
 if __name__ == "__main__":

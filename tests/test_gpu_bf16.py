@@ -367,22 +367,25 @@ def test_full_size_swin_properties(synth_sd):
         assert err < 2e-2, (shift, err)
 
 
-def test_forward_720p_reference_golden(golden_dir, net):
-    """The bench configuration itself (1 x 5 x 3 x 720 x 1280, `_forwardbs`) against the REFERENCE's own output (G14: every 8th
-    pixel of its 720p frame + per-channel statistics, tests/golden/make_golden_720p.py): the f32-grade modes within the 1e-3
-    bound of the small golden cases (the exact-fp32 path and bf16x3), the throughput mode within its documented bound."""
-    d = np.load(os.path.join(golden_dir, "g14_fwd_720p.npz"))
+@pytest.mark.parametrize("name,b,h,w", [("g14_fwd_720p", 1, 720, 1280), ("g15_fwd_720p_noref", 1, 720, 1280),
+                                        ("g16_fwd_480x640_mixed", 2, 480, 640)])
+def test_forward_full_size_reference_golden(golden_dir, net, name, b, h, w):
+    """The full sizes against the REFERENCE's own outputs (tests/golden/make_golden_720p.py: every 8th pixel of its frames +
+    per-channel statistics): the bench configuration (720p, `_forwardbs`), the same through `_forwardb`, and a mixed-routing
+    batch at the BSD size.  The f32-grade modes stay within the 1e-3 bound of the small golden cases (exact fp32 and
+    bf16x3), the throughput mode within its documented bound."""
+    d = np.load(os.path.join(golden_dir, name + ".npz"))
     sub, mean, std = (torch.from_numpy(d[k]) for k in ("sub", "mean", "std"))
-    x = synth_frames(1, 720, 1280, seed=int(d["seed"])).to(DEV)
+    x = synth_frames(b, h, w, seed=int(d["seed"]), zero_ref=tuple(int(i) for i in d["zero_ref"])).to(DEV)
     try:
         for mode, corr, tol in (("f32", "bf16x3", 1e-3), ("bf16x3", "bf16x3", 1e-3), ("bf16", "bf16", 0.05)):
             net.precision, net.corr_precision = mode, corr
             with torch.no_grad():
-                out = net(x)[0].cpu()
-            err = (out[:, ::8, ::8] - sub).abs().max().item()
-            dm = (out.mean(dim=(1, 2)) - mean).abs().max().item()
-            ds = (out.std(dim=(1, 2)) - std).abs().max().item()
-            print(f"720p vs reference, {mode}/{corr}: max |err| on the 8x8 grid {err:.2e}, |d mean| {dm:.1e}, |d std| {ds:.1e}")
+                out = net(x).cpu()
+            err = (out[:, :, ::8, ::8] - sub).abs().max().item()
+            dm = (out.mean(dim=(2, 3)) - mean).abs().max().item()
+            ds = (out.std(dim=(2, 3)) - std).abs().max().item()
+            print(f"{name} vs reference, {mode}/{corr}: max |err| on the 8x8 grid {err:.2e}, |d mean| {dm:.1e}, |d std| {ds:.1e}")
             assert err < tol and dm < tol / 10 and ds < tol / 10, mode
     finally:
         net.precision, net.corr_precision = "f32", "bf16x3"
