@@ -112,3 +112,14 @@ def test_g10_forward(golden_dir, synth_sd, name, b, h, w):
     x = synth_frames(b, h, w, seed=int(d["seed"]), zero_ref=zr)
     out = O.forward(x, synth_sd, O.Cfg())
     close(out, d["out"], 2e-4, 1e-5)
+
+
+def test_g16_forward_480x640_subsampled(golden_dir, synth_sd):
+    """The oracle at the BSD frame size (mixed-routing batch of two; about a minute on 8 threads) against the reference's own
+    output, of which G16 keeps every 8th pixel and the per-channel statistics."""
+    d = np.load(os.path.join(golden_dir, "g16_fwd_480x640_mixed.npz"))
+    x = synth_frames(2, 480, 640, seed=int(d["seed"]), zero_ref=tuple(int(i) for i in d["zero_ref"]))
+    with torch.no_grad():
+        out = O.forward(x, synth_sd)
+    close(out[:, :, ::8, ::8], torch.from_numpy(d["sub"]), 1e-3, 1e-4)
+    assert (out.mean(dim=(2, 3)) - torch.from_numpy(d["mean"])).abs().max().item() < 1e-5
