@@ -385,7 +385,11 @@ def test_forward_full_size_reference_golden(golden_dir, net, name, b, h, w):
             err = (out[:, :, ::8, ::8] - sub).abs().max().item()
             dm = (out.mean(dim=(2, 3)) - mean).abs().max().item()
             ds = (out.std(dim=(2, 3)) - std).abs().max().item()
-            print(f"{name} vs reference, {mode}/{corr}: max |err| on the 8x8 grid {err:.2e}, |d mean| {dm:.1e}, |d std| {ds:.1e}")
-            assert err < tol and dm < tol / 10 and ds < tol / 10, mode
+            # the north-star criterion: PSNR (uint8, 4-pixel crop, against the middle input frame as the stand-in target) of
+            # our frame minus PSNR of the reference's frame: 1e-3 dB for the f32-grade modes
+            dp = max(abs(O.psnr_uint8(O.to_uint8(out[i:i + 1]), O.to_uint8(x[i:i + 1, 1].cpu())) - float(d["psnr"][i])) for i in range(b))
+            print(f"{name} vs reference, {mode}/{corr}: max |err| on the 8x8 grid {err:.2e}, |d mean| {dm:.1e}, |d std| {ds:.1e}, "
+                  f"|dPSNR| {dp:.1e} dB")
+            assert err < tol and dm < tol / 10 and ds < tol / 10 and dp <= (1e-3 if mode != "bf16" else 0.1), mode
     finally:
         net.precision, net.corr_precision = "f32", "bf16x3"
