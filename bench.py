@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=["f32", "bf16x3", "bf16"], default="bf16",
                     help="arithmetic of the GEMM-shaped kernels; BASELINE.json configs[1] is the bf16 forward")
-    ap.add_argument("--corr-precision", choices=["bf16x3", "bf16"], default="bf16",
+    ap.add_argument("--corr-precision", choices=["bf16x3", "bf16", "bf16r"], default="bf16r",
                     help="correlation arg-max products when --precision is not f32 (bf16x3 = f32-grade scores, 2.4x the kernel time)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying one hipGraph per frame")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams for the independent neighbour-frame / reference branches of a frame")
@@ -110,7 +110,6 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run for N > 1", file=sys.stderr)
     dev = torch.device("cuda", local)
 
-    from speinet_amd import ops
     from speinet_amd.speinet import SPEINet, default_args
     from speinet_amd.synth import state_dict_template, synth_frames, synth_state_dict
 
@@ -134,12 +133,11 @@ def main():
     with torch.no_grad():
         for i in range(args.warmup):
             net(frames[i % 2], routing=routing)
-        if not net.use_graph:
-            ops.PROFILE = {"corr_argmax": []}
+        prof = {"corr_argmax": []}
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            out = net(frames[i % 2], routing=routing)
+            out = net(frames[i % 2], routing=routing, profile=None if net.use_graph else prof)
             checksum += out.double().sum()
         barrier()
         dt = time.perf_counter() - t0
@@ -147,13 +145,11 @@ def main():
         # HIP events cannot bracket a node inside a replayed graph: time the dominant kernel on eager launches of the
         # same frames on the same stream, right after the timed region
         net.use_graph = False
-        ops.PROFILE = {"corr_argmax": []}
         with torch.no_grad():
             for i in range(2):
-                net(frames[i % 2], routing=routing)
+                net(frames[i % 2], routing=routing, profile=prof)
         torch.cuda.synchronize()
-    prof = ops.PROFILE["corr_argmax"]
-    ops.PROFILE = None
+    prof = prof["corr_argmax"]
     corr_ms = sum(s.elapsed_time(e) for s, e in prof) / max(1, len(prof))
 
     from speinet_amd.dist import gather_metrics, max_over_ranks

@@ -161,6 +161,18 @@ int spei_corr_slab_bf16(const void* lr_hi, const void* lr_lo, const void* ref_hi
                         const float* inv_lr, const float* inv_ref, int Hl, int Wl, int Hr, int Wr, int C, float* S,
                         int32_t* arg, float* ws, spei_stream_t stream);
 
+/* Exact arg-max at bf16 cost (ops.Ctx corr_precision "bf16r").  spei_corr_slab_top2_bf16: the slab kernel with single
+ * bf16 products keeping the TWO best candidates of every query: arg / arg2 (arg2 = -1: no second candidate) with their
+ * approximate, un-normalised-by-inv_lr scores S / S2.  spei_corr_rescore then re-scores both candidates on the fp32 maps
+ * with fp64 accumulation and overwrites S (= dot * inv_ref[j] * inv_lr[i], fp32) and arg (ties -> lowest index): the
+ * winner no longer depends on bf16 rounding (model/SearchTransfer.py:33-34 computes R in fp32). */
+int spei_corr_slab_top2_bf16(const void* lr_bf16, const void* ref_bf16, const float* inv_lr, const float* inv_ref,
+                             int Hl, int Wl, int Hr, int Wr, int C, float* S, int32_t* arg, float* S2, int32_t* arg2,
+                             float* ws, spei_stream_t stream);
+int spei_corr_rescore(const float* lr, int ldl, const float* ref, int ldr, const float* inv_lr, const float* inv_ref,
+                      int Hl, int Wl, int Hr, int Wr, int C, float* S, int32_t* arg, const float* S2, const int32_t* arg2,
+                      spei_stream_t stream);
+
 /* K12 — gather the best-matching reference patch and overlap-add (unfold -> bis -> fold / 9,
  * model/SearchTransfer.py:36-46).  scale s in {1,2,4}: patch 3s, stride s, pad s. */
 int spei_gather_fold(const float* ref, int ldr, const int32_t* arg, float* out, int ldo, int H3, int W3,

@@ -37,6 +37,8 @@ SIGNATURES = {
     "spei_mlp_fused_bf16": (I, [P, P, P, P, P, P, L, P]),
     "spei_split_bf16": (I, [P, I, P, P, L, I, P]),
     "spei_corr_slab_bf16": (I, [P, P, P, P, P, P, I, I, I, I, I, P, P, P, P]),
+    "spei_corr_slab_top2_bf16": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, P, P]),
+    "spei_corr_rescore": (I, [P, I, P, I, P, P, I, I, I, I, I, P, P, P, P, P]),
     "spei_corr_argmax_bf16": (I, [P, P, P, P, P, P, I, I, I, I, I, P, P, P, P]),
     "spei_gate_ws_floats": (L, [I, I, I]),
     "spei_resblock_gates": (I, [P, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),

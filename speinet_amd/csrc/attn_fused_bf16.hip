@@ -366,7 +366,7 @@ extern "C" int spei_attn_fused_bf16(const float* x, float* out, const void* yhat
     p.bkv = bkv; p.wproj = (const __bf16*)wproj_frag; p.bproj = bproj; p.relbias = relbias;
     p.H = H; p.W = W; p.shift = shift; p.nwin = (H / WS) * (W / WS);
     const size_t lds = (size_t)2 * ROWS * PA + 2 * ROWS * sizeof(int);
-    ensure_dyn_lds(&attn_fused_kernel, lds);
+    ensure_dyn_lds<&attn_fused_kernel>(lds);
     hipLaunchKernelGGL(attn_fused_kernel, dim3((p.nwin + 1) / 2), dim3(256), lds, (hipStream_t)stream, p);
     SPEI_CHECK_LAUNCH("spei_attn_fused_bf16");
     return 0;

@@ -26,17 +26,28 @@ void spei_set_error(const char* fmt, ...);
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Tuning knobs (tile-shape / ablation switches read by tools/ablate_*.py).  The shipping build has NONE: every knob is
+// its compile-time default and the dispatch code folds.  `python -m speinet_amd.build --tuning` defines SPEI_TUNING and
+// lets the named environment variable override the default (read once per process).
+#ifdef SPEI_TUNING
+#include <stdlib.h>
+static inline int spei_knob(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#else
+static constexpr int spei_knob(const char*, int dflt) { return dflt; }
+#endif
+
 // Raise a kernel's dynamic-LDS limit before its first launch with `lds` bytes ON THE CURRENT DEVICE.  The attribute is
 // per device: a process that drives several GPUs (the reference's nn.DataParallel calls forward from one thread per
-// device) must set it on each.  One table per kernel instantiation (the template parameter), keyed by device; the races
+// device) must set it on each.  The KERNEL is the template parameter (a non-type one): one table per kernel
+// instantiation, keyed by device — instantiations that share a function-pointer TYPE do not share a table.  The races
 // are benign (the call is idempotent).
-template <typename K>
-inline void ensure_dyn_lds(K kernel, size_t lds) {
+template <auto Kernel>
+inline void ensure_dyn_lds(size_t lds) {
     static size_t have[32] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 32 || lds > have[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (dev >= 0 && dev < 32) have[dev] = lds;
     }
 }

@@ -385,10 +385,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
 
 template <int WM, int WN, int TM, int TN, bool SPLIT, typename TA, typename TO>
 int launch(const SlabParams& p, size_t lds, hipStream_t s) {
-    ensure_dyn_lds(&conv_slab_kernel<WM, WN, TM, TN, SPLIT, TA, TO>, lds);
+    ensure_dyn_lds<&conv_slab_kernel<WM, WN, TM, TN, SPLIT, TA, TO>>(lds);
     SlabParams q = p;
     q.n_chunks = p.N / (WN * TN * 32);
-    static const int dbg = getenv("SPEI_SLAB_DBG") ? atoi(getenv("SPEI_SLAB_DBG")) : 0;
+    static const int dbg = spei_knob("SPEI_SLAB_DBG", 0);
     q.dbg = dbg;
     dim3 grid(p.tiles_x * cdiv(p.Hout, p.TH), 1);
     hipLaunchKernelGGL((conv_slab_kernel<WM, WN, TM, TN, SPLIT, TA, TO>), grid, dim3(64 * WM * WN), lds, s, q);
@@ -432,7 +432,7 @@ int dispatch(SlabParams& p, hipStream_t s) {
     const size_t hard = 160 * 1024 - 512;
     // 8-wave workgroups (two waves per SIMD share one slab) for the non-split mode; knobs for tools/ablate_slab.py:
     // SPEI_SLAB_W8=<bitmask> 1: N%128 layers, 2: N%64 layers, 4: N=32 layers
-    static const int w8 = getenv("SPEI_SLAB_W8") ? atoi(getenv("SPEI_SLAB_W8")) : 0;
+    static const int w8 = spei_knob("SPEI_SLAB_W8", 0);
     size_t lds;
     if (p.N % 128 == 0) {
         if (!SPLIT && (w8 & 1)) {
@@ -443,7 +443,7 @@ int dispatch(SlabParams& p, hipStream_t s) {
         }
         lds = setup(128);
         const int64_t tiles128 = (int64_t)p.tiles_x * cdiv(p.Hout, p.TH);
-        static const int min_tiles = getenv("SPEI_SLAB_MIN_TILES128") ? atoi(getenv("SPEI_SLAB_MIN_TILES128")) : 0;
+        static const int min_tiles = spei_knob("SPEI_SLAB_MIN_TILES128", 0);
         if (lds <= budget && tiles128 >= min_tiles && p.IH * p.IW < 2048) return launch<1, 4, 4, 1, SPLIT, TA, TO>(p, lds, s);
         lds = setup(64);
         if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 4, 2, 1, SPLIT, TA, TO>(p, lds, s);
@@ -459,7 +459,7 @@ int dispatch(SlabParams& p, hipStream_t s) {
             lds = setup(512);
             if (lds <= hard && p.IH * p.IW < 2048) return launch<8, 1, 2, 1, SPLIT, TA, TO>(p, lds, s);
         }
-        static const int n32_tile = getenv("SPEI_SLAB_N32_TILE") ? atoi(getenv("SPEI_SLAB_N32_TILE")) : 256;
+        static const int n32_tile = spei_knob("SPEI_SLAB_N32_TILE", 256);
         lds = setup(256);
         if (n32_tile == 256 && lds <= budget && p.IH * p.IW < 2048) return launch<4, 1, 2, 1, SPLIT, TA, TO>(p, lds, s);
         lds = setup(128);

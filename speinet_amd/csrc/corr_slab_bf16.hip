@@ -17,7 +17,11 @@
 //   * the MFMA (v_mfma_f32_32x32x16_bf16) puts reference positions on accumulator rows and query positions on
 //     lanes, so the running (max, argmax) over j is per lane, in registers; R (13.3 GB at 720p) never exists.
 // lo == NULL: single bf16 products; lo != NULL: split products al*bh + ah*bl + ah*bh (bf16x3, f32-grade scores).
-#include <stdlib.h>
+// TOP2 (spei_corr_slab_top2_bf16): single bf16 products, but every query keeps its TWO best candidates; the exact
+// winner is then decided by spei_corr_rescore (search.hip) on fp32 features with fp64 accumulation — f32-grade arg-max
+// and S at the cost of the bf16 kernel.  The fold costs what the top-1 fold costs: a candidate is ONE float whose low
+// five mantissa bits carry (31 - row of the 32-row group), so "insert into a sorted pair" is v_max_f32 + v_med3_f32.
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -45,9 +49,22 @@ struct CorrSlabParams {
 
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 
+// top-2 of the union of two pairs, each sorted under `better` (value descending, then index ascending)
+__device__ __forceinline__ void merge2(float& a1, int& i1, float& a2, int& i2, float b1, int j1, float b2, int j2) {
+    if (better(b1, j1, a1, i1)) {
+        const bool s = better(b2, j2, a1, i1);
+        a2 = s ? b2 : a1; i2 = s ? j2 : i1;
+        a1 = b1; i1 = j1;
+    } else {
+        const bool s = better(b1, j1, a2, i2);
+        a2 = s ? b1 : a2; i2 = s ? j1 : i2;
+    }
+}
+
 // NI: query tile rows (x 32 columns); KC: reference channels per stage; SPLIT: bf16x3; WJ: waves along the reference rows
-template <int NI, int KC, bool SPLIT, int WJ>
+template <int NI, int KC, bool SPLIT, int WJ, bool TOP2>
 __global__ __launch_bounds__(128 * WJ) void corr_slab_kernel(const CorrSlabParams p) {
+    static_assert(!(SPLIT && TOP2), "TOP2 is the single-product form");
     constexpr int C = 128;
     constexpr int NT = 128 * WJ;                       // threads
     constexpr int RB_H = 2 * WJ;                       // reference block rows
@@ -96,7 +113,8 @@ __global__ __launch_bounds__(128 * WJ) void corr_slab_kernel(const CorrSlabParam
         if (ch == 0 && tid < RB_H * RB_W) {              // the block's normalisers ride along with its first stage
             const int jy = rby * RB_H + (tid >> 5), jx = rbx * RB_W + (tid & 31);
             // positions outside the map get a NaN normaliser: their scores become NaN and lose every `>` of the fold
-            riv = (jy < p.Hr && jx < p.Wr) ? p.inv_ref[jy * p.Wr + jx] : __builtin_nanf("");
+            // (TOP2: a 0 normaliser marks them; real normalisers are > 0)
+            riv = (jy < p.Hr && jx < p.Wr) ? p.inv_ref[jy * p.Wr + jx] : (TOP2 ? 0.f : __builtin_nanf(""));
         }
 #pragma unroll
         for (int u = 0; u < RLOADS; ++u) {
@@ -134,12 +152,12 @@ __global__ __launch_bounds__(128 * WJ) void corr_slab_kernel(const CorrSlabParam
     for (int j = 0; j < TN; ++j) {                      // query columns: tile pixel (qy, qx) = (wn*TN+j, fr)
         bbase[j] = ((wn * TN + j) * SLAB_W + fr) * PITCH_L + fk * 16;
     }
-    float bestv[TN], il[TN];
-    int besti[TN];
+    float bestv[TN], il[TN], best2v[TN];
+    int besti[TN], best2i[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        bestv[j] = -INFINITY;
-        besti[j] = 0x7fffffff;
+        bestv[j] = best2v[j] = -INFINITY;
+        besti[j] = best2i[j] = 0x7fffffff;
         const int qy = iy0 + wn * TN + j, qx = ix0 + fr;
         il[j] = (qy < p.Hl && qx < p.Wl) ? p.inv_lr[qy * p.Wl + qx] : 0.f;
     }
@@ -220,6 +238,39 @@ __global__ __launch_bounds__(128 * WJ) void corr_slab_kernel(const CorrSlabParam
 #pragma unroll
             for (int row = 0; row < 32; ++row) irv[row] = pinv[(row >> 4) * 32 + (row & 3) + 8 * ((row & 15) >> 2)];
             const int jj0 = (rby * RB_H + wm * 2) * p.Wr + rbx * RB_W + 4 * fk;
+            if constexpr (TOP2) {
+                // sorted pair (lk1 >= lk2) of keys per query column: key = score with (31 - row) in its low 5 mantissa bits
+                // (2^-19 relative, far below the bf16 product error; among equal truncated scores the earlier row wins)
+                const bool edge = (rby * RB_H + RB_H > p.Hr) | (rbx * RB_W + RB_W > p.Wr);     // block-uniform
+                float lk1[TN], lk2[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) lk1[j] = lk2[j] = -INFINITY;
+                auto fold = [&](auto EDGE) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int row = 0; row < 32; ++row) {
+                        const int i = row >> 4, r = row & 15;
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const float v = acc[i][j][r] * irv[row];
+                            float key = __uint_as_float((__float_as_uint(v) & ~31u) | (unsigned)(31 - row));
+                            if (decltype(EDGE)::value) key = irv[row] == 0.f ? -INFINITY : key;      // row outside the map
+                            lk2[j] = __builtin_amdgcn_fmed3f(lk1[j], lk2[j], key);
+                            lk1[j] = fmaxf(lk1[j], key);
+                        }
+                    }
+                };
+                if (edge) fold(std::true_type{}); else fold(std::false_type{});
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    auto pos = [&](float k) __attribute__((always_inline)) {
+                        const int row = 31 - (int)(__float_as_uint(k) & 31u);
+                        return jj0 + (row >> 4) * p.Wr + (row & 3) + 8 * ((row & 15) >> 2);
+                    };
+                    if (lk1[j] > -INFINITY)
+                        merge2(bestv[j], besti[j], best2v[j], best2i[j], lk1[j], pos(lk1[j]), lk2[j],
+                               lk2[j] > -INFINITY ? pos(lk2[j]) : 0x7fffffff);
+                }
+            } else {
             float lbv[TN];
             int lbi[TN];
 #pragma unroll
@@ -241,13 +292,46 @@ __global__ __launch_bounds__(128 * WJ) void corr_slab_kernel(const CorrSlabParam
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 if (lbv[j] > -INFINITY && better(lbv[j], lbi[j], bestv[j], besti[j])) { bestv[j] = lbv[j]; besti[j] = lbi[j]; }
+            }
         }
         __syncthreads();
     }
 
     // ---- combine lane halves, then the two waves (wm) sharing the same query columns ---------------------------
-    float* rv = reinterpret_cast<float*>(smem);            // [WJ][NI*32]
-    int* ri = reinterpret_cast<int*>(smem) + WJ * NI * 32;
+    float* rv = reinterpret_cast<float*>(smem);            // [WJ][NI*32] ([..][2] with TOP2)
+    int* ri = reinterpret_cast<int*>(smem) + (TOP2 ? 2 : 1) * WJ * NI * 32;
+    if constexpr (TOP2) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float o1 = __shfl_xor(bestv[j], 32, 64), o2 = __shfl_xor(best2v[j], 32, 64);
+            const int p1 = __shfl_xor(besti[j], 32, 64), p2 = __shfl_xor(best2i[j], 32, 64);
+            merge2(bestv[j], besti[j], best2v[j], best2i[j], o1, p1, o2, p2);
+            if (fk == 0) {
+                const int col = (wn * TN + j) * 32 + fr;
+                rv[(wm * NI * 32 + col) * 2] = bestv[j];
+                rv[(wm * NI * 32 + col) * 2 + 1] = best2v[j];
+                ri[(wm * NI * 32 + col) * 2] = besti[j];
+                ri[(wm * NI * 32 + col) * 2 + 1] = best2i[j];
+            }
+        }
+        __syncthreads();
+        if (tid < NI * 32) {
+            const int qy = iy0 + (tid >> 5), qx = ix0 + (tid & 31);
+            if (qy < p.Hl && qx < p.Wl) {
+                float v1 = rv[tid * 2], v2 = rv[tid * 2 + 1];
+                int x1 = ri[tid * 2], x2 = ri[tid * 2 + 1];
+#pragma unroll
+                for (int w = 1; w < WJ; ++w) {
+                    const int o = (w * NI * 32 + tid) * 2;
+                    merge2(v1, x1, v2, x2, rv[o], ri[o], rv[o + 1], ri[o + 1]);
+                }
+                const size_t i = ((size_t)blockIdx.y * p.Nl + (qy * p.Wl + qx)) * 2;
+                p.pval[i] = v1; p.pval[i + 1] = v2;
+                p.pidx[i] = x1; p.pidx[i + 1] = x2;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const float ov = __shfl_xor(bestv[j], 32, 64);
@@ -275,6 +359,23 @@ __global__ __launch_bounds__(128 * WJ) void corr_slab_kernel(const CorrSlabParam
     }
 }
 
+// merge the per-split pairs of the TOP2 form: (S, arg) = best candidate, (S2, arg2) = runner-up (arg2 = -1: none)
+__global__ __launch_bounds__(256) void corr_top2_final_kernel(const float* __restrict__ pval, const int32_t* __restrict__ pidx,
+                                                              int splits, int Nl, float* __restrict__ S, int32_t* __restrict__ arg,
+                                                              float* __restrict__ S2, int32_t* __restrict__ arg2) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Nl) return;
+    float v1 = pval[(size_t)i * 2], v2 = pval[(size_t)i * 2 + 1];
+    int x1 = pidx[(size_t)i * 2], x2 = pidx[(size_t)i * 2 + 1];
+    for (int s = 1; s < splits; ++s) {
+        const size_t o = ((size_t)s * Nl + i) * 2;
+        merge2(v1, x1, v2, x2, pval[o], pidx[o], pval[o + 1], pidx[o + 1]);
+    }
+    S[i] = v1; S2[i] = v2;
+    arg[i] = x1 == 0x7fffffff ? 0 : x1;
+    arg2[i] = x2 == 0x7fffffff ? -1 : x2;
+}
+
 __global__ __launch_bounds__(256) void corr_slab_final_kernel(const float* __restrict__ pval, const int32_t* __restrict__ pidx,
                                                               int splits, int Nl, float* __restrict__ S, int32_t* __restrict__ arg) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -290,7 +391,7 @@ __global__ __launch_bounds__(256) void corr_slab_final_kernel(const float* __res
     arg[i] = ix == 0x7fffffff ? 0 : ix;
 }
 
-template <int NI, int KC, bool SPLIT, int WJ>
+template <int NI, int KC, bool SPLIT, int WJ, bool TOP2 = false>
 void launch_corr(const CorrSlabParams& p, int itiles, int splits, hipStream_t st) {
     constexpr int C = 128;
     constexpr int RB_H = 2 * WJ;
@@ -298,21 +399,23 @@ void launch_corr(const CorrSlabParams& p, int itiles, int splits, hipStream_t st
     constexpr int L_BYTES = ((((NI + 2) * SLAB_W) * (2 * C + 16) + 15) / 16) * 16;
     constexpr int R_BYTES = ((((RB_H + 2) * SLAB_W) * (2 * KC + 16) + 15) / 16) * 16;
     const size_t lds = (size_t)NPART * L_BYTES + (size_t)2 * NPART * R_BYTES + (size_t)2 * RB_H * RB_W * sizeof(float);
-    ensure_dyn_lds(&corr_slab_kernel<NI, KC, SPLIT, WJ>, lds);
-    hipLaunchKernelGGL((corr_slab_kernel<NI, KC, SPLIT, WJ>), dim3(itiles, splits), dim3(128 * WJ), lds, st, p);
+    ensure_dyn_lds<&corr_slab_kernel<NI, KC, SPLIT, WJ, TOP2>>(lds);
+    hipLaunchKernelGGL((corr_slab_kernel<NI, KC, SPLIT, WJ, TOP2>), dim3(itiles, splits), dim3(128 * WJ), lds, st, p);
 }
 
 }  // namespace
 
-extern "C" int spei_corr_slab_bf16(const void* lr_hi, const void* lr_lo, const void* ref_hi, const void* ref_lo,
-                                   const float* inv_lr, const float* inv_ref, int Hl, int Wl, int Hr, int Wr, int C,
-                                   float* S, int32_t* arg, float* ws, spei_stream_t stream) {
-    SPEI_REQUIRE(lr_hi && ref_hi && inv_lr && inv_ref && S && arg && ws, "spei_corr_slab_bf16: null pointer");
-    SPEI_REQUIRE((lr_lo == nullptr) == (ref_lo == nullptr), "spei_corr_slab_bf16: lo parts must both be given or both be NULL");
-    SPEI_REQUIRE(C == 128, "spei_corr_slab_bf16: C=%d (128 built)", C);
-    SPEI_REQUIRE(Hl > 0 && Wl > 0 && Hr > 0 && Wr > 0, "spei_corr_slab_bf16: empty map");
-    SPEI_REQUIRE((int64_t)Hl * Wl < (1ll << 30) && (int64_t)Hr * Wr < (1ll << 30), "spei_corr_slab_bf16: map too large");
-    SPEI_REQUIRE(((uintptr_t)lr_hi | (uintptr_t)ref_hi | (uintptr_t)lr_lo | (uintptr_t)ref_lo) % 16 == 0, "spei_corr_slab_bf16: 16-byte alignment required");
+// shared host side of the three forms: bf16 (top-1), bf16x3 (top-1), bf16 top-2
+static int corr_slab_run(const void* lr_hi, const void* lr_lo, const void* ref_hi, const void* ref_lo, const float* inv_lr,
+                         const float* inv_ref, int Hl, int Wl, int Hr, int Wr, int C, float* S, int32_t* arg, float* S2,
+                         int32_t* arg2, float* ws, spei_stream_t stream, const char* who) {
+    const bool top2 = S2 != nullptr;
+    SPEI_REQUIRE(lr_hi && ref_hi && inv_lr && inv_ref && S && arg && ws && (!top2 || arg2), "%s: null pointer", who);
+    SPEI_REQUIRE((lr_lo == nullptr) == (ref_lo == nullptr), "%s: lo parts must both be given or both be NULL", who);
+    SPEI_REQUIRE(C == 128, "%s: C=%d (128 built)", who, C);
+    SPEI_REQUIRE(Hl > 0 && Wl > 0 && Hr > 0 && Wr > 0, "%s: empty map", who);
+    SPEI_REQUIRE((int64_t)Hl * Wl < (1ll << 30) && (int64_t)Hr * Wr < (1ll << 30), "%s: map too large", who);
+    SPEI_REQUIRE(((uintptr_t)lr_hi | (uintptr_t)ref_hi | (uintptr_t)lr_lo | (uintptr_t)ref_lo) % 16 == 0, "%s: 16-byte alignment required", who);
     const bool split = lr_lo != nullptr;
     const int NI = split ? 2 : 4;
     CorrSlabParams p;
@@ -322,8 +425,7 @@ extern "C" int spei_corr_slab_bf16(const void* lr_hi, const void* lr_lo, const v
     p.itiles_x = cdiv(Wl, RB_W);
     const int itiles = p.itiles_x * cdiv(Hl, NI);
     p.rblocks_x = cdiv(Wr, RB_W);
-    static const int wj_bf16 = getenv("SPEI_CORR_WJ") ? atoi(getenv("SPEI_CORR_WJ")) : 4;     // A/B knob: 2 = the 256-thread form
-    const int rb_h = split ? 4 : 2 * wj_bf16;
+    const int rb_h = split ? 4 : 8;                  // 2 * WJ
     p.rblocks = p.rblocks_x * cdiv(Hr, rb_h);
     // split the reference blocks so that the grid fills 256 CUs (one workgroup per CU) with little tail
     int best_s = 1;
@@ -335,13 +437,32 @@ extern "C" int spei_corr_slab_bf16(const void* lr_hi, const void* lr_lo, const v
     }
     p.rb_per_split = cdiv(p.rblocks, best_s);
     const int splits = cdiv(p.rblocks, p.rb_per_split);
+    // workspace (spei_corr_ws_floats = 4 * CMAXSPLIT * Nl words): values, then indices; pairs in the top-2 form
     p.pval = ws;
-    p.pidx = reinterpret_cast<int32_t*>(ws + (size_t)CMAXSPLIT * p.Nl);
+    p.pidx = reinterpret_cast<int32_t*>(ws + (size_t)(top2 ? 2 : 1) * CMAXSPLIT * p.Nl);
     hipStream_t st = (hipStream_t)stream;
     if (split) launch_corr<2, 32, true, 2>(p, itiles, splits, st);
-    else if (wj_bf16 == 4) launch_corr<4, 64, false, 4>(p, itiles, splits, st);
-    else launch_corr<4, 64, false, 2>(p, itiles, splits, st);
-    hipLaunchKernelGGL(corr_slab_final_kernel, dim3(cdiv(p.Nl, 256)), dim3(256), 0, st, p.pval, p.pidx, splits, p.Nl, S, arg);
-    SPEI_CHECK_LAUNCH("spei_corr_slab_bf16");
+    else if (top2) launch_corr<4, 64, false, 4, true>(p, itiles, splits, st);
+    else launch_corr<4, 64, false, 4>(p, itiles, splits, st);
+    if (top2)
+        hipLaunchKernelGGL(corr_top2_final_kernel, dim3(cdiv(p.Nl, 256)), dim3(256), 0, st, p.pval, p.pidx, splits, p.Nl, S, arg, S2, arg2);
+    else
+        hipLaunchKernelGGL(corr_slab_final_kernel, dim3(cdiv(p.Nl, 256)), dim3(256), 0, st, p.pval, p.pidx, splits, p.Nl, S, arg);
+    SPEI_CHECK_LAUNCH(who);
     return 0;
+}
+
+extern "C" int spei_corr_slab_bf16(const void* lr_hi, const void* lr_lo, const void* ref_hi, const void* ref_lo,
+                                   const float* inv_lr, const float* inv_ref, int Hl, int Wl, int Hr, int Wr, int C,
+                                   float* S, int32_t* arg, float* ws, spei_stream_t stream) {
+    return corr_slab_run(lr_hi, lr_lo, ref_hi, ref_lo, inv_lr, inv_ref, Hl, Wl, Hr, Wr, C, S, arg, nullptr, nullptr, ws, stream,
+                         "spei_corr_slab_bf16");
+}
+
+extern "C" int spei_corr_slab_top2_bf16(const void* lr_bf16, const void* ref_bf16, const float* inv_lr, const float* inv_ref,
+                                        int Hl, int Wl, int Hr, int Wr, int C, float* S, int32_t* arg, float* S2, int32_t* arg2,
+                                        float* ws, spei_stream_t stream) {
+    SPEI_REQUIRE(S2 && arg2, "spei_corr_slab_top2_bf16: null pointer");
+    return corr_slab_run(lr_bf16, nullptr, ref_bf16, nullptr, inv_lr, inv_ref, Hl, Wl, Hr, Wr, C, S, arg, S2, arg2, ws, stream,
+                         "spei_corr_slab_top2_bf16");
 }

@@ -218,7 +218,7 @@ template <int BM, int BN, int WM, int WN, int BK, bool SPLIT>
 int launch(const IgemmParams& p, hipStream_t s) {
     constexpr int PITCH = 2 * BK + 16;
     const size_t lds = (size_t)2 * (SPLIT ? 2 : 1) * (BM + BN) * PITCH;
-    ensure_dyn_lds(&igemm_bf16_kernel<BM, BN, WM, WN, BK, SPLIT>, lds);
+    ensure_dyn_lds<&igemm_bf16_kernel<BM, BN, WM, WN, BK, SPLIT>>(lds);
     dim3 grid(cdiv(p.M, BM), p.N / BN);
     hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WM, WN, BK, SPLIT>), grid, dim3(256), lds, s, p);
     SPEI_CHECK_LAUNCH("spei_igemm_bf16");

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmParams p) {
 template <int BM, int BN, int WM, int WN>
 int launch(const IgemmParams& p, hipStream_t s) {
     const size_t lds = (size_t)2 * (BM + BN) * LDSK * sizeof(float);
-    ensure_dyn_lds(&igemm_f32_kernel<BM, BN, WM, WN>, lds);
+    ensure_dyn_lds<&igemm_f32_kernel<BM, BN, WM, WN>>(lds);
     dim3 grid(cdiv(p.M, BM), p.N / BN);
     hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN>), grid, dim3(256), lds, s, p);
     SPEI_CHECK_LAUNCH("spei_igemm_f32");

@@ -250,7 +250,7 @@ extern "C" int spei_mlp_fused_bf16(const float* x, float* out, const void* w1_fr
     MlpParams p;
     p.x = x; p.out = out; p.w1 = (const __bf16*)w1_frag; p.b1 = b1; p.w2 = (const __bf16*)w2_frag; p.b2 = b2; p.M = (int)M;
     const size_t lds = (size_t)2 * MT * PA + HID * sizeof(float);
-    ensure_dyn_lds(&mlp_fused_kernel, lds);
+    ensure_dyn_lds<&mlp_fused_kernel>(lds);
     hipLaunchKernelGGL(mlp_fused_kernel, dim3(cdiv(M, MT)), dim3(512), lds, (hipStream_t)stream, p);
     SPEI_CHECK_LAUNCH("spei_mlp_fused_bf16");
     return 0;

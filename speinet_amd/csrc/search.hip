@@ -217,6 +217,55 @@ __global__ __launch_bounds__(256) void corr_final_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------
+// exact re-score of the two best candidates of the bf16 pass (spei_corr_slab_top2_bf16): one wave per query,
+// fp32 features, products and sums in fp64 (1152 terms each) — the winner and S no longer depend on bf16 rounding
+// or on any summation order.  S = dot * inv_ref[j] * inv_lr[i] as in corr_argmax_kernel; ties -> lowest index.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void corr_rescore_kernel(const float* __restrict__ lr, int ldl, const float* __restrict__ ref, int ldr,
+                                                           const float* __restrict__ inv_lr, const float* __restrict__ inv_ref,
+                                                           int Hl, int Wl, int Hr, int Wr, int C, float* __restrict__ S,
+                                                           int32_t* __restrict__ arg, const int32_t* __restrict__ arg2) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= (int64_t)Hl * Wl) return;
+    const int qy = (int)(q / Wl), qx = (int)(q - (int64_t)qy * Wl);
+    int cand[2] = {arg[q], arg2[q]};
+    const int nc = cand[1] >= 0 ? 2 : 1;
+    double d[2] = {0.0, 0.0};
+    for (int t = 0; t < 9; ++t) {
+        const int ty = t / 3 - 1, tx = t - (t / 3) * 3 - 1;
+        const int y = qy + ty, x = qx + tx;
+        if (y < 0 || y >= Hl || x < 0 || x >= Wl) continue;          // zero-padded unfold: the term vanishes
+        const float* a = lr + ((size_t)y * Wl + x) * ldl;
+        for (int k = 0; k < nc; ++k) {
+            const int cy = cand[k] / Wr + ty, cx = cand[k] % Wr + tx;
+            if (cy < 0 || cy >= Hr || cx < 0 || cx >= Wr) continue;
+            const float* b = ref + ((size_t)cy * Wr + cx) * ldr;
+            double acc = 0.0;
+            for (int c = lane * 2; c < C; c += 128) {
+                const float2 av = *reinterpret_cast<const float2*>(a + c);
+                const float2 bv = *reinterpret_cast<const float2*>(b + c);
+                acc += (double)av.x * (double)bv.x + (double)av.y * (double)bv.y;
+            }
+            d[k] += acc;
+        }
+    }
+    for (int k = 0; k < 2; ++k)
+        for (int m = 32; m >= 1; m >>= 1) d[k] += __shfl_xor(d[k], m, 64);
+    if (lane == 0) {
+        const double s0 = d[0] * (double)inv_ref[cand[0]];
+        int win = cand[0];
+        double sw = s0;
+        if (nc == 2) {
+            const double s1 = d[1] * (double)inv_ref[cand[1]];
+            if (s1 > s0 || (s1 == s0 && cand[1] < cand[0])) { win = cand[1]; sw = s1; }
+        }
+        S[q] = (float)(sw * (double)inv_lr[q]);
+        arg[q] = win;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // gather + fold: out[y][x] = (1/9) sum over the 3x3 patches q covering (y,x) of ref[patch(arg[q]) at the same
 // in-patch offset]; patch 3s x 3s, stride s, pad s  (unfold -> bis -> fold, SearchTransfer.py:36-46)
 // ---------------------------------------------------------------------------------------------------
@@ -260,7 +309,7 @@ extern "C" int spei_patch_invnorm(const float* f, int ldf, float* inv, int H, in
     return 0;
 }
 
-extern "C" int64_t spei_corr_ws_floats(int64_t n_lr) { return 2 * (int64_t)CMAXSPLIT * n_lr; }
+extern "C" int64_t spei_corr_ws_floats(int64_t n_lr) { return 4 * (int64_t)CMAXSPLIT * n_lr; }   // top-2 form: pairs
 
 extern "C" int spei_corr_argmax(const float* lr, int ldl, const float* ref, int ldr, const float* inv_lr,
                                 const float* inv_ref, int Hl, int Wl, int Hr, int Wr, int C, float* S, int32_t* arg,
@@ -285,11 +334,25 @@ extern "C" int spei_corr_argmax(const float* lr, int ldl, const float* ref, int 
     p.pval = ws;
     p.pidx = reinterpret_cast<int32_t*>(ws + (size_t)CMAXSPLIT * p.Nl);
     const size_t lds = (size_t)2 * (CBM + CBN) * CLD * sizeof(float);
-    ensure_dyn_lds(&corr_argmax_kernel, lds);
+    ensure_dyn_lds<&corr_argmax_kernel>(lds);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(corr_argmax_kernel, dim3(itiles, splits), dim3(256), lds, st, p);
     hipLaunchKernelGGL(corr_final_kernel, dim3(cdiv(p.Nl, 256)), dim3(256), 0, st, p.pval, p.pidx, splits, p.Nl, S, arg);
     SPEI_CHECK_LAUNCH("spei_corr_argmax");
+    return 0;
+}
+
+extern "C" int spei_corr_rescore(const float* lr, int ldl, const float* ref, int ldr, const float* inv_lr, const float* inv_ref,
+                                 int Hl, int Wl, int Hr, int Wr, int C, float* S, int32_t* arg, const float* S2, const int32_t* arg2,
+                                 spei_stream_t stream) {
+    (void)S2;     // the runner-up's bf16 score is not needed: both candidates are re-scored exactly
+    SPEI_REQUIRE(lr && ref && inv_lr && inv_ref && S && arg && arg2, "spei_corr_rescore: null pointer");
+    SPEI_REQUIRE(C > 0 && C % 2 == 0 && ldl % 2 == 0 && ldr % 2 == 0 && ldl >= C && ldr >= C, "spei_corr_rescore: C=%d ldl=%d ldr=%d", C, ldl, ldr);
+    SPEI_REQUIRE(Hl > 0 && Wl > 0 && Hr > 0 && Wr > 0, "spei_corr_rescore: empty map");
+    SPEI_REQUIRE(((uintptr_t)lr | (uintptr_t)ref) % 8 == 0, "spei_corr_rescore: 8-byte alignment required");
+    hipLaunchKernelGGL(corr_rescore_kernel, dim3(cdiv((int64_t)Hl * Wl, 4)), dim3(256), 0, (hipStream_t)stream, lr, ldl, ref, ldr, inv_lr,
+                       inv_ref, Hl, Wl, Hr, Wr, C, S, arg, arg2);
+    SPEI_CHECK_LAUNCH("spei_corr_rescore");
     return 0;
 }
 

@@ -240,7 +240,7 @@ template <int BK, bool SPLIT>
 int launch_corr(const CorrParams& p, int itiles, int splits, hipStream_t st) {
     constexpr int PITCH = 2 * BK + 16;
     const size_t lds = (size_t)2 * 2 * (SPLIT ? 2 : 1) * 128 * PITCH;
-    ensure_dyn_lds(&corr_bf16_kernel<BK, SPLIT>, lds);
+    ensure_dyn_lds<&corr_bf16_kernel<BK, SPLIT>>(lds);
     hipLaunchKernelGGL((corr_bf16_kernel<BK, SPLIT>), dim3(itiles, splits), dim3(256), lds, st, p);
     return 0;
 }

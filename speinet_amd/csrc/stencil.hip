@@ -235,7 +235,7 @@ extern "C" int spei_conv5_out(const float* in_hwc, int ldi, const float* w, cons
     SPEI_REQUIRE(in_hwc && w && bias && out_chw && H > 0 && W > 0, "spei_conv5_out: bad arguments");
     SPEI_REQUIRE(Cin == 32 && ldi % 4 == 0 && ldi >= 32, "spei_conv5_out: Cin=%d ldi=%d (only n_feat=32 is built)", Cin, ldi);
     const size_t lds = ((size_t)(CO_TH + 4) * (CO_TW + 4) * CO_P + 3 * 25 * 32) * sizeof(float);
-    ensure_dyn_lds(&conv5_out_kernel, lds);
+    ensure_dyn_lds<&conv5_out_kernel>(lds);
     hipLaunchKernelGGL(conv5_out_kernel, dim3(cdiv(W, CO_TW), cdiv(H, CO_TH)), dim3(256), lds, (hipStream_t)stream,
                        in_hwc, ldi, w, bias, out_chw, H, W);
     SPEI_CHECK_LAUNCH("spei_conv5_out");

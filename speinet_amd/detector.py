@@ -29,21 +29,25 @@ def focus_measures(frames: torch.Tensor, kernel_size: int = 11) -> torch.Tensor:
     n, c, h, w = frames.shape
     assert c == 3
     lib = _lib.lib()
-    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    gray = torch.empty(n, h, w, device=frames.device)
-    _lib.check(lib.spei_det_gray(C.c_void_p(frames.data_ptr()), C.c_void_p(gray.data_ptr()), n, h, w, st), "spei_det_gray")
-    return gray_focus_measures(gray, kernel_size)
+    with torch.cuda.device(frames.device):       # kernels launch on the current device: make it the tensor's
+        st = C.c_void_p(torch.cuda.current_stream(frames.device).cuda_stream)
+        gray = torch.empty(n, h, w, device=frames.device)
+        _lib.check(lib.spei_det_gray(C.c_void_p(frames.data_ptr()), C.c_void_p(gray.data_ptr()), n, h, w, st), "spei_det_gray")
+        return gray_focus_measures(gray, kernel_size)
 
 
 def gray_focus_measures(gray: torch.Tensor, kernel_size: int = 11) -> torch.Tensor:
+    if not gray.is_cuda:
+        raise RuntimeError("speinet_amd.detector runs on MI355X only (HIP kernels); there is no CPU path")
     gray = gray.contiguous().float()
     n, h, w = gray.shape
     lib = _lib.lib()
-    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    out = torch.empty(n, 6, device=gray.device)
-    ws = torch.empty(lib.spei_det_ws_floats(n, h, w, kernel_size), device=gray.device)
-    _lib.check(lib.spei_det_features(C.c_void_p(gray.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), n, h, w,
-                                     kernel_size, st), "spei_det_features")
+    with torch.cuda.device(gray.device):
+        st = C.c_void_p(torch.cuda.current_stream(gray.device).cuda_stream)
+        out = torch.empty(n, 6, device=gray.device)
+        ws = torch.empty(lib.spei_det_ws_floats(n, h, w, kernel_size), device=gray.device)
+        _lib.check(lib.spei_det_features(C.c_void_p(gray.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), n, h, w,
+                                         kernel_size, st), "spei_det_features")
     return out
 
 

@@ -1,64 +1,67 @@
 """The per-sequence forward pass as a sequence of HIP kernel launches (one sample at a time).
 
 Mirrors reference model/speinet.py:75-148 (`_process`, `_decode`, `_forwardbs`, `_forwardb`); every step is a
-call into the C-ABI through speinet_amd.ops.  Feature maps stay NHWC fp32 in HBM between kernels; channel
+call into the C-ABI through a `speinet_amd.ops.Ctx` (the call's arithmetic mode / device; no global state).  Feature maps stay NHWC fp32 in HBM between kernels; channel
 concatenations are never materialised (two-source GEMM operands, strided output views).
 """
 from __future__ import annotations
 
 import torch
 
-from . import ops
-from .ops import ACT_GELU, ACT_RELU, CONV_T, FMap
+from .ops import ACT_GELU, ACT_RELU, CONV_T, Ctx, FMap
 
 
 # ---- encoder / decoder stacks (reference model/recons_video_ori.py:26-77) -----------------------------
-def _resblocks(f: FMap, blocks, extra=None, out=None) -> FMap:
+def _resblocks(ctx: Ctx, f: FMap, blocks, extra=None, out=None) -> FMap:
     n = len(blocks)
     for i, pk in enumerate(blocks):
         last = i == n - 1
-        f = ops.resblock(f, pk, extra=extra if last else None, out=out if last else None)
+        f = ctx.resblock(f, pk, extra=extra if last else None, out=out if last else None)
     return f
 
 
-def in_block(frame: torch.Tensor, pk: dict) -> FMap:
-    return _resblocks(ops.conv5_in(frame, pk["head_w"], pk["head_b"]), pk["blocks"])
+def in_block(ctx: Ctx, frame: torch.Tensor, pk: dict) -> FMap:
+    ctx = ctx.for_stage("enc")
+    return _resblocks(ctx, ctx.conv5_in(frame, pk["head_w"], pk["head_b"]), pk["blocks"])
 
 
-def enc_stage(f: FMap, pk: dict, extra=None, out=None) -> FMap:
+def enc_stage(ctx: Ctx, f: FMap, pk: dict, extra=None, out=None) -> FMap:
+    ctx = ctx.for_stage("enc")
     n = pk["head_b"].numel()
-    f = ops.igemm(f, pk["head_w"], pk["head_b"], n, ksize=5, stride=2, act=ACT_RELU)
-    return _resblocks(f, pk["blocks"], extra, out)
+    f = ctx.igemm(f, pk["head_w"], pk["head_b"], n, ksize=5, stride=2, act=ACT_RELU)
+    return _resblocks(ctx, f, pk["blocks"], extra, out)
 
 
-def enc(frame: torch.Tensor, P: dict, extra=None, out=None) -> FMap:
+def enc(ctx: Ctx, frame: torch.Tensor, P: dict, extra=None, out=None) -> FMap:
     """encoder_second(encoder_first(inBlock(frame)))  [+ extra, fused into the last ResBlock's apply]."""
-    return enc_stage(enc_stage(in_block(frame, P["inBlock"]), P["encoder_first"]), P["encoder_second"], extra, out)
+    return enc_stage(ctx, enc_stage(ctx, in_block(ctx, frame, P["inBlock"]), P["encoder_first"]), P["encoder_second"], extra, out)
 
 
-def dec_stage(f: FMap, pk: dict) -> FMap:
-    f = _resblocks(f, pk["blocks"])
-    return ops.igemm(f, pk["tail_w"], pk["tail_b"], pk["tail_b"].numel(), ksize=3, stride=2, mode=CONV_T, act=ACT_RELU)
+def dec_stage(ctx: Ctx, f: FMap, pk: dict) -> FMap:
+    f = _resblocks(ctx, f, pk["blocks"])
+    return ctx.igemm(f, pk["tail_w"], pk["tail_b"], pk["tail_b"].numel(), ksize=3, stride=2, mode=CONV_T, act=ACT_RELU)
 
 
 # ---- cross-window-attention SwinIR (reference model/swinir.py:763-810) ---------------------------------
 class SwinX:
     """x-side tensors shared by the two swin calls of one frame: conv_first(f_mid) and its patch-embed LN."""
 
-    def __init__(self, f_mid: FMap, sw: dict):
+    def __init__(self, ctx: Ctx, f_mid: FMap, sw: dict):
+        ctx = ctx.for_stage("swin")
         self.f_mid = f_mid
-        self.x_first = ops.igemm(f_mid, sw["conv_first_w"], sw["conv_first_b"], 256, ksize=3)
-        self.xt0 = ops.layernorm(self.x_first.t, sw["pe_g"], sw["pe_b"])
+        self.x_first = ctx.igemm(f_mid, sw["conv_first_w"], sw["conv_first_b"], 256, ksize=3)
+        self.xt0 = ctx.layernorm(self.x_first.t, sw["pe_g"], sw["pe_b"])
 
 
-def swin(sx: SwinX, feat: FMap, sw: dict, out: FMap) -> FMap:
+def swin(ctx: Ctx, sx: SwinX, feat: FMap, sw: dict, out: FMap) -> FMap:
+    ctx = ctx.for_stage("swin")
     h, w = feat.H, feat.W
     m = h * w
     dev = feat.t.device
-    y_first = ops.igemm(feat, sw["conv_first_w"], sw["conv_first_b"], 256, ksize=3)
-    yt = ops.layernorm(y_first.t, sw["pe_g"], sw["pe_b"])
-    idt = ops.inter_dtype()                       # bf16 in the throughput mode: these tensors only feed GEMMs / attention
-    yhat = ops.layernorm(yt, out_dtype=idt)       # norm1(y) without affine; gamma/beta live in wq/bq (pack.py)
+    y_first = ctx.igemm(feat, sw["conv_first_w"], sw["conv_first_b"], 256, ksize=3)
+    yt = ctx.layernorm(y_first.t, sw["pe_g"], sw["pe_b"])
+    idt = ctx.inter_dtype()                       # bf16 in the throughput mode: these tensors only feed GEMMs / attention
+    yhat = ctx.layernorm(yt, out_dtype=idt)       # norm1(y) without affine; gamma/beta live in wq/bq (pack.py)
     del y_first, yt
     r = sx.xt0.clone()                            # RSTB input / running residual
     bufs = [torch.empty(m, 256, device=dev), torch.empty(m, 256, device=dev)]
@@ -72,102 +75,103 @@ def swin(sx: SwinX, feat: FMap, sw: dict, out: FMap) -> FMap:
         for bi, bk in enumerate(layer["blocks"]):
             shift = 0 if bi % 2 == 0 else 2
             nxt = bufs[bi % 2]
-            if ops.attn_fused_available():
-                ops.attn_fused(cur, yhat, bk, h, w, shift, out=nxt)               # whole attention branch, one kernel
+            if ctx.attn_fused_available():
+                ctx.attn_fused(cur, yhat, bk, h, w, shift, out=nxt)               # whole attention branch, one kernel
             else:
-                if ops.ln_fused_available():
-                    ops.linear(cur, bk["wkv"], bk["bkv"], out=kv, ln_input=True)  # norm1 inside the GEMM's staging
+                if ctx.ln_fused_available():
+                    ctx.linear(cur, bk["wkv"], bk["bkv"], out=kv, ln_input=True)  # norm1 inside the GEMM's staging
                 else:
-                    ops.layernorm(cur, out=xh)
-                    ops.linear(xh, bk["wkv"], bk["bkv"], out=kv)
-                ops.linear(yhat, bk["wq"], bk["bq"], out=q)
-                ops.window_attention(q, kv, bk["relbias"], h, w, shift, out=att)
-                ops.linear(att, bk["wproj"], bk["bproj"], residual=cur, out=nxt)
-            if ops.mlp_fused_available():
-                ops.mlp_fused(nxt, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out=nxt)
+                    ctx.layernorm(cur, out=xh)
+                    ctx.linear(xh, bk["wkv"], bk["bkv"], out=kv)
+                ctx.linear(yhat, bk["wq"], bk["bq"], out=q)
+                ctx.window_attention(q, kv, bk["relbias"], h, w, shift, out=att)
+                ctx.linear(att, bk["wproj"], bk["bproj"], residual=cur, out=nxt)
+            if ctx.mlp_fused_available():
+                ctx.mlp_fused(nxt, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out=nxt)
             else:
-                if ops.ln_fused_available():
-                    ops.linear(nxt, bk["w1"], bk["b1"], act=ACT_GELU, out=hid, ln_input=True)
+                if ctx.ln_fused_available():
+                    ctx.linear(nxt, bk["w1"], bk["b1"], act=ACT_GELU, out=hid, ln_input=True)
                 else:
-                    ops.layernorm(nxt, out=xh)
-                    ops.linear(xh, bk["w1"], bk["b1"], act=ACT_GELU, out=hid)
-                ops.linear(hid, bk["w2"], bk["b2"], residual=nxt, out=nxt)
+                    ctx.layernorm(nxt, out=xh)
+                    ctx.linear(xh, bk["w1"], bk["b1"], act=ACT_GELU, out=hid)
+                ctx.linear(hid, bk["w2"], bk["b2"], residual=nxt, out=nxt)
             cur = nxt
         # RSTB: conv3x3(blocks(x)) + x   (swinir.py:483-484), in place on the residual buffer
         rf = FMap(r, h, w, 256)
-        ops.igemm(FMap(cur, h, w, 256), layer["conv_w"], layer["conv_b"], 256, ksize=3, residual=rf, out=rf)
-    xt = ops.layernorm(r, sw["norm_g"], sw["norm_b"])
-    res = ops.igemm(FMap(xt, h, w, 256), sw["cab_w"], sw["cab_b"], 256, ksize=3, residual=sx.x_first)
-    return ops.igemm(res, sw["conv_last_w"], sw["conv_last_b"], 128, ksize=3, residual=sx.f_mid, out=out)
+        ctx.igemm(FMap(cur, h, w, 256), layer["conv_w"], layer["conv_b"], 256, ksize=3, residual=rf, out=rf)
+    xt = ctx.layernorm(r, sw["norm_g"], sw["norm_b"])
+    res = ctx.igemm(FMap(xt, h, w, 256), sw["cab_w"], sw["cab_b"], 256, ksize=3, residual=sx.x_first)
+    return ctx.igemm(res, sw["conv_last_w"], sw["conv_last_b"], 128, ksize=3, residual=sx.f_mid, out=out)
 
 
 # ---- SearchTransfer / SelfTransfer (reference model/SearchTransfer.py) ---------------------------------
-def search_transfer(f_fusion: FMap, lv1: FMap, lv2: FMap, lv3: FMap, return_arg=False):
-    inv_l = ops.patch_invnorm(f_fusion)
-    inv_r = ops.patch_invnorm(lv3)
-    s, arg = ops.corr_argmax(f_fusion, lv3, inv_l, inv_r)
+def search_transfer(ctx: Ctx, f_fusion: FMap, lv1: FMap, lv2: FMap, lv3: FMap, return_arg=False):
+    ctx = ctx.for_stage("search")
+    inv_l = ctx.patch_invnorm(f_fusion)
+    inv_r = ctx.patch_invnorm(lv3)
+    s, arg = ctx.corr_argmax(f_fusion, lv3, inv_l, inv_r)
+    if ctx.capture is not None:
+        ctx.capture.update(arg=arg, s=s)
     h3, w3 = f_fusion.H, f_fusion.W
-    t3 = ops.gather_fold(lv3, arg, h3, w3, lv3.H, lv3.W, 1)
-    t2 = ops.gather_fold(lv2, arg, h3, w3, lv3.H, lv3.W, 2)
-    t1 = ops.gather_fold(lv1, arg, h3, w3, lv3.H, lv3.W, 4)
+    t3 = ctx.gather_fold(lv3, arg, h3, w3, lv3.H, lv3.W, 1)
+    t2 = ctx.gather_fold(lv2, arg, h3, w3, lv3.H, lv3.W, 2)
+    t1 = ctx.gather_fold(lv1, arg, h3, w3, lv3.H, lv3.W, 4)
     if return_arg:
         return s, t3, t2, t1, arg
     return s, t3, t2, t1
 
 
-def self_transfer(f_fusion: FMap, P: dict):
-    ref = ops.rot90(f_fusion)
-    s, _ = ops.corr_argmax(f_fusion, ref, ops.patch_invnorm(f_fusion), ops.patch_invnorm(ref))
+def self_transfer(ctx: Ctx, f_fusion: FMap, P: dict):
+    ctx = ctx.for_stage("search")
+    ref = ctx.rot90(f_fusion)
+    s, _ = ctx.corr_argmax(f_fusion, ref, ctx.patch_invnorm(f_fusion), ctx.patch_invnorm(ref))
+    if ctx.capture is not None:
+        ctx.capture.update(s_self=s)
     p1, p2 = P["SelfTransfer.search1"], P["SelfTransfer.search2"]
-    t2 = ops.up_conv1x1_relu(f_fusion, p1["w"], p1["b"], 64)
-    t1 = ops.up_conv1x1_relu(t2, p2["w"], p2["b"], 32)
+    t2 = ctx.up_conv1x1_relu(f_fusion, p1["w"], p1["b"], 64)
+    t1 = ctx.up_conv1x1_relu(t2, p2["w"], p2["b"], 32)
     return s, f_fusion, t2, t1
 
 
 # ---- decode (reference model/speinet.py:92-120) -----------------------------------------------------------
-def decode(ff: FMap, s: torch.Tensor, t3: FMap, t2: FMap, t1: FMap, P: dict, out: torch.Tensor) -> torch.Tensor:
+def decode(ctx: Ctx, ff: FMap, s: torch.Tensor, t3: FMap, t2: FMap, t1: FMap, P: dict, out: torch.Tensor) -> torch.Tensor:
+    ctx = ctx.for_stage("decode")
     c = lambda name: (P[name]["w"], P[name]["b"])
     h3, w3 = ff.H, ff.W
     smap = FMap(s.view(h3 * w3, 1), h3, w3, 1)
-    f_lv3 = ops.igemm(ff, *c("conv_lv3"), 128, a1=t3, rowscale=s, residual=ff)
-    dec2 = dec_stage(f_lv3, P["decoder_second"])
-    s2 = ops.upsample(smap, 2).t.view(-1)
-    f_lv2 = ops.igemm(dec2, *c("conv_lv2"), 64, a1=t2, rowscale=s2, residual=dec2)
-    s1 = ops.up_conv1x1_relu(f_lv3, *c("search1"), 64)
-    sr2 = ops.igemm(f_lv2, *c("search3"), 64, ksize=3, act=ACT_RELU)
-    f_v3 = ops.igemm(dec2, *c("search2"), 64, a1=s1, act=ACT_RELU, residual=dec2)
-    f_lv2 = ops.igemm(f_lv2, *c("search2"), 64, a1=sr2, act=ACT_RELU, residual=f_lv2)
-    dec1 = dec_stage(f_lv2, P["decoder_first"])
-    s4 = ops.upsample(smap, 4).t.view(-1)
-    f_lv1 = ops.igemm(dec1, *c("conv_lv1"), 32, a1=t1, rowscale=s4, residual=dec1)
-    s13 = ops.up_conv1x1_relu(f_v3, *c("search13"), 32)
-    s23 = ops.igemm(ops.upsample(f_lv2, 2), *c("search33"), 32, ksize=3, act=ACT_RELU)
-    s33 = ops.igemm(f_lv1, *c("search43"), 32, ksize=3, act=ACT_RELU)
-    acc = ops.igemm(s13, *c("search33"), 32, ksize=3, a1=s23, act=ACT_RELU, residual=f_lv1)
-    ops.igemm(s13, *c("search33"), 32, ksize=3, a1=s33, act=ACT_RELU, residual=acc, out=acc)
-    ops.igemm(s23, *c("search33"), 32, ksize=3, a1=s33, act=ACT_RELU, residual=acc, out=acc)
+    f_lv3 = ctx.igemm(ff, *c("conv_lv3"), 128, a1=t3, rowscale=s, residual=ff)
+    dec2 = dec_stage(ctx, f_lv3, P["decoder_second"])
+    s2 = ctx.upsample(smap, 2).t.view(-1)
+    f_lv2 = ctx.igemm(dec2, *c("conv_lv2"), 64, a1=t2, rowscale=s2, residual=dec2)
+    s1 = ctx.up_conv1x1_relu(f_lv3, *c("search1"), 64)
+    sr2 = ctx.igemm(f_lv2, *c("search3"), 64, ksize=3, act=ACT_RELU)
+    f_v3 = ctx.igemm(dec2, *c("search2"), 64, a1=s1, act=ACT_RELU, residual=dec2)
+    f_lv2 = ctx.igemm(f_lv2, *c("search2"), 64, a1=sr2, act=ACT_RELU, residual=f_lv2)
+    dec1 = dec_stage(ctx, f_lv2, P["decoder_first"])
+    s4 = ctx.upsample(smap, 4).t.view(-1)
+    f_lv1 = ctx.igemm(dec1, *c("conv_lv1"), 32, a1=t1, rowscale=s4, residual=dec1)
+    s13 = ctx.up_conv1x1_relu(f_v3, *c("search13"), 32)
+    s23 = ctx.igemm(ctx.upsample(f_lv2, 2), *c("search33"), 32, ksize=3, act=ACT_RELU)
+    s33 = ctx.igemm(f_lv1, *c("search43"), 32, ksize=3, act=ACT_RELU)
+    acc = ctx.igemm(s13, *c("search33"), 32, ksize=3, a1=s23, act=ACT_RELU, residual=f_lv1)
+    ctx.igemm(s13, *c("search33"), 32, ksize=3, a1=s33, act=ACT_RELU, residual=acc, out=acc)
+    ctx.igemm(s23, *c("search33"), 32, ksize=3, a1=s33, act=ACT_RELU, residual=acc, out=acc)
     ob = P["outBlock"]
-    f = _resblocks(acc, ob["blocks"])
-    return ops.conv5_out(f, ob["tail_w"], ob["tail_b"], out, ob.get("tail_w32"), ob.get("tail_b32"))
+    f = _resblocks(ctx, acc, ob["blocks"])
+    return ctx.conv5_out(f, ob["tail_w"], ob["tail_b"], out, ob.get("tail_w32"), ob.get("tail_b32"))
 
 
 # ---- one sample --------------------------------------------------------------------------------------------
 # The neighbour-frame branches (2 encoder passes + one swin each) and the reference-frame encoder are independent of
-# each other: with STREAMS > 1 they are issued round-robin on HIP side streams (fork after conv_first(f_mid), join before
-# the `fusion` conv).  Every kernel of the path leaves CUs idle in its last partial round of workgroups and in its
+# each other: with more than one lane they are issued round-robin on HIP side streams (fork after conv_first(f_mid), join
+# before the `fusion` conv).  Every kernel of the path leaves CUs idle in its last partial round of workgroups and in its
 # load / store phases; a second stream's kernels fill those.  Captured into the frame's hipGraph as parallel branches.
-STREAMS = 1
-_side_streams: dict = {}
+# `sides`: the side streams (owned by the calling model, per device); the current stream of ctx.device is the main lane.
+def _lanes(ctx: Ctx, sides) -> list:
+    return [torch.cuda.current_stream(ctx.device)] + list(sides or ())
 
 
-def _sides(dev, n: int) -> list:
-    key = (dev.index, n)
-    if key not in _side_streams:
-        _side_streams[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
-    return _side_streams[key]
-
-
-def forward_sample(x: torch.Tensor, P: dict, n_seq: int, has_ref: bool, out: torch.Tensor) -> torch.Tensor:
+def forward_sample(ctx: Ctx, x: torch.Tensor, P: dict, n_seq: int, has_ref: bool, out: torch.Tensor, sides=()) -> torch.Tensor:
     """x [n_seq+2, 3, H, W] (contiguous, cuda) -> out [3, H, W].
 
     f_mid, the neighbour-frame swin fusions and the 1x1 `fusion` conv (speinet.py:75-90,129-134), then
@@ -175,21 +179,19 @@ def forward_sample(x: torch.Tensor, P: dict, n_seq: int, has_ref: bool, out: tor
     h, w = x.shape[-2:]
     h3, w3 = h // 4, w // 4
     dev = x.device
-    main = torch.cuda.current_stream(dev)
-    lanes = [main] + (_sides(dev, STREAMS - 1) if STREAMS > 1 else [])
+    lanes = _lanes(ctx, sides)
+    main = lanes[0]
     for s_ in lanes[1:]:
         s_.wait_stream(main)                      # fork: the input frames (and anything before them) are ready
     lv = None
     if has_ref:                                   # sharp-reference pyramid: last lane, ahead of its neighbour frames
         with torch.cuda.stream(lanes[-1]):
-            lv1 = in_block(x[n_seq + 1], P["inBlock"])
-            lv2 = enc_stage(lv1, P["encoder_first"])
-            lv = (lv1, lv2, enc_stage(lv2, P["encoder_second"]))
+            lv = reference_pyramid(ctx, x[n_seq + 1], P)
     cat = FMap(torch.empty(h3 * w3, 128 * n_seq, device=dev), h3, w3, 128 * n_seq)
     mid = x[n_seq // 2]
-    e0 = enc(mid, P)
-    f_mid = enc(ops.rl_prior(mid, 5, 0.01), P, extra=e0, out=cat.view(0, 128))
-    sx = SwinX(f_mid, P["swin"])
+    e0 = enc(ctx, mid, P)
+    f_mid = enc(ctx, ctx.rl_prior(mid, 5, 0.01), P, extra=e0, out=cat.view(0, 128))
+    sx = SwinX(ctx, f_mid, P["swin"])
     ready = torch.cuda.Event()
     ready.record(main)
     for slot, i in enumerate([i for i in range(n_seq) if i != n_seq // 2], start=1):
@@ -197,19 +199,23 @@ def forward_sample(x: torch.Tensor, P: dict, n_seq: int, has_ref: bool, out: tor
         if lane is not main:
             lane.wait_event(ready)
         with torch.cuda.stream(lane):
-            e = enc(x[i], P)
-            feat = enc(ops.rl_prior(x[i], 1, 0.01), P, extra=e)
-            swin(sx, feat, P["swin"], out=cat.view(128 * slot, 128))
+            e = enc(ctx, x[i], P)
+            feat = enc(ctx, ctx.rl_prior(x[i], 1, 0.01), P, extra=e)
+            swin(ctx, sx, feat, P["swin"], out=cat.view(128 * slot, 128))
             del e, feat
     for s_ in lanes[1:]:
         main.wait_stream(s_)                      # join
+    return _tail(ctx, cat, lv, P, out)
+
+
+def _tail(ctx: Ctx, cat: FMap, lv, P: dict, out: torch.Tensor) -> torch.Tensor:
     fw = P["fusion"]
-    ff = ops.igemm(cat, fw["w"], fw["b"], 128)
-    if has_ref:
-        s, t3, t2, t1 = search_transfer(ff, *lv)
+    ff = ctx.igemm(cat, fw["w"], fw["b"], 128)
+    if lv is not None:
+        s, t3, t2, t1 = search_transfer(ctx, ff, *lv)
     else:
-        s, t3, t2, t1 = self_transfer(ff, P)
-    return decode(ff, s, t3, t2, t1, P, out)
+        s, t3, t2, t1 = self_transfer(ctx, ff, P)
+    return decode(ctx, ff, s, t3, t2, t1, P, out)
 
 
 # ---- cross-window reuse --------------------------------------------------------------------
@@ -217,32 +223,32 @@ def forward_sample(x: torch.Tensor, P: dict, n_seq: int, has_ref: bool, out: tor
 # ones: frame t is the right neighbour of window t-1, the middle of window t and the left neighbour of window t+1, and a
 # sharp reference serves several windows.  The per-frame pieces below are exactly the sub-graphs `forward_sample` runs
 # (same kernels, same operands => bit-identical results); `fuse_and_decode` is everything after them.
-def encode_raw(frame: torch.Tensor, P: dict) -> FMap:
+def encode_raw(ctx: Ctx, frame: torch.Tensor, P: dict) -> FMap:
     """enc(frame): shared by the frame's RL-1 (neighbour) and RL-5 (middle) sums."""
-    return enc(frame, P)
+    return enc(ctx, frame, P)
 
 
-def encode_sum(frame: torch.Tensor, iters: int, e_raw: FMap, P: dict) -> FMap:
+def encode_sum(ctx: Ctx, frame: torch.Tensor, iters: int, e_raw: FMap, P: dict) -> FMap:
     """enc(RL_iters(frame)) + enc(frame)  (speinet.py:82-84 with iters = 5 for the middle frame, :129-132 with 1)."""
-    return enc(ops.rl_prior(frame, iters, 0.01), P, extra=e_raw)
+    return enc(ctx, ctx.rl_prior(frame, iters, 0.01), P, extra=e_raw)
 
 
-def reference_pyramid(frame: torch.Tensor, P: dict):
-    lv1 = in_block(frame, P["inBlock"])
-    lv2 = enc_stage(lv1, P["encoder_first"])
-    return lv1, lv2, enc_stage(lv2, P["encoder_second"])
+def reference_pyramid(ctx: Ctx, frame: torch.Tensor, P: dict):
+    lv1 = in_block(ctx, frame, P["inBlock"])
+    lv2 = enc_stage(ctx, lv1, P["encoder_first"])
+    return lv1, lv2, enc_stage(ctx, lv2, P["encoder_second"])
 
 
-def fuse_and_decode(f_mid: FMap, feats: list, lv, P: dict, n_seq: int, out: torch.Tensor) -> torch.Tensor:
+def fuse_and_decode(ctx: Ctx, f_mid: FMap, feats: list, lv, P: dict, n_seq: int, out: torch.Tensor, sides=()) -> torch.Tensor:
     """Everything after the encoders: the neighbour-frame fusions (on the side lanes), `fusion`, SearchTransfer (lv = the
     reference pyramid) or SelfTransfer (lv = None), decoder.  f_mid / feats: [H/4*W/4, 128] maps."""
     h3, w3 = f_mid.H, f_mid.W
     dev = f_mid.t.device
-    main = torch.cuda.current_stream(dev)
-    lanes = [main] + (_sides(dev, STREAMS - 1) if STREAMS > 1 else [])
+    lanes = _lanes(ctx, sides)
+    main = lanes[0]
     cat = FMap(torch.empty(h3 * w3, 128 * n_seq, device=dev), h3, w3, 128 * n_seq)
     cat.t[:, :128].copy_(f_mid.t)
-    sx = SwinX(f_mid, P["swin"])
+    sx = SwinX(ctx, f_mid, P["swin"])
     ready = torch.cuda.Event()
     ready.record(main)
     for slot, feat in enumerate(feats, start=1):
@@ -250,13 +256,7 @@ def fuse_and_decode(f_mid: FMap, feats: list, lv, P: dict, n_seq: int, out: torc
         if lane is not main:
             lane.wait_event(ready)
         with torch.cuda.stream(lane):
-            swin(sx, feat, P["swin"], out=cat.view(128 * slot, 128))
+            swin(ctx, sx, feat, P["swin"], out=cat.view(128 * slot, 128))
     for s_ in lanes[1:]:
         main.wait_stream(s_)
-    fw = P["fusion"]
-    ff = ops.igemm(cat, fw["w"], fw["b"], 128)
-    if lv is not None:
-        s, t3, t2, t1 = search_transfer(ff, *lv)
-    else:
-        s, t3, t2, t1 = self_transfer(ff, P)
-    return decode(ff, s, t3, t2, t1, P, out)
+    return _tail(ctx, cat, lv, P, out)

@@ -134,6 +134,11 @@ class Inference:
         self.args = args
         self.n_seq = args.n_sequence
         self.device = torch.device(args.device)
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)      # worker threads and torch helpers default to the current device
+        for k in ("data_path", "result_path"):
+            if not getattr(args, k, None):
+                raise ValueError(f"--{k} is not set and --default_data {getattr(args, 'default_data', None)!r} has no preset for it")
         self.rank, self.world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
         now = time.strftime("%Y-%m-%d %H:%M:%S", time.localtime())
         self.logger = Logger(args.result_path, f"inference_log_{now}_rank{self.rank}.txt", echo=self.rank == 0)
@@ -147,7 +152,7 @@ class Inference:
             self.net.load_state_dict(synth_state_dict(state_dict_template(), seed=0))
         self.net = self.net.to(self.device).eval()
         self.net.precision = args.precision
-        self.net.corr_precision = args.precision if args.precision != "f32" else "bf16x3"
+        self.net.corr_precision = {"f32": "bf16x3", "bf16x3": "bf16x3", "bf16": "bf16r"}[args.precision]
         self.net.use_graph = bool(getattr(args, "graph", True))      # one hipGraph per frame shape / routing
         self.net.streams = int(getattr(args, "streams", 2))
         workers = max(2, min(8, (os.cpu_count() or 4) // max(1, self.world)))
@@ -282,6 +287,11 @@ def main(argv=None):
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         a.device = f"cuda:{os.environ.get('LOCAL_RANK', '0')}"
         dist.init_process_group("nccl")
+        try:
+            Inference(a).infer()
+        finally:
+            dist.destroy_process_group()
+        return
     Inference(a).infer()
 
 

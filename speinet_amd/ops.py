@@ -2,6 +2,10 @@
 
 PyTorch is plumbing here: it owns device memory and the stream; every arithmetic step is one of the HIP
 kernels in speinet_amd/csrc.  There is no fallback: a missing library or a failed call raises.
+
+All state of a call lives in a `Ctx` (arithmetic mode, storage knobs, device, optional per-op timing hook): there is
+NO process-global mode — two models with different modes can run from two threads (the reference's nn.DataParallel
+calls `forward` from one Python thread per device, model/__init__.py:19-20; SURVEY.md §8b "threading").
 """
 from __future__ import annotations
 
@@ -20,49 +24,12 @@ CONV, CONV_T = 0, 1
 #   "f32"    v_mfma_f32_32x32x2_f32, exact fp32 (the PSNR-parity configuration)
 #   "bf16x3" split-bf16 products on v_mfma_f32_32x32x16_bf16: f32-grade results at 3/16 of the f32 MFMA cost
 #   "bf16"   single bf16 products, fp32 accumulate (the throughput configuration of BASELINE.json configs[1])
-# CORR_PRECISION applies to the correlation arg-max when PRECISION != "f32" ("bf16x3" keeps the arg-max stable).
-PRECISION = "f32"
-CORR_PRECISION = "bf16x3"
-USE_SLAB = True      # bf16 modes: slab-resident conv/linear kernel (conv_slab_bf16.hip) instead of igemm_bf16.hip
-BF16_STORAGE = True  # "bf16" mode: tensors that only feed the next GEMM / the attention kernel live in HBM as bf16
-
-
-def inter_dtype() -> torch.dtype:
-    """Storage type of GEMM-only intermediates (x-hat, q, kv, attention output, MLP hidden, ResBlock conv1 output)."""
-    return torch.bfloat16 if (PRECISION == "bf16" and USE_SLAB and BF16_STORAGE) else torch.float32
-
-
-def set_precision(mode: str, corr: str = None) -> None:
-    global PRECISION, CORR_PRECISION
-    if mode not in ("f32", "bf16x3", "bf16"):
-        raise ValueError(f"unknown precision {mode!r}")
-    PRECISION = mode
-    if corr is not None:
-        if corr not in ("bf16x3", "bf16"):
-            raise ValueError(f"unknown correlation precision {corr!r}")
-        CORR_PRECISION = corr
-
-# Optional per-op timing hook for bench.py: {op name: [(start_event, end_event), ...]} recorded on the
-# current stream (the stream the kernels are launched on).  None = off (default).
-PROFILE = None
-
-
-class _timed:
-    def __init__(self, name):
-        self.name = name
-
-    def __enter__(self):
-        if PROFILE is not None and self.name in PROFILE:
-            self.s = torch.cuda.Event(enable_timing=True)
-            self.e = torch.cuda.Event(enable_timing=True)
-            self.s.record()
-        return self
-
-    def __exit__(self, *a):
-        if PROFILE is not None and self.name in PROFILE:
-            self.e.record()
-            PROFILE[self.name].append((self.s, self.e))
-        return False
+# Correlation arg-max when precision != "f32":
+#   "bf16x3" f32-grade scores;  "bf16" single bf16 products (winner may flip between near-ties);
+#   "bf16r"  single bf16 products carrying the two best candidates per query, then an exact-fp32 re-score of every
+#            query whose bf16 margin is inside the bf16 error bound (spei_corr_rescore): f32-grade winners and S at bf16 cost
+PRECISIONS = ("f32", "bf16x3", "bf16")
+CORR_PRECISIONS = ("bf16x3", "bf16", "bf16r")
 
 
 class FMap:
@@ -110,273 +77,369 @@ def _vp(p) -> C.c_void_p:
     return C.c_void_p(p)
 
 
-def _tp(t: Optional[torch.Tensor]) -> C.c_void_p:
-    if t is None:
-        return C.c_void_p(0)
-    assert t.is_cuda and t.is_contiguous()
-    return C.c_void_p(t.data_ptr())
+class _timed:
+    def __init__(self, ctx: "Ctx", name: str):
+        self.on = ctx.profile is not None and name in ctx.profile
+        self.ctx, self.name = ctx, name
+
+    def __enter__(self):
+        if self.on:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record(torch.cuda.current_stream(self.ctx.device))
+        return self
+
+    def __exit__(self, *a):
+        if self.on:
+            self.e.record(torch.cuda.current_stream(self.ctx.device))
+            self.ctx.profile[self.name].append((self.s, self.e))
+        return False
 
 
-def _stream() -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+class Ctx:
+    """Everything one forward call needs to know besides its tensors.  Immutable; `replace` derives a variant.
 
+    precision / corr_precision   see PRECISIONS / CORR_PRECISIONS above
+    device                       the ROCm device every tensor of the call lives on; kernels are launched on torch's current
+                                 stream OF THAT DEVICE, and every pointer handed to the C-ABI is checked against it
+    knobs (all default True; parity ablations switch them off one at a time, tools/ablate_parity.py):
+      use_slab        bf16 modes: slab-resident conv / linear kernel (conv_slab_bf16.hip) instead of igemm_bf16.hip
+      bf16_storage    "bf16": tensors that ONLY feed the next GEMM / the attention kernel live in HBM as bf16
+      x1_bf16         "bf16": the ResBlock's conv2 output (read by the gate statistics and the apply pass) is bf16
+      fuse_mlp        "bf16": LayerNorm -> fc1 -> GELU -> fc2 -> +x in one kernel (mlp_fused_bf16.hip)
+      fuse_attn       "bf16": LayerNorm -> q/kv GEMMs -> window attention -> proj -> +x in one kernel
+      commute_upconv  "bf16": relu(conv1x1(bicubic_up(x))) evaluated as relu(bicubic_up(conv1x1(x)))
+    stage        {stage name: {field: value}} overrides applied by `for_stage` (engine: "enc", "swin", "search", "decode")
+    profile      None, or {op name: [(start_event, end_event), ...]} filled on the launch stream (bench.py)
+    capture      None, or a dict that receives intermediate device tensors by name ("arg", "s": what SearchTransfer
+                 decided) for the parity tests; eager launches only
+    """
+    ACT_NONE, ACT_RELU, ACT_GELU = ACT_NONE, ACT_RELU, ACT_GELU
+    CONV, CONV_T = CONV, CONV_T
+    _FIELDS = ("precision", "corr_precision", "device", "use_slab", "bf16_storage", "x1_bf16", "fuse_mlp", "fuse_attn",
+               "commute_upconv", "stage", "profile", "capture")
+    __slots__ = _FIELDS
 
-def any_nonzero(x: torch.Tensor, flag: torch.Tensor) -> None:
-    _lib.check(_lib.lib().spei_any_nonzero(_tp(x), x.numel(), _tp(flag), _stream()), "spei_any_nonzero")
+    def __init__(self, precision: str = "f32", corr_precision: str = "bf16x3", device=None, use_slab: bool = True,
+                 bf16_storage: bool = True, x1_bf16: bool = True, fuse_mlp: bool = True, fuse_attn: bool = True,
+                 commute_upconv: bool = True, stage: Optional[dict] = None, profile: Optional[dict] = None,
+                 capture: Optional[dict] = None):
+        if precision not in PRECISIONS:
+            raise ValueError(f"unknown precision {precision!r}")
+        if corr_precision not in CORR_PRECISIONS:
+            raise ValueError(f"unknown correlation precision {corr_precision!r}")
+        cur = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        device = torch.device("cuda", cur) if device is None else torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("speinet_amd runs on MI355X only (HIP kernels); there is no CPU path")
+        if device.index is None:
+            device = torch.device("cuda", cur)
+        object.__setattr__(self, "precision", precision)
+        object.__setattr__(self, "corr_precision", corr_precision)
+        object.__setattr__(self, "device", device)
+        for k, v in (("use_slab", use_slab), ("bf16_storage", bf16_storage), ("x1_bf16", x1_bf16), ("fuse_mlp", fuse_mlp),
+                     ("fuse_attn", fuse_attn), ("commute_upconv", commute_upconv)):
+            object.__setattr__(self, k, bool(v))
+        object.__setattr__(self, "stage", dict(stage) if stage else {})
+        object.__setattr__(self, "profile", profile)
+        object.__setattr__(self, "capture", capture)
 
+    def __setattr__(self, k, v):
+        raise AttributeError("Ctx is immutable; use replace()")
 
-def rl_prior(img: torch.Tensor, iters: int, lam: float = 0.01) -> torch.Tensor:
-    """img [3,H,W] -> [3,H,W]."""
-    c, h, w = img.shape
-    out = torch.empty_like(img)
-    scratch = torch.empty_like(img)
-    _lib.check(_lib.lib().spei_rl_prior(_tp(img), _tp(out), _tp(scratch), c, h, w, iters, lam, _stream()), "spei_rl_prior")
-    return out
+    def replace(self, **kw) -> "Ctx":
+        d = {k: getattr(self, k) for k in self._FIELDS}
+        d.update(kw)
+        return Ctx(**d)
 
+    def for_stage(self, name: str) -> "Ctx":
+        o = self.stage.get(name)
+        return self.replace(**o) if o else self
 
-def conv5_in(img: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> FMap:
-    c, h, wd = img.shape
-    assert c == 3
-    out = FMap.empty(h, wd, b.numel(), img.device)
-    _lib.check(_lib.lib().spei_conv5_in(_tp(img), _tp(w), _tp(b), _vp(out.ptr), h, wd, b.numel(), _stream()), "spei_conv5_in")
-    return out
+    # ---- plumbing ----------------------------------------------------------------------------------------------
+    def _tp(self, t: Optional[torch.Tensor]) -> C.c_void_p:
+        if t is None:
+            return C.c_void_p(0)
+        assert t.is_cuda and t.is_contiguous()
+        assert t.device == self.device, f"tensor on {t.device}, call context on {self.device}"
+        return C.c_void_p(t.data_ptr())
 
+    def _fp(self, f: Optional[FMap]) -> C.c_void_p:
+        if f is None:
+            return C.c_void_p(0)
+        assert f.t.device == self.device, f"feature map on {f.t.device}, call context on {self.device}"
+        return C.c_void_p(f.ptr)
 
-def conv5_out(f: FMap, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, w32=None, b32: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Last conv, NHWC 32 channels -> three NCHW planes.  w32 / b32 (weights zero-padded to 32 output channels, packed):
-    the "bf16" mode runs the layer on the slab kernel."""
-    assert out.shape == (3, f.H, f.W) and out.is_contiguous() and out.dtype == torch.float32
-    if PRECISION == "bf16" and USE_SLAB and w32 is not None and f.C == 32:
-        _lib.check(_lib.lib().spei_conv5_out_slab_bf16(_vp(f.ptr), f.ld, int(f.bf16), _tp(w32.fhi), _tp(b32), _tp(out), f.H, f.W, _stream()),
-                   "spei_conv5_out_slab_bf16")
+    def _stream(self) -> C.c_void_p:
+        # kernels run on the CURRENT HIP device: the caller (SPEINet.forward, detector, tests) holds
+        # `torch.cuda.device(ctx.device)`; checked here so a foreign-device launch fails loudly instead of faulting
+        assert torch.cuda.current_device() == self.device.index, \
+            f"current device cuda:{torch.cuda.current_device()} != call context {self.device}"
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def inter_dtype(self) -> torch.dtype:
+        """Storage type of GEMM-only intermediates (x-hat, q, kv, attention output, MLP hidden, ResBlock conv1 output)."""
+        return torch.bfloat16 if (self.precision == "bf16" and self.use_slab and self.bf16_storage) else torch.float32
+
+    # ---- K15 / K1 / first and last conv ------------------------------------------------------------------------
+    def any_nonzero(self, x: torch.Tensor, flag: torch.Tensor) -> None:
+        _lib.check(_lib.lib().spei_any_nonzero(self._tp(x), x.numel(), self._tp(flag), self._stream()), "spei_any_nonzero")
+
+    def rl_prior(self, img: torch.Tensor, iters: int, lam: float = 0.01) -> torch.Tensor:
+        """img [3,H,W] -> [3,H,W]."""
+        c, h, w = img.shape
+        out = torch.empty_like(img)
+        scratch = torch.empty_like(img)
+        _lib.check(_lib.lib().spei_rl_prior(self._tp(img), self._tp(out), self._tp(scratch), c, h, w, iters, lam, self._stream()),
+                   "spei_rl_prior")
         return out
-    assert not f.bf16
-    _lib.check(_lib.lib().spei_conv5_out(_vp(f.ptr), f.ld, _tp(w), _tp(b), _tp(out), f.H, f.W, f.C, _stream()), "spei_conv5_out")
-    return out
 
+    def conv5_in(self, img: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> FMap:
+        c, h, wd = img.shape
+        assert c == 3
+        out = FMap.empty(h, wd, b.numel(), img.device)
+        _lib.check(_lib.lib().spei_conv5_in(self._tp(img), self._tp(w), self._tp(b), self._fp(out), h, wd, b.numel(), self._stream()),
+                   "spei_conv5_in")
+        return out
 
-def igemm(a0: FMap, w: torch.Tensor, bias: Optional[torch.Tensor], N: int, ksize: int = 1, stride: int = 1,
-          mode: int = CONV, act: int = ACT_NONE, a1: Optional[FMap] = None, residual: Optional[FMap] = None,
-          rowscale: Optional[torch.Tensor] = None, out: Optional[FMap] = None, out_dtype=torch.float32,
-          ln_input: bool = False) -> FMap:
-    pad = ksize // 2
-    if mode == CONV:
-        ho, wo = (a0.H + 2 * pad - ksize) // stride + 1, (a0.W + 2 * pad - ksize) // stride + 1
-    else:
-        ho, wo = a0.H * stride, a0.W * stride
-    if out is None:
-        out = FMap.empty(ho, wo, N, a0.t.device, out_dtype)
-    assert out.H == ho and out.W == wo and out.C == N
-    k0, k1 = a0.C, (a1.C if a1 is not None else 0)
-    slab = PRECISION != "f32" and USE_SLAB and mode == CONV
-    assert slab or (mode == CONV_T and PRECISION == "bf16" and USE_SLAB) or not (a0.bf16 or out.bf16), \
-        "bf16 activations are only supported by the slab kernel"
-    assert a1 is None or a1.bf16 == a0.bf16
-    assert residual is None or not residual.bf16
-    assert not ln_input or (slab and w.fhi is not None), "ln_input is a feature of the slab kernel"
-    if torch.is_tensor(w):
-        w = PackedW(w, a0.t.device)
-    assert tuple(w.shape) == (ksize * ksize, N, k0 + k1), (tuple(w.shape), ksize, N, k0, k1)
-    if a1 is not None:
-        assert (a1.H, a1.W) == (a0.H, a0.W)
-    if residual is not None:
-        assert (residual.H, residual.W, residual.C) == (ho, wo, N)
-    if rowscale is not None:
-        assert rowscale.numel() == ho * wo
-    common = (_vp(out.ptr), out.ld, _vp(residual.ptr if residual is not None else 0),
-              residual.ld if residual is not None else 0, _tp(rowscale), a0.H, a0.W, ho, wo, N, ksize, stride, pad, mode, act,
-              _stream())
-    srcs = (_vp(a0.ptr), a0.ld, k0, _vp(a1.ptr if a1 is not None else 0), a1.ld if a1 is not None else 0, k1)
-    if (mode == CONV_T and PRECISION == "bf16" and USE_SLAB and ksize == 3 and stride == 2 and a1 is None and residual is None
-            and rowscale is None and N % 32 == 0 and k0 % 32 == 0):
-        # stride-2 transposed conv = four stride-1 convs (one per output parity) on the slab kernel
-        cf = w.convT_class_frags()
-        _lib.check(_lib.lib().spei_convt2_slab_bf16(_vp(a0.ptr), a0.ld, k0, int(a0.bf16), _tp(cf[(0, 0)]), _tp(cf[(0, 1)]), _tp(cf[(1, 0)]),
-                                                   _tp(cf[(1, 1)]), _tp(bias), _vp(out.ptr), out.ld, int(out.bf16), a0.H, a0.W, N, act,
-                                                   _stream()), "spei_convt2_slab_bf16")
-    elif PRECISION == "f32":
-        _lib.check(_lib.lib().spei_igemm_f32(*srcs, _tp(w.f32), _tp(bias), *common), "spei_igemm_f32")
-    elif slab and w.fhi is not None:
-        dims = (a0.H * a0.W, 1, ho * wo, 1) if (ksize == 1 and stride == 1) else (a0.H, a0.W, ho, wo)
-        _lib.check(_lib.lib().spei_conv_slab_bf16(
-            *srcs, int(a0.bf16), _tp(w.fhi), _tp(w.flo) if PRECISION == "bf16x3" else _vp(0), _tp(bias), _vp(out.ptr), out.ld,
-            int(out.bf16), _vp(residual.ptr if residual is not None else 0), residual.ld if residual is not None else 0,
-            _tp(rowscale), *dims, N, ksize, stride, pad, act, int(ln_input), _stream()), "spei_conv_slab_bf16")
-    else:
-        _lib.check(_lib.lib().spei_igemm_bf16(*srcs, _tp(w.hi), _tp(w.lo) if PRECISION == "bf16x3" else _vp(0), _tp(bias), *common),
-                   "spei_igemm_bf16")
-    return out
+    def conv5_out(self, f: FMap, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, w32=None,
+                  b32: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Last conv, NHWC 32 channels -> three NCHW planes.  w32 / b32 (weights zero-padded to 32 output channels,
+        packed): the "bf16" mode runs the layer on the slab kernel."""
+        assert out.shape == (3, f.H, f.W) and out.is_contiguous() and out.dtype == torch.float32
+        if self.precision == "bf16" and self.use_slab and w32 is not None and f.C == 32:
+            _lib.check(_lib.lib().spei_conv5_out_slab_bf16(self._fp(f), f.ld, int(f.bf16), self._tp(w32.fhi), self._tp(b32),
+                                                          self._tp(out), f.H, f.W, self._stream()), "spei_conv5_out_slab_bf16")
+            return out
+        assert not f.bf16
+        _lib.check(_lib.lib().spei_conv5_out(self._fp(f), f.ld, self._tp(w), self._tp(b), self._tp(out), f.H, f.W, f.C, self._stream()),
+                   "spei_conv5_out")
+        return out
 
+    # ---- the GEMM family ---------------------------------------------------------------------------------------
+    def igemm(self, a0: FMap, w, bias: Optional[torch.Tensor], N: int, ksize: int = 1, stride: int = 1,
+              mode: int = CONV, act: int = ACT_NONE, a1: Optional[FMap] = None, residual: Optional[FMap] = None,
+              rowscale: Optional[torch.Tensor] = None, out: Optional[FMap] = None, out_dtype=torch.float32,
+              ln_input: bool = False) -> FMap:
+        prec = self.precision
+        pad = ksize // 2
+        if mode == CONV:
+            ho, wo = (a0.H + 2 * pad - ksize) // stride + 1, (a0.W + 2 * pad - ksize) // stride + 1
+        else:
+            ho, wo = a0.H * stride, a0.W * stride
+        if out is None:
+            out = FMap.empty(ho, wo, N, a0.t.device, out_dtype)
+        assert out.H == ho and out.W == wo and out.C == N
+        k0, k1 = a0.C, (a1.C if a1 is not None else 0)
+        slab = prec != "f32" and self.use_slab and mode == CONV
+        assert slab or (mode == CONV_T and prec == "bf16" and self.use_slab) or not (a0.bf16 or out.bf16), \
+            "bf16 activations are only supported by the slab kernel"
+        assert a1 is None or a1.bf16 == a0.bf16
+        assert residual is None or not residual.bf16
+        if torch.is_tensor(w):
+            w = PackedW(w, a0.t.device)
+        assert not ln_input or (slab and w.fhi is not None), "ln_input is a feature of the slab kernel"
+        assert tuple(w.shape) == (ksize * ksize, N, k0 + k1), (tuple(w.shape), ksize, N, k0, k1)
+        if a1 is not None:
+            assert (a1.H, a1.W) == (a0.H, a0.W)
+        if residual is not None:
+            assert (residual.H, residual.W, residual.C) == (ho, wo, N)
+        if rowscale is not None:
+            assert rowscale.numel() == ho * wo
+        tp, fp = self._tp, self._fp
+        common = (fp(out), out.ld, fp(residual), residual.ld if residual is not None else 0, tp(rowscale), a0.H, a0.W, ho, wo, N,
+                  ksize, stride, pad, mode, act, self._stream())
+        srcs = (fp(a0), a0.ld, k0, fp(a1), a1.ld if a1 is not None else 0, k1)
+        lib = _lib.lib()
+        if (mode == CONV_T and prec == "bf16" and self.use_slab and ksize == 3 and stride == 2 and a1 is None and residual is None
+                and rowscale is None and N % 32 == 0 and k0 % 32 == 0):
+            # stride-2 transposed conv = four stride-1 convs (one per output parity) on the slab kernel
+            cf = w.convT_class_frags()
+            _lib.check(lib.spei_convt2_slab_bf16(fp(a0), a0.ld, k0, int(a0.bf16), tp(cf[(0, 0)]), tp(cf[(0, 1)]), tp(cf[(1, 0)]),
+                                                 tp(cf[(1, 1)]), tp(bias), fp(out), out.ld, int(out.bf16), a0.H, a0.W, N, act,
+                                                 self._stream()), "spei_convt2_slab_bf16")
+        elif prec == "f32":
+            _lib.check(lib.spei_igemm_f32(*srcs, tp(w.f32), tp(bias), *common), "spei_igemm_f32")
+        elif slab and w.fhi is not None:
+            dims = (a0.H * a0.W, 1, ho * wo, 1) if (ksize == 1 and stride == 1) else (a0.H, a0.W, ho, wo)
+            _lib.check(lib.spei_conv_slab_bf16(
+                *srcs, int(a0.bf16), tp(w.fhi), tp(w.flo) if prec == "bf16x3" else _vp(0), tp(bias), fp(out), out.ld,
+                int(out.bf16), fp(residual), residual.ld if residual is not None else 0,
+                tp(rowscale), *dims, N, ksize, stride, pad, act, int(ln_input), self._stream()), "spei_conv_slab_bf16")
+        else:
+            _lib.check(lib.spei_igemm_bf16(*srcs, tp(w.hi), tp(w.lo) if prec == "bf16x3" else _vp(0), tp(bias), *common),
+                       "spei_igemm_bf16")
+        return out
 
-def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: int = ACT_NONE,
-           residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_dtype=torch.float32,
-           ln_input: bool = False) -> torch.Tensor:
-    """Token-space linear: x [M,K] -> [M,N]; w [N,K]."""
-    m, k = x.shape
-    if torch.is_tensor(w):
-        w = PackedW(w.reshape(1, *w.shape), x.device)
-    n = w.shape[1]
-    if out is None:
-        out = torch.empty(m, n, device=x.device, dtype=out_dtype)
-    igemm(FMap(x, m, 1, k), w, b, n, act=act, ln_input=ln_input,
-          residual=FMap(residual, m, 1, n) if residual is not None else None, out=FMap(out, m, 1, n))
-    return out
+    def linear(self, x: torch.Tensor, w, b: Optional[torch.Tensor], act: int = ACT_NONE,
+               residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_dtype=torch.float32,
+               ln_input: bool = False) -> torch.Tensor:
+        """Token-space linear: x [M,K] -> [M,N]; w [N,K]."""
+        m, k = x.shape
+        if torch.is_tensor(w):
+            w = PackedW(w.reshape(1, *w.shape), x.device)
+        n = w.shape[1]
+        if out is None:
+            out = torch.empty(m, n, device=x.device, dtype=out_dtype)
+        self.igemm(FMap(x, m, 1, k), w, b, n, act=act, ln_input=ln_input,
+                   residual=FMap(residual, m, 1, n) if residual is not None else None, out=FMap(out, m, 1, n))
+        return out
 
+    # ---- ResBlock (K3) -----------------------------------------------------------------------------------------
+    def resblock_gates(self, x1: FMap, pk: dict):
+        dev = x1.t.device
+        lib = _lib.lib()
+        tp = self._tp
+        assert x1.off == 0 and x1.ld == x1.C
+        s = torch.empty(x1.C, device=dev)
+        g1 = torch.empty(x1.H, x1.C, device=dev)
+        g2 = torch.empty(x1.W, x1.C, device=dev)
+        ws = torch.empty(lib.spei_gate_ws_floats(x1.H, x1.W, x1.C), device=dev)
+        _lib.check(lib.spei_resblock_gates(self._fp(x1), int(x1.bf16), x1.H, x1.W, x1.C, tp(pk["se_w1"]), tp(pk["se_b1"]), tp(pk["se_w2"]),
+                                           tp(pk["se_b2"]), tp(pk["cw_w"]), tp(pk["cw_bn"]), tp(pk["hc_w"]), tp(pk["hc_bn"]),
+                                           tp(s), tp(g1), tp(g2), tp(ws), self._stream()), "spei_resblock_gates")
+        return s, g1, g2
 
-def resblock_gates(x1: FMap, pk: dict):
-    dev = x1.t.device
-    lib = _lib.lib()
-    assert x1.off == 0 and x1.ld == x1.C
-    s = torch.empty(x1.C, device=dev)
-    g1 = torch.empty(x1.H, x1.C, device=dev)
-    g2 = torch.empty(x1.W, x1.C, device=dev)
-    ws = torch.empty(lib.spei_gate_ws_floats(x1.H, x1.W, x1.C), device=dev)
-    _lib.check(lib.spei_resblock_gates(_vp(x1.ptr), int(x1.bf16), x1.H, x1.W, x1.C, _tp(pk["se_w1"]), _tp(pk["se_b1"]), _tp(pk["se_w2"]),
-                                       _tp(pk["se_b2"]), _tp(pk["cw_w"]), _tp(pk["cw_bn"]), _tp(pk["hc_w"]), _tp(pk["hc_bn"]),
-                                       _tp(s), _tp(g1), _tp(g2), _tp(ws), _stream()), "spei_resblock_gates")
-    return s, g1, g2
+    def resblock(self, x: FMap, pk: dict, extra: Optional[FMap] = None, out: Optional[FMap] = None) -> FMap:
+        """x + SE(x1) + TE(x1), x1 = conv5(relu(conv5(x)))  (reference model/block.py:127-140)."""
+        c = x.C
+        assert x.off == 0 and x.ld == c
+        idt = self.inter_dtype()
+        t = self.igemm(x, pk["w1"], pk["b1"], c, ksize=5, act=ACT_RELU, out_dtype=idt)   # only conv2 reads it
+        x1 = self.igemm(t, pk["w2"], pk["b2"], c, ksize=5, out_dtype=idt if self.x1_bf16 else torch.float32)
+        s, g1, g2 = self.resblock_gates(x1, pk)
+        if out is None:
+            out = FMap.empty(x.H, x.W, c, x.t.device)
+        if extra is not None:
+            assert extra.off == 0 and extra.ld == c
+        _lib.check(_lib.lib().spei_resblock_apply(self._fp(x), self._fp(x1), int(x1.bf16), self._tp(s), self._tp(g1), self._tp(g2),
+                                                  self._fp(extra), self._fp(out), out.ld, x.H, x.W, c, self._stream()),
+                   "spei_resblock_apply")
+        return out
 
+    # ---- Swin (K6-K9) ------------------------------------------------------------------------------------------
+    def ln_fused_available(self) -> bool:
+        """LayerNorm folded into the staging of the following 256-wide linear (slab kernel, any bf16 mode)."""
+        return self.precision != "f32" and self.use_slab
 
-def resblock(x: FMap, pk: dict, extra: Optional[FMap] = None, out: Optional[FMap] = None) -> FMap:
-    """x + SE(x1) + TE(x1), x1 = conv5(relu(conv5(x)))  (reference model/block.py:127-140)."""
-    c = x.C
-    assert x.off == 0 and x.ld == c
-    t = igemm(x, pk["w1"], pk["b1"], c, ksize=5, act=ACT_RELU, out_dtype=inter_dtype())   # only conv2 reads it
-    x1 = igemm(t, pk["w2"], pk["b2"], c, ksize=5, out_dtype=inter_dtype() if X1_BF16 else torch.float32)
-    s, g1, g2 = resblock_gates(x1, pk)
-    if out is None:
-        out = FMap.empty(x.H, x.W, c, x.t.device)
-    if extra is not None:
-        assert extra.off == 0 and extra.ld == c
-    _lib.check(_lib.lib().spei_resblock_apply(_vp(x.ptr), _vp(x1.ptr), int(x1.bf16), _tp(s), _tp(g1), _tp(g2),
-                                              _vp(extra.ptr if extra is not None else 0), _vp(out.ptr), out.ld, x.H, x.W, c,
-                                              _stream()), "spei_resblock_apply")
-    return out
+    def attn_fused_available(self) -> bool:
+        return self.precision == "bf16" and self.use_slab and self.fuse_attn and self.bf16_storage
 
+    def mlp_fused_available(self) -> bool:
+        return self.precision == "bf16" and self.use_slab and self.fuse_mlp
 
-X1_BF16 = True       # "bf16" mode: the ResBlock's conv2 output (read by the gate statistics and the apply pass) is bf16
-FUSE_MLP = True      # "bf16" mode: LayerNorm -> fc1 -> GELU -> fc2 -> +x in one kernel (mlp_fused_bf16.hip)
+    def attn_fused(self, x: torch.Tensor, yhat: torch.Tensor, bk: dict, H: int, W: int, shift: int, out: torch.Tensor) -> torch.Tensor:
+        """out = x + proj(window_attention(...))  (reference model/swinir.py:238-278); in place when out is x."""
+        assert x.shape == (H * W, 256) and x.dtype == torch.float32 and out.shape == x.shape and out.dtype == torch.float32
+        assert yhat.shape == x.shape and yhat.dtype == torch.bfloat16
+        tp = self._tp
+        _lib.check(_lib.lib().spei_attn_fused_bf16(tp(x), tp(out), tp(yhat), tp(bk["wq"].fhi), tp(bk["bq"]), tp(bk["wkv"].fhi),
+                                                   tp(bk["bkv"]), tp(bk["wproj"].fhi), tp(bk["bproj"]), tp(bk["relbias"]), H, W, shift,
+                                                   self._stream()), "spei_attn_fused_bf16")
+        return out
 
+    def mlp_fused(self, x: torch.Tensor, w1, b1: torch.Tensor, w2, b2: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """out = x + fc2(gelu(fc1(LN(x))))  (reference model/swinir.py:279); in place when out is x."""
+        assert x.shape[1] == 256 and x.dtype == torch.float32 and out.shape == x.shape and out.dtype == torch.float32
+        assert tuple(w1.shape) == (1, 512, 256) and tuple(w2.shape) == (1, 256, 512)
+        tp = self._tp
+        _lib.check(_lib.lib().spei_mlp_fused_bf16(tp(x), tp(out), tp(w1.fhi), tp(b1), tp(w2.fhi), tp(b2), x.shape[0], self._stream()),
+                   "spei_mlp_fused_bf16")
+        return out
 
-def ln_fused_available() -> bool:
-    """LayerNorm folded into the staging of the following 256-wide linear (slab kernel, any bf16 mode)."""
-    return PRECISION != "f32" and USE_SLAB
+    def layernorm(self, x: torch.Tensor, g: Optional[torch.Tensor] = None, b: Optional[torch.Tensor] = None,
+                  out: Optional[torch.Tensor] = None, out_dtype=torch.float32) -> torch.Tensor:
+        assert x.shape[1] == 256 and x.is_contiguous() and x.dtype == torch.float32
+        if out is None:
+            out = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+        tp = self._tp
+        _lib.check(_lib.lib().spei_layernorm256(tp(x), tp(out), int(out.dtype == torch.bfloat16), tp(g), tp(b), x.shape[0], self._stream()),
+                   "spei_layernorm256")
+        return out
 
+    def window_attention(self, q: torch.Tensor, kv: torch.Tensor, relbias: torch.Tensor, H: int, W: int, shift: int,
+                         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        assert q.shape == (H * W, 256) and kv.shape == (H * W, 512) and relbias.shape == (8, 25, 25)
+        if out is None:
+            out = torch.empty_like(q)
+        assert q.dtype == kv.dtype == out.dtype
+        tp = self._tp
+        _lib.check(_lib.lib().spei_window_attention(tp(q), tp(kv), int(q.dtype == torch.bfloat16), tp(relbias), tp(out), H, W, shift,
+                                                    self._stream()), "spei_window_attention")
+        return out
 
-FUSE_ATTN = True     # "bf16" mode: LayerNorm -> q/kv GEMMs -> window attention -> proj -> +x in one kernel
+    # ---- SearchTransfer (K10-K12) ------------------------------------------------------------------------------
+    def patch_invnorm(self, f: FMap) -> torch.Tensor:
+        inv = torch.empty(f.H * f.W, device=f.t.device)
+        _lib.check(_lib.lib().spei_patch_invnorm(self._fp(f), f.ld, self._tp(inv), f.H, f.W, f.C, self._stream()), "spei_patch_invnorm")
+        return inv
 
-
-def attn_fused_available() -> bool:
-    return PRECISION == "bf16" and USE_SLAB and FUSE_ATTN and BF16_STORAGE
-
-
-def attn_fused(x: torch.Tensor, yhat: torch.Tensor, bk: dict, H: int, W: int, shift: int, out: torch.Tensor) -> torch.Tensor:
-    """out = x + proj(window_attention(...))  (reference model/swinir.py:238-278); in place when out is x."""
-    assert x.shape == (H * W, 256) and x.dtype == torch.float32 and out.shape == x.shape and out.dtype == torch.float32
-    assert yhat.shape == x.shape and yhat.dtype == torch.bfloat16
-    _lib.check(_lib.lib().spei_attn_fused_bf16(_tp(x), _tp(out), _tp(yhat), _tp(bk["wq"].fhi), _tp(bk["bq"]), _tp(bk["wkv"].fhi),
-                                               _tp(bk["bkv"]), _tp(bk["wproj"].fhi), _tp(bk["bproj"]), _tp(bk["relbias"]), H, W, shift,
-                                               _stream()), "spei_attn_fused_bf16")
-    return out
-
-
-def mlp_fused_available() -> bool:
-    return PRECISION == "bf16" and USE_SLAB and FUSE_MLP
-
-
-def mlp_fused(x: torch.Tensor, w1, b1: torch.Tensor, w2, b2: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-    """out = x + fc2(gelu(fc1(LN(x))))  (reference model/swinir.py:279); in place when out is x."""
-    assert x.shape[1] == 256 and x.dtype == torch.float32 and out.shape == x.shape and out.dtype == torch.float32
-    assert tuple(w1.shape) == (1, 512, 256) and tuple(w2.shape) == (1, 256, 512)
-    _lib.check(_lib.lib().spei_mlp_fused_bf16(_tp(x), _tp(out), _tp(w1.fhi), _tp(b1), _tp(w2.fhi), _tp(b2), x.shape[0], _stream()),
-               "spei_mlp_fused_bf16")
-    return out
-
-
-def layernorm(x: torch.Tensor, g: Optional[torch.Tensor] = None, b: Optional[torch.Tensor] = None,
-              out: Optional[torch.Tensor] = None, out_dtype=torch.float32) -> torch.Tensor:
-    assert x.shape[1] == 256 and x.is_contiguous() and x.dtype == torch.float32
-    if out is None:
-        out = torch.empty(x.shape, device=x.device, dtype=out_dtype)
-    _lib.check(_lib.lib().spei_layernorm256(_tp(x), _tp(out), int(out.dtype == torch.bfloat16), _tp(g), _tp(b), x.shape[0], _stream()),
-               "spei_layernorm256")
-    return out
-
-
-def window_attention(q: torch.Tensor, kv: torch.Tensor, relbias: torch.Tensor, H: int, W: int, shift: int,
-                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    assert q.shape == (H * W, 256) and kv.shape == (H * W, 512) and relbias.shape == (8, 25, 25)
-    if out is None:
-        out = torch.empty_like(q)
-    assert q.dtype == kv.dtype == out.dtype
-    _lib.check(_lib.lib().spei_window_attention(_tp(q), _tp(kv), int(q.dtype == torch.bfloat16), _tp(relbias), _tp(out), H, W, shift,
-                                                _stream()), "spei_window_attention")
-    return out
-
-
-def patch_invnorm(f: FMap) -> torch.Tensor:
-    inv = torch.empty(f.H * f.W, device=f.t.device)
-    _lib.check(_lib.lib().spei_patch_invnorm(_vp(f.ptr), f.ld, _tp(inv), f.H, f.W, f.C, _stream()), "spei_patch_invnorm")
-    return inv
-
-
-def corr_argmax(lr: FMap, ref: FMap, inv_lr: torch.Tensor, inv_ref: torch.Tensor):
-    lib = _lib.lib()
-    dev = lr.t.device
-    n = lr.H * lr.W
-    s = torch.empty(n, device=dev)
-    arg = torch.empty(n, device=dev, dtype=torch.int32)
-    ws = torch.empty(lib.spei_corr_ws_floats(n), device=dev)
-    if PRECISION == "f32":
-        with _timed("corr_argmax"):
-            _lib.check(lib.spei_corr_argmax(_vp(lr.ptr), lr.ld, _vp(ref.ptr), ref.ld, _tp(inv_lr), _tp(inv_ref), lr.H, lr.W, ref.H, ref.W,
-                                            lr.C, _tp(s), _tp(arg), _tp(ws), _stream()), "spei_corr_argmax")
+    def corr_argmax(self, lr: FMap, ref: FMap, inv_lr: torch.Tensor, inv_ref: torch.Tensor):
+        lib = _lib.lib()
+        dev = lr.t.device
+        tp, fp = self._tp, self._fp
+        n = lr.H * lr.W
+        s = torch.empty(n, device=dev)
+        arg = torch.empty(n, device=dev, dtype=torch.int32)
+        ws = torch.empty(lib.spei_corr_ws_floats(n), device=dev)
+        if self.precision == "f32":
+            with _timed(self, "corr_argmax"):
+                _lib.check(lib.spei_corr_argmax(fp(lr), lr.ld, fp(ref), ref.ld, tp(inv_lr), tp(inv_ref), lr.H, lr.W, ref.H, ref.W,
+                                                lr.C, tp(s), tp(arg), tp(ws), self._stream()), "spei_corr_argmax")
+            return s, arg
+        split = self.corr_precision == "bf16x3"
+        rescore = self.corr_precision == "bf16r" and self.use_slab and lr.C == 128
+        parts = []
+        for f in (lr, ref):
+            hi = torch.empty(f.H * f.W, f.C, device=dev, dtype=torch.bfloat16)
+            lo = torch.empty_like(hi) if split else None
+            _lib.check(lib.spei_split_bf16(fp(f), f.ld, tp(hi), tp(lo), f.H * f.W, f.C, self._stream()), "spei_split_bf16")
+            parts += [hi, lo]
+        if rescore:
+            arg2 = torch.empty(n, device=dev, dtype=torch.int32)
+            s2 = torch.empty(n, device=dev)
+            with _timed(self, "corr_argmax"):
+                _lib.check(lib.spei_corr_slab_top2_bf16(tp(parts[0]), tp(parts[2]), tp(inv_lr), tp(inv_ref), lr.H, lr.W, ref.H, ref.W,
+                                                        lr.C, tp(s), tp(arg), tp(s2), tp(arg2), tp(ws), self._stream()),
+                           "spei_corr_slab_top2_bf16")
+            _lib.check(lib.spei_corr_rescore(fp(lr), lr.ld, fp(ref), ref.ld, tp(inv_lr), tp(inv_ref), lr.H, lr.W, ref.H, ref.W, lr.C,
+                                             tp(s), tp(arg), tp(s2), tp(arg2), self._stream()), "spei_corr_rescore")
+            return s, arg
+        fn, name = (lib.spei_corr_slab_bf16, "spei_corr_slab_bf16") if (self.use_slab and lr.C == 128) else \
+            (lib.spei_corr_argmax_bf16, "spei_corr_argmax_bf16")
+        with _timed(self, "corr_argmax"):
+            _lib.check(fn(tp(parts[0]), tp(parts[1]), tp(parts[2]), tp(parts[3]), tp(inv_lr), tp(inv_ref),
+                          lr.H, lr.W, ref.H, ref.W, lr.C, tp(s), tp(arg), tp(ws), self._stream()), name)
         return s, arg
-    split = CORR_PRECISION == "bf16x3"
-    parts = []
-    for f in (lr, ref):
-        hi = torch.empty(f.H * f.W, f.C, device=dev, dtype=torch.bfloat16)
-        lo = torch.empty_like(hi) if split else None
-        _lib.check(lib.spei_split_bf16(_vp(f.ptr), f.ld, _tp(hi), _tp(lo), f.H * f.W, f.C, _stream()), "spei_split_bf16")
-        parts += [hi, lo]
-    fn, name = (lib.spei_corr_slab_bf16, "spei_corr_slab_bf16") if (USE_SLAB and lr.C == 128) else (lib.spei_corr_argmax_bf16, "spei_corr_argmax_bf16")
-    with _timed("corr_argmax"):
-        _lib.check(fn(_tp(parts[0]), _tp(parts[1]), _tp(parts[2]), _tp(parts[3]), _tp(inv_lr), _tp(inv_ref),
-                                             lr.H, lr.W, ref.H, ref.W, lr.C, _tp(s), _tp(arg), _tp(ws), _stream()), name)
-    return s, arg
 
+    def gather_fold(self, ref: FMap, arg: torch.Tensor, H3: int, W3: int, Hr3: int, Wr3: int, s: int) -> FMap:
+        assert ref.H == Hr3 * s and ref.W == Wr3 * s
+        out = FMap.empty(H3 * s, W3 * s, ref.C, ref.t.device)
+        _lib.check(_lib.lib().spei_gather_fold(self._fp(ref), ref.ld, self._tp(arg), self._fp(out), out.ld, H3, W3, Hr3, Wr3, ref.C, s,
+                                               self._stream()), "spei_gather_fold")
+        return out
 
-def gather_fold(ref: FMap, arg: torch.Tensor, H3: int, W3: int, Hr3: int, Wr3: int, s: int) -> FMap:
-    assert ref.H == Hr3 * s and ref.W == Wr3 * s
-    out = FMap.empty(H3 * s, W3 * s, ref.C, ref.t.device)
-    _lib.check(_lib.lib().spei_gather_fold(_vp(ref.ptr), ref.ld, _tp(arg), _vp(out.ptr), out.ld, H3, W3, Hr3, Wr3, ref.C, s, _stream()),
-               "spei_gather_fold")
-    return out
+    # ---- glue (K13-K14) ----------------------------------------------------------------------------------------
+    def rot90(self, f: FMap) -> FMap:
+        out = FMap.empty(f.W, f.H, f.C, f.t.device)
+        _lib.check(_lib.lib().spei_rot90(self._fp(f), f.ld, self._fp(out), f.H, f.W, f.C, self._stream()), "spei_rot90")
+        return out
 
+    def upsample(self, f: FMap, s: int, act: int = ACT_NONE) -> FMap:
+        out = FMap.empty(f.H * s, f.W * s, f.C, f.t.device)
+        _lib.check(_lib.lib().spei_upsample_bicubic(self._fp(f), f.ld, self._fp(out), out.ld, f.H, f.W, f.C, s, act, self._stream()),
+                   "spei_upsample_bicubic")
+        return out
 
-def rot90(f: FMap) -> FMap:
-    out = FMap.empty(f.W, f.H, f.C, f.t.device)
-    _lib.check(_lib.lib().spei_rot90(_vp(f.ptr), f.ld, _vp(out.ptr), f.H, f.W, f.C, _stream()), "spei_rot90")
-    return out
+    def up_conv1x1_relu(self, f: FMap, w, b: torch.Tensor, n: int, s: int = 2) -> FMap:
+        """relu(conv1x1(bicubic_up(f))) (reference model/speinet.py:96-97,108-109, model/SearchTransfer.py:73-76).  Both maps
+        are linear and the bicubic weights sum to 1, so the "bf16" mode runs the conv first, at 1/s^2 of the pixels and with
+        half the bytes through the upsampler; the f32-grade modes keep the reference's order of operations."""
+        if self.precision == "bf16" and self.commute_upconv:
+            return self.upsample(self.igemm(f, w, b, n), s, act=ACT_RELU)
+        return self.igemm(self.upsample(f, s), w, b, n, act=ACT_RELU)
 
-
-def upsample(f: FMap, s: int, act: int = ACT_NONE) -> FMap:
-    out = FMap.empty(f.H * s, f.W * s, f.C, f.t.device)
-    _lib.check(_lib.lib().spei_upsample_bicubic(_vp(f.ptr), f.ld, _vp(out.ptr), out.ld, f.H, f.W, f.C, s, act, _stream()),
-               "spei_upsample_bicubic")
-    return out
-
-
-def up_conv1x1_relu(f: FMap, w, b: torch.Tensor, n: int, s: int = 2) -> FMap:
-    """relu(conv1x1(bicubic_up(f))) (reference model/speinet.py:96-97,108-109, model/SearchTransfer.py:73-76).  Both maps
-    are linear and the bicubic weights sum to 1, so the "bf16" mode runs the conv first, at 1/s^2 of the pixels and with
-    half the bytes through the upsampler; the f32-grade modes keep the reference's order of operations."""
-    if PRECISION == "bf16":
-        return upsample(igemm(f, w, b, n), s, act=ACT_RELU)
-    return igemm(upsample(f, s), w, b, n, act=ACT_RELU)
-
-
-def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    out = torch.empty_like(a)
-    _lib.check(_lib.lib().spei_add(_tp(a), _tp(b), _tp(out), a.numel(), _stream()), "spei_add")
-    return out
+    def add(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        out = torch.empty_like(a)
+        _lib.check(_lib.lib().spei_add(self._tp(a), self._tp(b), self._tp(out), a.numel(), self._stream()), "spei_add")
+        return out

@@ -211,61 +211,98 @@ class SPEINet(nn.Module):
         self.search13 = nn.Conv2d(nf * 2, nf, 1)
         if load_recons_net:
             self.recons_net.load_state_dict(torch.load(recons_pretrain_fn, weights_only=True))
-        self._packed = None
-        self._packed_key = None
+        self._packed = {}            # device -> packed weights (speinet_amd/pack.py), rebuilt after invalidate_packed()
+        self._generation = 0
         # arithmetic of the GEMM-shaped kernels: "f32" (exact, PSNR parity), "bf16x3" (f32-grade, 5x cheaper) or
-        # "bf16" (throughput config); see speinet_amd/ops.py.  Not part of the reference signature.
+        # "bf16" (throughput config); correlation: "bf16x3" | "bf16" | "bf16r" (bf16 + exact re-score of near-ties);
+        # see speinet_amd/ops.py.  Not part of the reference signature; read once per forward call into an ops.Ctx.
         self.precision = os.environ.get("SPEINET_PRECISION", "f32")
         self.corr_precision = os.environ.get("SPEINET_CORR_PRECISION", "bf16x3")
         self.use_graph = os.environ.get("SPEINET_GRAPH", "0") == "1"     # hipGraph replay of a whole frame
         self.streams = int(os.environ.get("SPEINET_STREAMS", "1"))        # HIP streams for the independent frame branches
+        self.knobs = {}              # extra ops.Ctx fields (parity ablations, tools/ablate_parity.py)
         self._graphs = {}
+        self._side_streams = {}      # (device index, n) -> side streams, owned by this model
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed())
 
     # ---- weight packing cache -----------------------------------------------------------------------
+    def invalidate_packed(self) -> None:
+        """Drop the packed weights and captured graphs.  Called automatically after `load_state_dict` and after
+        `.to()` / `.cuda()` / `.float()` (`_apply`); call it yourself after editing parameters in place
+        (`p.data.mul_()`, an optimizer step): in-place edits are invisible to the module."""
+        self._packed = {}
+        self._graphs = {}
+        self._generation += 1
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self.invalidate_packed()
+        return out
+
     def _pack(self, device):
-        key = (str(device), tuple(p._version for p in self.parameters()), tuple(b._version for b in self.buffers()),
-               tuple(p.data_ptr() for p in self.parameters()))
-        if self._packed is None or self._packed_key != key:
-            self._packed = pack.pack_all(self.state_dict(), self.cfg, device)
-            self._packed_key = key
-        return self._packed
+        device = torch.device(device)
+        key = str(device)
+        if key not in self._packed:
+            self._packed[key] = pack.pack_all(self.state_dict(), self.cfg, device)
+        return self._packed[key]
 
-    def _route(self, x: torch.Tensor) -> list:
-        """`_forwardx` (reference :70-73): True where frame 3 is identically zero.  One device reduction per
-        sample, ONE host sync for the batch (the reference syncs twice through `.any()`)."""
-        b = x.shape[0]
-        flags = torch.empty(b, dtype=torch.int32, device=x.device)
-        for i in range(b):
-            ops.any_nonzero(x[i, 3], flags[i:i + 1])
-        return [v == 0 for v in flags.tolist()]
+    def _ctx(self, device, profile=None, capture=None) -> ops.Ctx:
+        return ops.Ctx(self.precision, self.corr_precision, device=device, profile=profile, capture=capture, **self.knobs)
 
-    def forward(self, x: torch.Tensor, routing: Optional[Sequence[bool]] = None) -> torch.Tensor:
-        """x [B, n_sequence+2, 3, H, W] fp32 in [0,1] -> [B, 3, H, W] (unclamped).
+    def _sides(self, device) -> list:
+        n = max(1, int(self.streams)) - 1
+        key = (torch.device(device).index, n)
+        if key not in self._side_streams:
+            self._side_streams[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+        return self._side_streams[key]
 
-        ``routing`` (optional, beyond the reference signature): per-sample "frame 3 is all zero" decisions when the
-        caller already knows them (the harness zeroes the frame itself), which removes the host sync.
-        """
-        if x.dim() != 5 or x.shape[1] != self.n_sequence + 2 or x.shape[2] != 3:
-            raise ValueError(f"expected [B,{self.n_sequence + 2},3,H,W], got {tuple(x.shape)}")
+    def _mode_key(self, device):
+        return (self.precision, self.corr_precision, int(self.streams), str(device), self._generation, repr(sorted(self.knobs.items())))
+
+    def _check_input(self, x: torch.Tensor, batch1: bool = False) -> None:
+        if x.dim() != 5 or x.shape[1] != self.n_sequence + 2 or x.shape[2] != 3 or (batch1 and x.shape[0] != 1):
+            raise ValueError(f"expected [{'1' if batch1 else 'B'},{self.n_sequence + 2},3,H,W], got {tuple(x.shape)}")
         h, w = x.shape[-2:]
         if h % 20 or w % 20:
             raise ValueError(f"H and W must be multiples of 20 (two stride-2 stages, then 5x5 windows); got {h}x{w}")
         if not x.is_cuda:
             raise RuntimeError("speinet_amd.SPEINet runs on MI355X only (HIP kernels); there is no CPU path")
+
+    def _route(self, ctx: ops.Ctx, x: torch.Tensor) -> list:
+        """`_forwardx` (reference :70-73): True where frame 3 is identically zero.  One device reduction per
+        sample, ONE host sync for the batch (the reference syncs twice through `.any()`)."""
+        b = x.shape[0]
+        flags = torch.empty(b, dtype=torch.int32, device=x.device)
+        for i in range(b):
+            ctx.any_nonzero(x[i, 3], flags[i:i + 1])
+        return [v == 0 for v in flags.tolist()]
+
+    def forward(self, x: torch.Tensor, routing: Optional[Sequence[bool]] = None, profile: Optional[dict] = None,
+                capture: Optional[dict] = None) -> torch.Tensor:
+        """x [B, n_sequence+2, 3, H, W] fp32 in [0,1] -> [B, 3, H, W] (unclamped).
+
+        ``routing`` (optional, beyond the reference signature): per-sample "frame 3 is all zero" decisions when the
+        caller already knows them (the harness zeroes the frame itself), which removes the host sync.
+        ``profile`` (optional): {op name: []} filled with HIP event pairs around those ops (eager launches only).
+        ``capture`` (optional): a dict that receives SearchTransfer's arg-max / weight map (parity tests; eager only).
+        """
+        self._check_input(x)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
             raise RuntimeError("speinet_amd: backward kernels are not built yet; use eval() under torch.no_grad()")
         _lib.lib()
-        ops.set_precision(self.precision, self.corr_precision)
-        engine.STREAMS = max(1, int(self.streams))
-        x = x.contiguous().float()
-        P = self._pack(x.device)
-        zero_ref = list(routing) if routing is not None else self._route(x)
-        if self.use_graph:
-            return self._forward_graph(x, P, zero_ref)
-        out = torch.empty(x.shape[0], 3, h, w, device=x.device, dtype=torch.float32)
-        for b in range(x.shape[0]):
-            engine.forward_sample(x[b], P, self.n_sequence, not zero_ref[b], out[b])
-        return out
+        h, w = x.shape[-2:]
+        with torch.cuda.device(x.device):           # kernels launch on the CURRENT device: make it the tensor's
+            ctx = self._ctx(x.device, profile, capture)
+            x = x.contiguous().float()
+            P = self._pack(x.device)
+            zero_ref = list(routing) if routing is not None else self._route(ctx, x)
+            if self.use_graph and profile is None and capture is None:
+                return self._forward_graph(ctx, x, P, zero_ref)
+            out = torch.empty(x.shape[0], 3, h, w, device=x.device, dtype=torch.float32)
+            sides = self._sides(x.device)
+            for b in range(x.shape[0]):
+                engine.forward_sample(ctx, x[b], P, self.n_sequence, not zero_ref[b], out[b], sides)
+            return out
 
     def forward_window(self, x: torch.Tensor, keys: Sequence, cache: "EncoderCache", zero_ref: bool) -> torch.Tensor:
         """One window of a clip with cross-window reuse of the per-frame encoder work (not part of the
@@ -273,39 +310,40 @@ class SPEINet(nn.Module):
         with equal ids MUST have equal pixels; cache: an `EncoderCache` the caller keeps per clip.  Bit-identical to
         `forward(x)`: the same kernels run on the same operands, only less often.  The encoder passes that are missing
         run eagerly; everything after them replays as one hipGraph when `use_graph` is set."""
-        if x.dim() != 5 or x.shape[0] != 1 or x.shape[1] != self.n_sequence + 2 or len(keys) != self.n_sequence + 2:
-            raise ValueError(f"expected x [1,{self.n_sequence + 2},3,H,W] and {self.n_sequence + 2} keys")
-        h, w = x.shape[-2:]
-        if h % 20 or w % 20:
-            raise ValueError(f"H and W must be multiples of 20; got {h}x{w}")
-        if not x.is_cuda:
-            raise RuntimeError("speinet_amd.SPEINet runs on MI355X only (HIP kernels); there is no CPU path")
+        self._check_input(x, batch1=True)
+        if len(keys) != self.n_sequence + 2:
+            raise ValueError(f"expected {self.n_sequence + 2} keys")
         _lib.lib()
-        ops.set_precision(self.precision, self.corr_precision)
-        engine.STREAMS = max(1, int(self.streams))
+        with torch.cuda.device(x.device):
+            return self._forward_window(x, keys, cache, zero_ref)
+
+    def _forward_window(self, x, keys, cache, zero_ref):
+        h, w = x.shape[-2:]
+        ctx = self._ctx(x.device)
         x = x.contiguous().float()
         P = self._pack(x.device)
+        sides = self._sides(x.device)
         n, mid = self.n_sequence, self.n_sequence // 2
-        tag = (self.precision, self.corr_precision, h, w, self._packed_key)
+        tag = (h, w) + self._mode_key(x.device)
 
         def raw(i):
-            return cache.get((tag, keys[i], "raw")) or cache.put((tag, keys[i], "raw"), engine.encode_raw(x[0, i], P))
+            return cache.get((tag, keys[i], "raw")) or cache.put((tag, keys[i], "raw"), engine.encode_raw(ctx, x[0, i], P))
 
         def summed(i, iters):
             k = (tag, keys[i], iters)
-            return cache.get(k) or cache.put(k, engine.encode_sum(x[0, i], iters, raw(i), P))
+            return cache.get(k) or cache.put(k, engine.encode_sum(ctx, x[0, i], iters, raw(i), P))
 
         f_mid = summed(mid, 5)
         feats = [summed(i, 1) for i in range(n) if i != mid]
         lv = None
         if not zero_ref:
             k = (tag, keys[n + 1], "ref")
-            lv = cache.get(k) or cache.put(k, engine.reference_pyramid(x[0, n + 1], P))
+            lv = cache.get(k) or cache.put(k, engine.reference_pyramid(ctx, x[0, n + 1], P))
         out = torch.empty(1, 3, h, w, device=x.device, dtype=torch.float32)
         if not self.use_graph:
-            engine.fuse_and_decode(f_mid, feats, lv, P, n, out[0])
+            engine.fuse_and_decode(ctx, f_mid, feats, lv, P, n, out[0], sides)
             return out
-        gkey = ("window", h, w, bool(zero_ref), self.precision, self.corr_precision, self.streams, str(x.device), self._packed_key)
+        gkey = ("window", h, w, bool(zero_ref)) + self._mode_key(x.device)
         g = self._graphs.get(gkey)
         if g is None:
             from .ops import FMap
@@ -316,11 +354,11 @@ class SPEINet(nn.Module):
             side = torch.cuda.Stream(device=x.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):           # warm-up off the capture
-                engine.fuse_and_decode(s_mid, s_feats, s_lv, P, n, s_out[0])
+                engine.fuse_and_decode(ctx, s_mid, s_feats, s_lv, P, n, s_out[0], sides)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                engine.fuse_and_decode(s_mid, s_feats, s_lv, P, n, s_out[0])
+                engine.fuse_and_decode(ctx, s_mid, s_feats, s_lv, P, n, s_out[0], sides)
             if len(self._graphs) >= 4:
                 self._graphs.clear()
             g = self._graphs[gkey] = (graph, s_mid, s_feats, s_lv, s_out)
@@ -334,24 +372,25 @@ class SPEINet(nn.Module):
         graph.replay()
         return s_out.clone()
 
-    def _forward_graph(self, x: torch.Tensor, P: dict, zero_ref: list) -> torch.Tensor:
+    def _forward_graph(self, ctx: ops.Ctx, x: torch.Tensor, P: dict, zero_ref: list) -> torch.Tensor:
         """Replay the ~1500 launches of a frame as ONE hipGraph (captured once per shape / routing / precision):
         the per-launch host cost (ctypes + hipLaunch, ~10 us each) otherwise leaves the GPU idle ~15 % of a frame."""
-        key = (tuple(x.shape), tuple(zero_ref), self.precision, self.corr_precision, self.streams, str(x.device), self._packed_key)
+        key = (tuple(x.shape), tuple(zero_ref)) + self._mode_key(x.device)
         g = self._graphs.get(key)
         if g is None:
+            sides = self._sides(x.device)
             static_x = x.clone()
             static_out = torch.empty(x.shape[0], 3, x.shape[-2], x.shape[-1], device=x.device, dtype=torch.float32)
             side = torch.cuda.Stream(device=x.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):       # warm-up off the capture: sets kernel attributes, fills the allocator
                 for b in range(x.shape[0]):
-                    engine.forward_sample(static_x[b], P, self.n_sequence, not zero_ref[b], static_out[b])
+                    engine.forward_sample(ctx, static_x[b], P, self.n_sequence, not zero_ref[b], static_out[b], sides)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 for b in range(x.shape[0]):
-                    engine.forward_sample(static_x[b], P, self.n_sequence, not zero_ref[b], static_out[b])
+                    engine.forward_sample(ctx, static_x[b], P, self.n_sequence, not zero_ref[b], static_out[b], sides)
             if len(self._graphs) >= 4:
                 self._graphs.clear()
             g = self._graphs[key] = (graph, static_x, static_out)

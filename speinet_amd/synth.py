@@ -127,3 +127,44 @@ def synth_frames(b: int, h: int, w: int, seed: int = 1234, zero_ref: tuple = ())
         if bi in zero_ref:
             out[bi, 3] = 0.0
     return torch.from_numpy(out)
+
+
+def synth_frames_edges(b: int, h: int, w: int, seed: int = 1700, zero_ref: tuple = ()):
+    """A second, edge-dominated content class (the shape of a deblurring workload rather than of a smooth field):
+    a sharp scene of random flat rectangles and discs over a gentle gradient plus fine texture; frames 0..2 are
+    that scene under per-frame translation and a horizontal box blur (motion-blur stand-in, 7..13 taps), frame 3 a
+    sharp neighbour, frame 4 the sharp reference.  Returns (x [b,5,3,h,w] in [0,1], gt [b,3,h,w]): gt is the sharp
+    scene at the middle frame's position, the PSNR target of the full-size golden case G17."""
+    r = np.random.RandomState(seed)
+    x = np.empty((b, 5, 3, h, w), dtype=np.float32)
+    gt = np.empty((b, 3, h, w), dtype=np.float32)
+    yy, xx = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing="ij")
+    for bi in range(b):
+        scene = np.empty((3, h, w), dtype=np.float32)
+        for c in range(3):
+            scene[c] = 0.35 + 0.3 * (yy / h) * r.uniform(0.3, 1.0) + 0.2 * (xx / w) * r.uniform(0.3, 1.0)
+        for _ in range(60):
+            col = r.uniform(0.05, 0.95, size=3).astype(np.float32)
+            cy, cx = r.uniform(0, h), r.uniform(0, w)
+            ry, rx = r.uniform(h * 0.02, h * 0.2), r.uniform(w * 0.02, w * 0.2)
+            if r.rand() < 0.5:
+                m = (np.abs(yy - cy) < ry) & (np.abs(xx - cx) < rx)
+            else:
+                m = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1.0
+            scene[:, m] = col[:, None]
+        tex = 0.03 * np.sin(0.9 * xx + 0.4 * yy) * np.sin(0.23 * yy - 0.11 * xx)
+        scene = np.clip(scene + tex[None], 0.0, 1.0).astype(np.float32)
+        for f in range(5):
+            dy, dx = (f - 1) * 2, (1 - f) * 3
+            moved = np.roll(scene, (dy, dx), axis=(1, 2))
+            if f < 3:
+                taps = 7 + 2 * int(r.randint(0, 4))
+                acc = np.zeros_like(moved)
+                for t in range(taps):
+                    acc += np.roll(moved, t - taps // 2, axis=2)
+                moved = acc / taps
+            x[bi, f] = np.clip(moved + 0.004 * r.randn(3, h, w).astype(np.float32), 0.0, 1.0)
+        gt[bi] = scene                              # frame 1 has dy = dx = 0
+        if bi in zero_ref:
+            x[bi, 3] = 0.0
+    return torch.from_numpy(x), torch.from_numpy(gt)

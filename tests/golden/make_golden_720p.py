@@ -1,11 +1,20 @@
 #!/usr/bin/env python3
-"""G14-G16: the REFERENCE's own forward pass at the full sizes (synthetic weights seed 0): the bench configuration
-(1 x 5 x 3 x 720 x 1280, `_forwardbs`), the same with a zeroed reference frame (`_forwardb`), and a mixed-routing batch of
-two at 480 x 640 (the BSD frame size) — minutes and ~20 GB on the build container's CPU.  Only a subsampled view of each
-output is committed: every 8th pixel, the per-channel mean / standard deviation of the full frame and its PSNR (uint8,
-4-pixel crop) against the middle input frame; the inputs are regenerated from their seeds by the tests.
+"""G14-G17: the REFERENCE's own forward pass at the full sizes (synthetic weights seed 0): the bench configuration
+(1 x 5 x 3 x 720 x 1280, `_forwardbs`), the same with a zeroed reference frame (`_forwardb`), a mixed-routing batch of
+two at 480 x 640 (the BSD frame size), and an edge-dominated 720p window (`synth_frames_edges`: blurred frames + sharp
+reference) — minutes and ~20 GB each on the build container's CPU.
 
-Run:  python tests/golden/make_golden_720p.py [case ...]     (needs /root/reference; writes tests/golden/g1[456]_*.npz)
+Committed per case (inputs are regenerated from their seeds by the tests):
+  sub, mean, std, psnr   every 8th pixel of the reference's output, per-channel statistics of the full frame, its PSNR
+                         (uint8, 4-pixel crop) against the stand-in target (middle input frame; G17: the sharp scene)
+  arg, s                 what the reference's SearchTransfer / SelfTransfer computed inside that forward pass
+                         (model/SearchTransfer.py:33-34): the arg-max index handed to `bis` (int32 [N3]; SearchTransfer only)
+                         and the weight map S = R.max (f32 [N3]) — recorded by hooks on the reference's own modules
+  margin                 top-1 minus top-2 of each query's correlation column (f32 [N3]), recomputed blockwise by this script
+                         from the tensors the reference handed to SearchTransfer (same unfold / normalize / matmul in fp32):
+                         lets a test tell a near-tie from a wrong winner.  Not a reference output; labelled as such.
+
+Run:  python tests/golden/make_golden_720p.py [case ...]     (needs /root/reference; writes tests/golden/g1[4567]_*.npz)
 """
 import os
 import sys
@@ -13,38 +22,92 @@ import time
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 from make_golden import import_reference, template_args      # noqa: E402
 
 
+def top2_margin(lr3: torch.Tensor, rf3: torch.Tensor, block: int = 2048):
+    """[1,C,H,W] x 2 -> (top1, arg, top1 - top2) per query position, blockwise (R is never materialised)."""
+    lu = F.normalize(F.unfold(lr3, (3, 3), padding=1), dim=1)[0]                     # [C*9, N]
+    ru = F.normalize(F.unfold(rf3, (3, 3), padding=1).permute(0, 2, 1), dim=2)[0]    # [Nr, C*9]
+    n = lu.shape[1]
+    best = torch.full((2, n), -float("inf"))
+    arg = torch.zeros(n, dtype=torch.long)
+    for j0 in range(0, ru.shape[0], block):
+        r = ru[j0:j0 + block] @ lu                                                     # [block, N]
+        v, i = torch.topk(r, 2, dim=0)
+        cand = torch.cat((best, v), 0)
+        cv, ci = torch.topk(cand, 2, dim=0)
+        newarg = torch.where(ci[0] == 0, arg, torch.where(ci[0] == 2, i[0] + j0, torch.where(ci[0] == 3, i[1] + j0, arg)))
+        arg, best = newarg, cv
+    return best[0], arg, best[0] - best[1]
+
+
 def main():
-    from speinet_amd.synth import synth_frames, synth_state_dict
+    from speinet_amd.synth import synth_frames, synth_frames_edges, synth_state_dict
+    from oracle import speinet_oracle as O
     ms, *_ = import_reference()
     torch.manual_seed(0)
     torch.set_num_threads(8)
     net = ms.SPEINet(in_channels=3, n_sequence=3, out_channels=3, n_resblock=3, n_feat=32, device="cpu", args=template_args())
     net.load_state_dict(synth_state_dict(net.state_dict(), seed=0), strict=True)
     net.eval()
-    cases = [("g14_fwd_720p", 1401, 1, 720, 1280, ()), ("g15_fwd_720p_noref", 1501, 1, 720, 1280, (0,)),
-             ("g16_fwd_480x640_mixed", 1601, 2, 480, 640, (1,))]
+
+    rec = {}
+    bis0 = net.SearchTransfer.bis
+
+    def bis_spy(inp, dim, index):                 # the reference's own index tensor, as it reaches its gather
+        rec.setdefault("arg", index.detach().clone())
+        return bis0(inp, dim, index)
+
+    net.SearchTransfer.bis = bis_spy
+    net.SearchTransfer.register_forward_pre_hook(lambda m, a: rec.update(st_in=(a[0].detach().clone(), a[1].detach().clone())))
+    net.SearchTransfer.register_forward_hook(lambda m, a, o: rec.update(s_search=o[0].detach().clone()))
+    net.SelfTransfer.register_forward_pre_hook(lambda m, a: rec.update(self_in=a[0].detach().clone()))
+    net.SelfTransfer.register_forward_hook(lambda m, a, o: rec.update(s_self=o[0].detach().clone()))
+
+    cases = [("g14_fwd_720p", 1401, 1, 720, 1280, (), "smooth"), ("g15_fwd_720p_noref", 1501, 1, 720, 1280, (0,), "smooth"),
+             ("g16_fwd_480x640_mixed", 1601, 2, 480, 640, (1,), "smooth"), ("g17_fwd_720p_edges", 1701, 1, 720, 1280, (), "edges")]
     only = sys.argv[1:]
-    for name, seed, b, h, w, zero_ref in cases:
+    for name, seed, b, h, w, zero_ref, kind in cases:
         if only and name not in only:
             continue
-        x = synth_frames(b, h, w, seed=seed, zero_ref=zero_ref)
+        if kind == "edges":
+            x, gt = synth_frames_edges(b, h, w, seed=seed, zero_ref=zero_ref)
+        else:
+            x = synth_frames(b, h, w, seed=seed, zero_ref=zero_ref)
+            gt = x[:, 1]
+        rec.clear()
         t0 = time.time()
         with torch.no_grad():
             out = net(x)
-        print(f"{name}: reference forward {time.time() - t0:.0f} s, output range [{out.min():.3f}, {out.max():.3f}]")
-        # the harness metric of the reference's frame (uint8 round trip, 4-pixel border cropped, inference_SPEINet.py:484-500)
-        # against the window's middle input frame as the stand-in target: lets the tests state a PSNR delta at full size
-        from oracle import speinet_oracle as O
-        psnr = np.array([O.psnr_uint8(O.to_uint8(out[i:i + 1]), O.to_uint8(x[i:i + 1, 1])) for i in range(b)])
+        print(f"{name}: reference forward {time.time() - t0:.0f} s, output range [{out.min():.3f}, {out.max():.3f}]", flush=True)
+        psnr = np.array([O.psnr_uint8(O.to_uint8(out[i:i + 1]), O.to_uint8(gt[i:i + 1])) for i in range(b)])
+        extra = {}
+        n3 = (h // 4) * (w // 4)
+        if "arg" in rec:                           # samples routed through SearchTransfer (batch order of the ~zero mask)
+            nb = rec["arg"].shape[0]
+            extra["arg"] = rec["arg"].view(nb, n3).numpy().astype(np.int32)
+            extra["s"] = rec["s_search"].reshape(nb, n3).numpy()
+            mg = []
+            for i in range(nb):
+                t1 = time.time()
+                top1, a2, m = top2_margin(rec["st_in"][0][i:i + 1], rec["st_in"][1][i:i + 1])
+                agree = (a2 == rec["arg"][i].view(-1)).float().mean().item()
+                print(f"  margin recompute sample {i}: {time.time() - t1:.0f} s, arg agreement with the reference {agree:.6f}, "
+                      f"max |top1 - S| {(top1 - rec['s_search'][i].view(-1)).abs().max():.2e}, margins < 1e-5: {(m < 1e-5).sum().item()}",
+                      flush=True)
+                mg.append(m.numpy())
+            extra["margin"] = np.stack(mg)
+        if "s_self" in rec:
+            extra["s_self"] = rec["s_self"].reshape(rec["s_self"].shape[0], n3).numpy()
         np.savez_compressed(os.path.join(HERE, name + ".npz"), seed=seed, zero_ref=np.array(zero_ref, dtype=np.int64),
                             sub=out[:, :, ::8, ::8].numpy(), mean=out.mean(dim=(2, 3)).numpy(), std=out.std(dim=(2, 3)).numpy(),
-                            psnr=psnr)
+                            psnr=psnr, kind=np.array(kind), **extra)
+        print(f"  wrote {name}.npz ({os.path.getsize(os.path.join(HERE, name + '.npz')) / 1024:.0f} KB): psnr {psnr}", flush=True)
 
 
 if __name__ == "__main__":

@@ -15,7 +15,8 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from oracle import speinet_oracle as O           # noqa: E402
-from speinet_amd import engine, ops, pack        # noqa: E402
+from speinet_amd import engine, pack             # noqa: E402
+from speinet_amd.ops import Ctx                  # noqa: E402
 from speinet_amd.ops import FMap                 # noqa: E402
 from speinet_amd.speinet import SPEINet, default_args  # noqa: E402
 from speinet_amd.synth import synth_frames       # noqa: E402
@@ -44,19 +45,13 @@ def relerr(a, b):
     return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
 
 
-@pytest.fixture(autouse=True)
-def _restore_precision():
-    yield
-    ops.set_precision("f32", "bf16x3")
-
-
 @pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("cin,cout,k,stride,h,w", [
     (32, 32, 5, 1, 20, 24), (64, 64, 5, 1, 13, 17), (128, 128, 5, 1, 10, 15), (32, 64, 5, 2, 40, 60),
     (64, 128, 5, 2, 22, 18), (128, 256, 3, 1, 10, 15), (256, 256, 3, 1, 9, 11), (256, 128, 3, 1, 10, 15),
     (384, 128, 1, 1, 10, 15), (64, 32, 1, 1, 21, 19), (96, 32, 3, 1, 21, 19), (512, 256, 1, 1, 33, 7)])
 def test_igemm_conv(mode, cin, cout, k, stride, h, w):
-    ops.set_precision(mode)
+    ops = Ctx(mode, device=DEV)
     x = rnd(1, 1, cin, h, w)
     wt = rnd(2, cout, cin, k, k, scale=1.0 / np.sqrt(cin * k * k))
     b = rnd(3, cout, scale=0.1)
@@ -68,7 +63,7 @@ def test_igemm_conv(mode, cin, cout, k, stride, h, w):
 
 @pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
 def test_igemm_concat_transpose_epilogue(mode):
-    ops.set_precision(mode)
+    ops = Ctx(mode, device=DEV)
     h, w = 14, 22
     xa, xb = rnd(4, 1, 64, h, w), rnd(5, 1, 32, h, w)
     wt, b, res = rnd(6, 64, 96, 3, 3, scale=0.05), rnd(7, 64, scale=0.1), rnd(8, 1, 64, h, w)
@@ -92,9 +87,9 @@ def test_igemm_concat_transpose_epilogue(mode):
 @pytest.mark.parametrize("name", ["g07_search", "g07_search_tie"])
 def test_search_bf16x3_argmax_exact(golden_dir, name):
     """With split-bf16 scores the arg-max of the golden cases (incl. the exact-tie one) stays bit exact."""
-    ops.set_precision("bf16x3", "bf16x3")
+    ops = Ctx("bf16x3", "bf16x3", device=DEV)
     d = g(golden_dir, name)
-    s, t3, t2, t1, arg = engine.search_transfer(fm(d["lr3"]), fm(d["rf1"]), fm(d["rf2"]), fm(d["rf3"]), return_arg=True)
+    s, t3, t2, t1, arg = engine.search_transfer(ops, fm(d["lr3"]), fm(d["rf1"]), fm(d["rf2"]), fm(d["rf3"]), return_arg=True)
     assert torch.equal(arg.cpu().long(), d["arg"][0])
     assert relerr(s.view(1, 1, 10, 15), d["s"]) < 2e-5
     assert relerr(t1.nchw(), d["t1"]) < 1e-6
@@ -102,11 +97,11 @@ def test_search_bf16x3_argmax_exact(golden_dir, name):
 
 def test_search_bf16_flip_rate():
     """Single-bf16 scores: the winner may flip between near-tied candidates; measure it on a 20x30 map."""
-    ops.set_precision("bf16", "bf16")
+    ops = Ctx("bf16", "bf16", device=DEV)
     lr3, rf3 = rnd(32, 1, 128, 20, 30), rnd(33, 1, 128, 20, 30)
     rf2, rf1 = rnd(34, 1, 64, 40, 60), rnd(35, 1, 32, 80, 120)
     s0, _, _, _, arg0 = O.search_transfer(lr3, rf3, rf1, rf2, rf3, return_arg=True)
-    s, t3, t2, t1, arg = engine.search_transfer(fm(lr3), fm(rf1), fm(rf2), fm(rf3), return_arg=True)
+    s, t3, t2, t1, arg = engine.search_transfer(ops, fm(lr3), fm(rf1), fm(rf2), fm(rf3), return_arg=True)
     flips = (arg.cpu().long() != arg0[0]).float().mean().item()
     serr = (s.cpu() - s0.reshape(-1)).abs().max().item()
     print(f"bf16 correlation: flip rate {flips:.3%}, max |S err| {serr:.2e}")
@@ -160,7 +155,7 @@ def test_forward_bf16_golden(golden_dir, net, name, b, h, w):
 
 def test_mlp_fused_vs_oracle(synth_sd):
     """Fused LN -> fc1 -> GELU -> fc2 -> +x kernel against the fp32 formula (bf16 products: 1.5e-2 of max|ref|)."""
-    ops.set_precision("bf16")
+    ops = Ctx("bf16", device=DEV)
     p = "swin.layers.1.residual_group.blocks.2."
     bk = pack.swin_block(synth_sd, p, 8, 5)
     w1, w2 = pack.PackedW(bk["w1"].t, DEV), pack.PackedW(bk["w2"].t, DEV)
@@ -182,7 +177,7 @@ def test_mlp_fused_vs_oracle(synth_sd):
 def test_attn_fused_vs_oracle(synth_sd, h, w, shift):
     """Fused LN -> q/kv -> shifted-window attention -> proj -> +x kernel against the oracle's attention branch
     (model/swinir.py:238-278); odd window counts leave the second window slot of the last workgroup empty."""
-    ops.set_precision("bf16")
+    ops = Ctx("bf16", device=DEV)
     p = "swin.layers.2.residual_group.blocks.1."
     bk = {k: (v.to(DEV) if torch.is_tensor(v) else pack.PackedW(v.t, DEV)) for k, v in pack.swin_block(synth_sd, p, 8, 5).items()}
     m = h * w
@@ -253,7 +248,7 @@ def test_forward_large_sizes_modes_agree(net, h, w, b, zero_ref):
 
 def test_conv5_out_slab():
     """Last conv (32 -> 3 channels, NCHW planes out) on the slab kernel in "bf16" mode; odd sizes -> partial tiles."""
-    ops.set_precision("bf16")
+    ops = Ctx("bf16", device=DEV)
     f = rnd(21, 1, 32, 27, 45)
     wo, bo = rnd(22, 3, 32, 5, 5, scale=0.05), rnd(23, 3, scale=0.1)
     w = pack.conv_w(wo)
@@ -271,7 +266,7 @@ def test_up_conv1x1_relu_commuted():
     wt, b = rnd(32, 64, 128, 1, 1, scale=0.08), rnd(33, 64, scale=0.2)
     ref = F.relu(F.conv2d(F.interpolate(x, scale_factor=2, mode="bicubic"), wt, b))
     for mode in ("bf16x3", "bf16"):
-        ops.set_precision(mode)
+        ops = Ctx(mode, device=DEV)
         out = ops.up_conv1x1_relu(fm(x), pack.conv_w(wt).to(DEV), b.to(DEV), 64)
         assert relerr(out.nchw(), ref) < TOL[mode], mode
 
@@ -281,7 +276,7 @@ def test_full_size_search_properties(mode, corr):
     """Size-independent properties at the 720p map size (180 x 320 positions, 128 channels; no oracle run at this size):
     a map correlated with itself finds every position at itself with a normalised score of 1, a shifted copy is found at the
     shift, and gathering with the identity indices reproduces the map (fold(unfold(x)) / 9: exactly x away from the border)."""
-    ops.set_precision(mode, corr)
+    ops = Ctx(mode, corr, device=DEV)
     h, w = 180, 320
     gen = torch.Generator().manual_seed(5)
     f = FMap(torch.randn(h * w, 128, generator=gen).to(DEV), h, w, 128)
@@ -307,7 +302,7 @@ def test_full_size_conv_identity(mode):
     """Identity kernels at the 720p layer sizes (no oracle run at these sizes): a centre-tap identity convolution must return
     its input exactly (bf16-rounded in "bf16" mode: x * 1 + zeros is exact) at every pixel incl. the map border and every
     partial tile; stride 2 returns the even pixels; the transposed conv writes the input to the even output pixels."""
-    ops.set_precision(mode)
+    ops = Ctx(mode, device=DEV)
     gen = torch.Generator().manual_seed(9)
     rnd_in = lambda x: x.bfloat16().float() if mode == "bf16" else x
     for c, h, w, ks in ((32, 720, 1280, 5), (64, 360, 640, 5), (128, 180, 320, 5), (256, 180, 320, 3)):
@@ -338,7 +333,7 @@ def test_full_size_swin_properties(synth_sd):
     windows): (i) MLP with fc2 = 0 returns x exactly; (ii) attention with proj = 0 returns x exactly; (iii) with V = a
     constant vector c (zero V weights, bias c) and proj = identity, softmax rows summing to 1 give x + c for every token
     of every (shifted, masked) window, up to the bf16 rounding of the probabilities."""
-    ops.set_precision("bf16")
+    ops = Ctx("bf16", device=DEV)
     h, w = 180, 320
     m = h * w
     gen = torch.Generator().manual_seed(13)

@@ -81,7 +81,5 @@ def test_forward_window_reuse_bit_identical(graph):
             ref = net(x, routing=[pre_zero])
             net.use_graph = graph
             assert torch.equal(out_w, ref), f"window {t}"
-    from speinet_amd import ops
-    ops.set_precision("f32", "bf16x3")               # the arithmetic mode is process-global: leave the default behind
     # 8 raw + 6 RL-5 + 8 RL-1 encoder passes and 2 reference pyramids were computed, instead of 36 + 5 without the cache
     assert cache.misses == 24 and cache.hits >= 10, (cache.hits, cache.misses)

@@ -14,20 +14,15 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _f32_mode():
-    """These tests check the exact-fp32 path; the arithmetic mode is a process-global that other test modules change."""
-    from speinet_amd import ops as _ops
-    _ops.set_precision("f32", "bf16x3")
-    yield
-
 from oracle import speinet_oracle as O           # noqa: E402
-from speinet_amd import engine, ops, pack        # noqa: E402
+from speinet_amd import engine, pack             # noqa: E402
+from speinet_amd.ops import Ctx                  # noqa: E402
 from speinet_amd.ops import FMap                 # noqa: E402
 from speinet_amd.speinet import SPEINet, default_args  # noqa: E402
 from speinet_amd.synth import synth_frames       # noqa: E402
 
 DEV = "cuda:0"
+ops = Ctx("f32", "bf16x3", device=DEV)      # these tests check the exact-fp32 path; the mode lives in the call context
 
 
 def g(golden_dir, name):
@@ -177,9 +172,9 @@ def test_resblock_ragged_vs_oracle(synth_sd):
 
 def test_encoder_golden(golden_dir, P):
     d = g(golden_dir, "g03_enc")
-    lv1 = engine.in_block(d["x"][0].to(DEV).contiguous(), P["inBlock"])
-    lv2 = engine.enc_stage(lv1, P["encoder_first"])
-    lv3 = engine.enc_stage(lv2, P["encoder_second"])
+    lv1 = engine.in_block(ops, d["x"][0].to(DEV).contiguous(), P["inBlock"])
+    lv2 = engine.enc_stage(ops, lv1, P["encoder_first"])
+    lv3 = engine.enc_stage(ops, lv2, P["encoder_second"])
     close(lv1.nchw(), d["lv1"], 1e-4, 1e-5, "lv1")
     close(lv2.nchw(), d["lv2"], 1e-4, 1e-5, "lv2")
     close(lv3.nchw(), d["lv3"], 1e-4, 1e-5, "lv3")
@@ -227,7 +222,7 @@ def test_swin_golden(golden_dir, P):
     d = g(golden_dir, "g06_swin")
     x = fm(d["x"])
     out = FMap.empty(10, 15, 128, DEV)
-    engine.swin(engine.SwinX(x, P["swin"]), fm(d["y"]), P["swin"], out)
+    engine.swin(ops, engine.SwinX(ops, x, P["swin"]), fm(d["y"]), P["swin"], out)
     close(out.nchw(), d["out"], 2e-4, 1e-5, "swin")
 
 
@@ -235,14 +230,14 @@ def test_swin_golden(golden_dir, P):
 def test_swin_vs_oracle(synth_sd, P, h, w):
     x, y = rnd(30, 1, 128, h, w, scale=0.5), rnd(31, 1, 128, h, w, scale=0.5)
     out = FMap.empty(h, w, 128, DEV)
-    engine.swin(engine.SwinX(fm(x), P["swin"]), fm(y), P["swin"], out)
+    engine.swin(ops, engine.SwinX(ops, fm(x), P["swin"]), fm(y), P["swin"], out)
     close(out.nchw(), O.swin(x, y, synth_sd, O.Cfg()), 2e-4, 1e-5, "swin oracle")
 
 
 @pytest.mark.parametrize("name", ["g07_search", "g07_search_tie"])
 def test_search_transfer_golden(golden_dir, name):
     d = g(golden_dir, name)
-    s, t3, t2, t1, arg = engine.search_transfer(fm(d["lr3"]), fm(d["rf1"]), fm(d["rf2"]), fm(d["rf3"]), return_arg=True)
+    s, t3, t2, t1, arg = engine.search_transfer(ops, fm(d["lr3"]), fm(d["rf1"]), fm(d["rf2"]), fm(d["rf3"]), return_arg=True)
     assert torch.equal(arg.cpu().long(), d["arg"][0]), "arg-max differs from the reference"
     close(s.view(1, 1, 10, 15), d["s"], 1e-5, 1e-6, "S")
     close(t3.nchw(), d["t3"], 1e-5, 1e-6, "T3")
@@ -255,7 +250,7 @@ def test_search_transfer_ragged_vs_oracle():
     lr3, rf3 = rnd(32, 1, 128, 15, 20), rnd(33, 1, 128, 15, 20)
     rf2, rf1 = rnd(34, 1, 64, 30, 40), rnd(35, 1, 32, 60, 80)
     s0, t30, t20, t10, arg0 = O.search_transfer(lr3, rf3, rf1, rf2, rf3, return_arg=True)
-    s, t3, t2, t1, arg = engine.search_transfer(fm(lr3), fm(rf1), fm(rf2), fm(rf3), return_arg=True)
+    s, t3, t2, t1, arg = engine.search_transfer(ops, fm(lr3), fm(rf1), fm(rf2), fm(rf3), return_arg=True)
     flips = (arg.cpu().long() != arg0[0]).sum().item()
     assert flips == 0, f"{flips} arg-max flips"
     close(s.view_as(s0[0, 0].reshape(-1)), s0.reshape(-1), 1e-5, 1e-6, "S")
@@ -264,7 +259,7 @@ def test_search_transfer_ragged_vs_oracle():
 
 def test_self_transfer_golden(golden_dir, P):
     d = g(golden_dir, "g08_self")
-    s, t3, t2, t1 = engine.self_transfer(fm(d["x"]), P)
+    s, t3, t2, t1 = engine.self_transfer(ops, fm(d["x"]), P)
     close(s.view(1, 1, 10, 15), d["s"], 1e-5, 1e-6, "S")
     close(t2.nchw(), d["t2"], 1e-4, 1e-5, "T2")
     close(t1.nchw(), d["t1"], 1e-4, 1e-5, "T1")
@@ -279,7 +274,7 @@ def test_bicubic(c, s, h, w):
 def test_decode_golden(golden_dir, P):
     d = g(golden_dir, "g09_decode")
     out = torch.empty(3, 40, 60, device=DEV)
-    engine.decode(fm(d["ff"]), d["s"].reshape(-1).to(DEV).contiguous(), fm(d["t3"]), fm(d["t2"]), fm(d["t1"]), P, out)
+    engine.decode(ops, fm(d["ff"]), d["s"].reshape(-1).to(DEV).contiguous(), fm(d["t3"]), fm(d["t2"]), fm(d["t1"]), P, out)
     close(out, d["out"][0], 2e-4, 1e-4, "decode")
 
 

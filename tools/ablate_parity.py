@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Where does the throughput mode's error come from?  Runs the full-size golden cases (the REFERENCE's own outputs,
+tests/golden/g14..g17) through a list of arithmetic configurations and prints, per configuration and case,
+max |err| on the committed 8x8 grid, |dPSNR| against the reference's PSNR (the north-star criterion, 1e-3 dB) and the
+number of SearchTransfer arg-max positions that differ from the reference's own arg-max.
+
+    python tools/ablate_parity.py [--cases g14_fwd_720p,...] [--out gpurun_out/ablate_parity.json]
+
+Configurations: the three modes, every stage of the path switched to bf16 on its own over an f32-grade (bf16x3)
+remainder, and every storage / fusion knob of the bf16 mode switched off on its own (speinet_amd.ops.Ctx).
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import speinet_oracle as O                                                     # noqa: E402  (checker only)
+from speinet_amd.speinet import SPEINet, default_args                                      # noqa: E402
+from speinet_amd.synth import state_dict_template, synth_frames, synth_frames_edges, synth_state_dict   # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+BF = {"precision": "bf16"}
+CONFIGS = [
+    ("f32", "f32", "bf16x3", {}),
+    ("bf16x3 / corr bf16x3", "bf16x3", "bf16x3", {}),
+    ("bf16x3 / corr bf16r", "bf16x3", "bf16r", {}),
+    ("bf16x3 / corr bf16", "bf16x3", "bf16", {}),
+    ("only enc bf16", "bf16x3", "bf16x3", {"stage": {"enc": BF}}),
+    ("only swin bf16", "bf16x3", "bf16x3", {"stage": {"swin": BF}}),
+    ("only decode bf16", "bf16x3", "bf16x3", {"stage": {"decode": BF}}),
+    ("bf16 / corr bf16x3", "bf16", "bf16x3", {}),
+    ("bf16 / corr bf16r", "bf16", "bf16r", {}),
+    ("bf16 / corr bf16  (round-1 bench mode)", "bf16", "bf16", {}),
+    ("bf16r, x1 fp32", "bf16", "bf16r", {"x1_bf16": False}),
+    ("bf16r, fp32 storage", "bf16", "bf16r", {"bf16_storage": False}),
+    ("bf16r, unfused MLP (erf GELU)", "bf16", "bf16r", {"fuse_mlp": False}),
+    ("bf16r, unfused attention", "bf16", "bf16r", {"fuse_attn": False}),
+    ("bf16r, conv after upsample", "bf16", "bf16r", {"commute_upconv": False}),
+]
+
+
+def load_case(name):
+    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    kind = str(d["kind"]) if "kind" in d.files else "smooth"
+    b = d["sub"].shape[0]
+    h, w = d["sub"].shape[2] * 8, d["sub"].shape[3] * 8
+    zr = tuple(int(i) for i in d["zero_ref"])
+    if kind == "edges":
+        x, gt = synth_frames_edges(b, h, w, seed=int(d["seed"]), zero_ref=zr)
+    else:
+        x = synth_frames(b, h, w, seed=int(d["seed"]), zero_ref=zr)
+        gt = x[:, 1]
+    return d, x, gt, zr
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", default="g14_fwd_720p,g17_fwd_720p_edges,g16_fwd_480x640_mixed")
+    ap.add_argument("--configs", default="", help="comma-separated substrings; default all")
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "ablate_parity.json"))
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    net = SPEINet(args=default_args())
+    net.load_state_dict(synth_state_dict(state_dict_template(), seed=0), strict=True)
+    net = net.to(dev).eval()
+    want = [c for c in args.configs.split(",") if c]
+    rows = []
+    for case in args.cases.split(","):
+        d, x, gt, zr = load_case(case)
+        xd = x.to(dev)
+        sub = torch.from_numpy(d["sub"])
+        ref_arg = torch.from_numpy(d["arg"]).long() if "arg" in d.files else None
+        margin = torch.from_numpy(d["margin"]) if "margin" in d.files else None
+        ref_s = torch.from_numpy(d["s"]) if "s" in d.files else None
+        for label, prec, corr, knobs in CONFIGS:
+            if want and not any(wd in label for wd in want):
+                continue
+            net.precision, net.corr_precision, net.knobs = prec, corr, knobs
+            outs, flips, tight, serr = [], 0, 0, 0.0
+            with torch.no_grad():
+                si = 0
+                for i in range(x.shape[0]):                       # one sample at a time: capture is per SearchTransfer call
+                    cap = {}
+                    outs.append(net(xd[i:i + 1], capture=cap).cpu())
+                    if "arg" in cap and ref_arg is not None:
+                        a = cap["arg"].cpu().long()
+                        diff = a != ref_arg[si]
+                        flips += int(diff.sum())
+                        tight += int((diff & (margin[si] >= 1e-5)).sum())     # flips that are NOT reference near-ties
+                        serr = max(serr, (cap["s"].cpu() - ref_s[si]).abs().max().item())
+                        si += 1
+            out = torch.cat(outs)
+            err = (out[:, :, ::8, ::8] - sub).abs().max().item()
+            dp = max(abs(O.psnr_uint8(O.to_uint8(out[i:i + 1]), O.to_uint8(gt[i:i + 1])) - float(d["psnr"][i])) for i in range(x.shape[0]))
+            rows.append({"case": case, "config": label, "max_err_grid": err, "dpsnr_db": dp, "argmax_flips": flips,
+                         "flips_margin_ge_1e-5": tight, "max_s_err": serr})
+            print(f"{case:26s} {label:40s} max|err| {err:.2e}  |dPSNR| {dp:.2e} dB  flips {flips:5d} (non-near-tie {tight})  "
+                  f"max|dS| {serr:.1e}", flush=True)
+    net.knobs = {}
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    json.dump(rows, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -3,9 +3,10 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from speinet_amd import ops, pack
+from speinet_amd import pack
+from speinet_amd.ops import Ctx
 from speinet_amd.ops import FMap
-ops.set_precision(os.environ.get("PREC", "bf16"))
+ops = Ctx(os.environ.get("PREC", "bf16"))
 dev = "cuda:0"
 shapes = [  # name, H, W, Cin, Cout, ks, stride, residual
     ("lv1 conv5 32->32", 720, 1280, 32, 32, 5, 1, False),

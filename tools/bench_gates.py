@@ -6,12 +6,13 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from speinet_amd import ops, pack                                        # noqa: E402
+from speinet_amd import pack                         # noqa: E402
+from speinet_amd.ops import Ctx                      # noqa: E402
 from speinet_amd.ops import FMap                                         # noqa: E402
 from speinet_amd.synth import state_dict_template, synth_state_dict      # noqa: E402
 
 dev = "cuda:0"
-ops.set_precision("bf16")
+ops = Ctx("bf16", device=dev)
 sd = synth_state_dict(state_dict_template())
 for name, prefix, h, w, c in (("lv1", "recons_net.inBlock.1.", 720, 1280, 32), ("lv2", "recons_net.encoder_first.1.", 360, 640, 64),
                               ("lv3", "recons_net.encoder_second.1.", 180, 320, 128)):

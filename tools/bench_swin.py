@@ -6,12 +6,13 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from speinet_amd import ops, pack                    # noqa: E402
+from speinet_amd import pack                         # noqa: E402
+from speinet_amd.ops import Ctx                      # noqa: E402
 from speinet_amd.synth import state_dict_template, synth_state_dict    # noqa: E402
 
 H, W = 180, 320
 dev = "cuda:0"
-ops.set_precision("bf16")
+ops = Ctx("bf16", device=dev)
 sd = synth_state_dict(state_dict_template())
 p = "swin.layers.0.residual_group.blocks.1."
 bk = {k: (v.to(dev) if torch.is_tensor(v) else pack.PackedW(v.t, dev)) for k, v in pack.swin_block(sd, p, 8, 5).items()}
