@@ -29,6 +29,13 @@ typedef void* spei_stream_t; /* hipStream_t */
 #define SPEI_ACT_RELU 1
 #define SPEI_ACT_GELU 2 /* exact erf GELU (nn.GELU default, reference model/swinir.py:14-19) */
 
+/* Element formats.  16-bit entry points take `fmt` = SPEI_BF16 or SPEI_F16: the operand type of the matrix pipe
+ * (v_mfma_f32_32x32x16_bf16 / _f16, same rate, fp32 accumulation; half keeps 11 significand bits instead of 8 at a
+ * range of +-65504).  `*_fmt` arguments say how a tensor is stored in HBM: SPEI_F32 or the call's 16-bit format. */
+#define SPEI_F32 0
+#define SPEI_BF16 1
+#define SPEI_F16 2
+
 #define SPEI_CONV 0
 #define SPEI_CONV_TRANSPOSED 1 /* ConvTranspose2d(k, stride, pad=k/2, output_padding=stride-1) */
 
@@ -72,69 +79,70 @@ int spei_igemm_bf16(const float* a0, int lda0, int k0, const float* a1, int lda1
                     const float* rowscale, int Hin, int Win, int Hout, int Wout, int N, int ksize, int stride,
                     int pad, int mode, int act, spei_stream_t stream);
 
-/* Slab-resident variant of spei_igemm_bf16 for SPEI_CONV (stride 1/2) and linears: the input tile + halo is staged
- * once into LDS as bf16 and the weights stream from HBM/L2 in MFMA fragment order
- * (wfrag: [N/32][tap][K/16][64][8] bf16, see speinet_amd/pack.py).  Linears: pass Hin = Hout = M, Win = Wout = 1.
- * a_bf16 / out_bf16: the activations (both sources) / the output are bf16 instead of fp32 in HBM — used for tensors
- * that only feed the next GEMM or the attention kernel; residual, rowscale and bias stay fp32.
+/* Slab-resident variant of spei_igemm_bf16 for SPEI_CONV (stride 1/2) and linears, bf16 or half operands (`fmt`): the
+ * input tile + halo is staged once into LDS as 16-bit and the weights stream from HBM/L2 in MFMA fragment order
+ * (wfrag: [N/32][tap][K/16][64][8] 16-bit, see speinet_amd/pack.py).  Linears: pass Hin = Hout = M, Win = Wout = 1.
+ * a_fmt / out_fmt: the activations (both sources) / the output are stored as fp32 or as `fmt` in HBM — 16-bit for
+ * tensors that only feed the next GEMM or the attention kernel; residual, rowscale and bias stay fp32.
+ * wfrag_lo != NULL: the split "bf16x3" product (SPEI_BF16 with fp32 activations only).
  * ln_input: LayerNorm(256) without affine (model/swinir.py:244, affine folded into the weights) is applied to each
  * 256-wide fp32 input row while it is staged, so the normalised tokens never exist in HBM. */
-int spei_conv_slab_bf16(const void* a0, int lda0, int k0, const void* a1, int lda1, int k1, int a_bf16,
-                        const void* wfrag_hi, const void* wfrag_lo, const float* bias, void* out, int ldo, int out_bf16,
-                        const float* residual, int ldr, const float* rowscale, int Hin, int Win, int Hout, int Wout,
-                        int N, int ksize, int stride, int pad, int act, int ln_input, spei_stream_t stream);
+int spei_conv_slab16(int fmt, const void* a0, int lda0, int k0, const void* a1, int lda1, int k1, int a_fmt,
+                     const void* wfrag_hi, const void* wfrag_lo, const float* bias, void* out, int ldo, int out_fmt,
+                     const float* residual, int ldr, const float* rowscale, int Hin, int Win, int Hout, int Wout,
+                     int N, int ksize, int stride, int pad, int act, int ln_input, spei_stream_t stream);
 
-/* Fused Swin MLP branch (model/swinir.py:12-29 Mlp.forward + the `x + mlp(norm2(x))` tail of :279), bf16 matrix pipe:
+/* Fused Swin MLP branch (model/swinir.py:12-29 Mlp.forward + the `x + mlp(norm2(x))` tail of :279), 16-bit matrix pipe:
  * out = x + fc2(GELU(fc1(LayerNorm256(x)))), LayerNorm affine folded into w1/b1 (pack.py); w*_frag in MFMA fragment
  * order; the normalised tokens and the 512-wide hidden activations live only in LDS.  x, out: [M][256] fp32, may alias. */
-int spei_mlp_fused_bf16(const float* x, float* out, const void* w1_frag, const float* b1, const void* w2_frag,
-                        const float* b2, int64_t M, spei_stream_t stream);
+int spei_mlp_fused16(int fmt, const float* x, float* out, const void* w1_frag, const float* b1, const void* w2_frag,
+                     const float* b2, int64_t M, spei_stream_t stream);
 
 /* ConvTranspose2d(k = 3, stride 2, padding 1, output_padding 1) on the slab kernel (reference model/recons_video_ori.py:58-71,
  * the tails of decoder_second / decoder_first): the four output-parity classes are stride-1 convolutions over the input
- * grid with 1 / 2 / 2 / 4 taps, written with pixel stride 2.  wfrag<py><px>: fragment-ordered bf16 weights of class
- * (oy % 2, ox % 2) (speinet_amd/pack.py).  a0 [Hin*Win][lda0] fp32 or bf16, out [2Hin*2Win][ldo] fp32 or bf16. */
-int spei_convt2_slab_bf16(const void* a0, int lda0, int k0, int a_bf16, const void* wfrag00, const void* wfrag01,
-                          const void* wfrag10, const void* wfrag11, const float* bias, void* out, int ldo, int out_bf16,
-                          int Hin, int Win, int N, int act, spei_stream_t stream);
+ * grid with 1 / 2 / 2 / 4 taps, written with pixel stride 2.  wfrag<py><px>: fragment-ordered 16-bit weights of class
+ * (oy % 2, ox % 2) (speinet_amd/pack.py).  a0 [Hin*Win][lda0] fp32 or `fmt`, out [2Hin*2Win][ldo] fp32 or `fmt`. */
+int spei_convt2_slab16(int fmt, const void* a0, int lda0, int k0, int a_fmt, const void* wfrag00, const void* wfrag01,
+                       const void* wfrag10, const void* wfrag11, const float* bias, void* out, int ldo, int out_fmt,
+                       int Hin, int Win, int N, int act, spei_stream_t stream);
 
-/* Last conv (model/recons_video_ori.py:75-77: 5x5, 32 -> 3 channels, NHWC in, three NCHW fp32 planes out) on the bf16
+/* Last conv (model/recons_video_ori.py:75-77: 5x5, 32 -> 3 channels, NHWC in, three NCHW fp32 planes out) on the
  * slab kernel: wfrag = fragment-ordered weights zero-padded to 32 output channels, bias32 = bias padded to 32. */
-int spei_conv5_out_slab_bf16(const void* in, int ldi, int in_bf16, const void* wfrag, const float* bias32, float* out_chw,
-                             int H, int W, spei_stream_t stream);
+int spei_conv5_out_slab16(int fmt, const void* in, int ldi, int in_fmt, const void* wfrag, const float* bias32, float* out_chw,
+                          int H, int W, spei_stream_t stream);
 
 /* Fused attention branch of a Swin block (model/swinir.py:238-278 + :115-149): out = x + proj(W-MSA(q = yhat Wq,
  * [k,v] = LayerNorm(x) Wkv)) with cyclic shift `shift`, 5x5 windows, 8 heads; x,out [H*W][256] fp32 (may alias), yhat
- * [H*W][256] bf16 (LayerNorm of y without affine); w*_frag in MFMA fragment order with the LayerNorm affine and the q
+ * [H*W][256] `fmt` (LayerNorm of y without affine); w*_frag in MFMA fragment order with the LayerNorm affine and the q
  * scale folded in (pack.py); relbias [8][25][25].  q, k, v, the attention matrix and its output never reach HBM. */
-int spei_attn_fused_bf16(const float* x, float* out, const void* yhat, const void* wq_frag, const float* bq,
-                         const void* wkv_frag, const float* bkv, const void* wproj_frag, const float* bproj,
-                         const float* relbias, int H, int W, int shift, spei_stream_t stream);
+int spei_attn_fused16(int fmt, const float* x, float* out, const void* yhat, const void* wq_frag, const float* bq,
+                      const void* wkv_frag, const float* bkv, const void* wproj_frag, const float* bproj,
+                      const float* relbias, int H, int W, int shift, spei_stream_t stream);
 
 /* K3 — ResBlock gates (model/block.py:8-24 SE, 71-96 ZPool+AttentionGate1/2, 108-124 TripletAttention).
- * x1: conv2 output [H][W][C], fp32 or (x1_bf16) bf16.  Workspace `ws` floats: spei_gate_ws_floats(H,W,C).
+ * x1: conv2 output [H][W][C] stored as x1_fmt (SPEI_F32 / SPEI_BF16 / SPEI_F16).  Workspace `ws` floats: spei_gate_ws_floats(H,W,C).
  * Produces s[C], g1[H][C], g2[W][C] such that ResBlock = x + x1*s + (x1*g1 + x1*g2).
  * gate params (packed by speinet_amd/pack.py): se_w1[C/4][C], se_b1[C/4], se_w2[C][C/4], se_b2[C],
  * cw_w[2][7][7], cw_bn[2] = {scale, shift}, hc_w[2][5][5], hc_bn[2]. */
 int64_t spei_gate_ws_floats(int H, int W, int C);
-int spei_resblock_gates(const void* x1, int x1_bf16, int H, int W, int C, const float* se_w1, const float* se_b1,
+int spei_resblock_gates(const void* x1, int x1_fmt, int H, int W, int C, const float* se_w1, const float* se_b1,
                         const float* se_w2, const float* se_b2, const float* cw_w, const float* cw_bn,
                         const float* hc_w, const float* hc_bn, float* s, float* g1, float* g2, float* ws,
                         spei_stream_t stream);
 /* out = x + x1*s + (x1*g1 + x1*g2) [+ extra]   (model/block.py:136-140; `extra` fuses speinet.py:84,132) */
-int spei_resblock_apply(const float* x, const void* x1, int x1_bf16, const float* s, const float* g1, const float* g2,
+int spei_resblock_apply(const float* x, const void* x1, int x1_fmt, const float* s, const float* g1, const float* g2,
                         const float* extra, float* out, int ldo, int H, int W, int C, spei_stream_t stream);
 
 /* K7 — LayerNorm over C=256, eps 1e-5 (model/swinir.py:244-245,279,528-529,776).  gamma/beta may be NULL
- * (affine folded into the following linear by pack.py); out_bf16: y is bf16 (it only feeds a GEMM). */
-int spei_layernorm256(const float* x, void* y, int out_bf16, const float* gamma, const float* beta, int64_t M,
+ * (affine folded into the following linear by pack.py); out_fmt: y is fp32, or 16-bit when it only feeds a GEMM. */
+int spei_layernorm256(const float* x, void* y, int out_fmt, const float* gamma, const float* beta, int64_t M,
                       spei_stream_t stream);
 
 /* K8 — window attention core: cyclic shift, 5x5 partition, softmax(q k^T + relbias + shift mask) v, reverse
  * (model/swinir.py:115-149, 215-236, 250-275).  q [H*W][256] (scale folded), kv [H*W][512] (K then V, head major),
- * relbias [8][25][25] pre-gathered, out [H*W][256]; heads = 8, head_dim = 32, window 5.  io_bf16: q, kv and out
- * are bf16 in HBM (the arithmetic stays fp32 on the f32 MFMA). */
-int spei_window_attention(const void* q, const void* kv, int io_bf16, const float* relbias, void* out, int H, int W,
+ * relbias [8][25][25] pre-gathered, out [H*W][256]; heads = 8, head_dim = 32, window 5.  io_fmt: q, kv and out
+ * are fp32 or 16-bit in HBM (the arithmetic stays fp32 on the f32 MFMA). */
+int spei_window_attention(const void* q, const void* kv, int io_fmt, const float* relbias, void* out, int H, int W,
                           int shift, spei_stream_t stream);
 
 /* K10 — 1 / max(||unfold3x3(f)[p]||_2, 1e-12) per position (F.normalize, model/SearchTransfer.py:30-31). */
@@ -148,27 +156,28 @@ int spei_corr_argmax(const float* lr, int ldl, const float* ref, int ldr, const 
                      const float* inv_ref, int Hl, int Wl, int Hr, int Wr, int C, float* S, int32_t* arg,
                      float* ws, spei_stream_t stream);
 
-/* K11 on the bf16 pipe.  spei_split_bf16 converts a map once: hi = bf16(x), lo = bf16(x - hi) (lo may be NULL);
- * outputs are dense [M][C] bf16.  spei_corr_argmax_bf16: lo pointers NULL -> single bf16 products, else bf16x3. */
-int spei_split_bf16(const float* x, int ld, void* hi, void* lo, int64_t M, int C, spei_stream_t stream);
+/* K11 on the 16-bit pipe.  spei_split16 converts a map once: hi = fmt(x), lo = fmt(x - hi) (lo may be NULL);
+ * outputs are dense [M][C] 16-bit.  spei_corr_argmax_bf16 (tile-restaging form, bf16 only): lo pointers NULL -> single
+ * bf16 products, else bf16x3. */
+int spei_split16(int fmt, const float* x, int ld, void* hi, void* lo, int64_t M, int C, spei_stream_t stream);
 int spei_corr_argmax_bf16(const void* lr_hi, const void* lr_lo, const void* ref_hi, const void* ref_lo,
                           const float* inv_lr, const float* inv_ref, int Hl, int Wl, int Hr, int Wr, int C, float* S,
                           int32_t* arg, float* ws, spei_stream_t stream);
 
-/* Slab-resident variant of spei_corr_argmax_bf16 (same arguments, C == 128): the query block and the streamed
- * reference blocks live in LDS with their 1-pixel halo, so the 3x3 unfold is LDS addressing, not memory traffic. */
-int spei_corr_slab_bf16(const void* lr_hi, const void* lr_lo, const void* ref_hi, const void* ref_lo,
-                        const float* inv_lr, const float* inv_ref, int Hl, int Wl, int Hr, int Wr, int C, float* S,
-                        int32_t* arg, float* ws, spei_stream_t stream);
+/* Slab-resident form (C == 128): the query block and the streamed reference blocks live in LDS with their 1-pixel
+ * halo, so the 3x3 unfold is LDS addressing, not memory traffic.  lo pointers: NULL, or (SPEI_BF16 only) the bf16x3 split. */
+int spei_corr_slab16(int fmt, const void* lr_hi, const void* lr_lo, const void* ref_hi, const void* ref_lo,
+                     const float* inv_lr, const float* inv_ref, int Hl, int Wl, int Hr, int Wr, int C, float* S,
+                     int32_t* arg, float* ws, spei_stream_t stream);
 
-/* Exact arg-max at bf16 cost (ops.Ctx corr_precision "bf16r").  spei_corr_slab_top2_bf16: the slab kernel with single
- * bf16 products keeping the TWO best candidates of every query: arg / arg2 (arg2 = -1: no second candidate) with their
+/* Exact arg-max at 16-bit cost (ops.Ctx corr_precision "top2").  spei_corr_slab_top2_16: the slab kernel with single
+ * 16-bit products keeping the TWO best candidates of every query: arg / arg2 (arg2 = -1: no second candidate) with their
  * approximate, un-normalised-by-inv_lr scores S / S2.  spei_corr_rescore then re-scores both candidates on the fp32 maps
  * with fp64 accumulation and overwrites S (= dot * inv_ref[j] * inv_lr[i], fp32) and arg (ties -> lowest index): the
- * winner no longer depends on bf16 rounding (model/SearchTransfer.py:33-34 computes R in fp32). */
-int spei_corr_slab_top2_bf16(const void* lr_bf16, const void* ref_bf16, const float* inv_lr, const float* inv_ref,
-                             int Hl, int Wl, int Hr, int Wr, int C, float* S, int32_t* arg, float* S2, int32_t* arg2,
-                             float* ws, spei_stream_t stream);
+ * winner no longer depends on 16-bit rounding (model/SearchTransfer.py:33-34 computes R in fp32). */
+int spei_corr_slab_top2_16(int fmt, const void* lr16, const void* ref16, const float* inv_lr, const float* inv_ref,
+                           int Hl, int Wl, int Hr, int Wr, int C, float* S, int32_t* arg, float* S2, int32_t* arg2,
+                           float* ws, spei_stream_t stream);
 int spei_corr_rescore(const float* lr, int ldl, const float* ref, int ldr, const float* inv_lr, const float* inv_ref,
                       int Hl, int Wl, int Hr, int Wr, int C, float* S, int32_t* arg, const float* S2, const int32_t* arg2,
                       spei_stream_t stream);

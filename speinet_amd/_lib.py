@@ -30,14 +30,14 @@ SIGNATURES = {
     "spei_conv5_out": (I, [P, I, P, P, P, I, I, I, P]),
     "spei_igemm_f32": (I, [P, I, I, P, I, I, P, P, P, I, P, I, P, I, I, I, I, I, I, I, I, I, I, P]),
     "spei_igemm_bf16": (I, [P, I, I, P, I, I, P, P, P, P, I, P, I, P, I, I, I, I, I, I, I, I, I, I, P]),
-    "spei_conv_slab_bf16": (I, [P, I, I, P, I, I, I, P, P, P, P, I, I, P, I, P, I, I, I, I, I, I, I, I, I, I, P]),
-    "spei_attn_fused_bf16": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
-    "spei_conv5_out_slab_bf16": (I, [P, I, I, P, P, P, I, I, P]),
-    "spei_convt2_slab_bf16": (I, [P, I, I, I, P, P, P, P, P, P, I, I, I, I, I, I, P]),
-    "spei_mlp_fused_bf16": (I, [P, P, P, P, P, P, L, P]),
-    "spei_split_bf16": (I, [P, I, P, P, L, I, P]),
-    "spei_corr_slab_bf16": (I, [P, P, P, P, P, P, I, I, I, I, I, P, P, P, P]),
-    "spei_corr_slab_top2_bf16": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, P, P]),
+    "spei_conv_slab16": (I, [I, P, I, I, P, I, I, I, P, P, P, P, I, I, P, I, P, I, I, I, I, I, I, I, I, I, I, P]),
+    "spei_attn_fused16": (I, [I, P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
+    "spei_conv5_out_slab16": (I, [I, P, I, I, P, P, P, I, I, P]),
+    "spei_convt2_slab16": (I, [I, P, I, I, I, P, P, P, P, P, P, I, I, I, I, I, I, P]),
+    "spei_mlp_fused16": (I, [I, P, P, P, P, P, P, L, P]),
+    "spei_split16": (I, [I, P, I, P, P, L, I, P]),
+    "spei_corr_slab16": (I, [I, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P]),
+    "spei_corr_slab_top2_16": (I, [I, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P]),
     "spei_corr_rescore": (I, [P, I, P, I, P, P, I, I, I, I, I, P, P, P, P, P]),
     "spei_corr_argmax_bf16": (I, [P, P, P, P, P, P, I, I, I, I, I, P, P, P, P]),
     "spei_gate_ws_floats": (L, [I, I, I]),

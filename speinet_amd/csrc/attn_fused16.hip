@@ -1,4 +1,4 @@
-// Fused attention branch of one cross-window Swin block on the gfx950 bf16 matrix pipe:
+// Fused attention branch of one cross-window Swin block on the gfx950 16-bit matrix pipe (bf16 or half operands):
 //
 //     x <- x + proj( W-MSA( q = norm1(y) Wq,  [k, v] = norm1(x) Wkv ) )
 //
@@ -22,22 +22,20 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
 constexpr int D = 256, HD = 32, NT = 25, WS = 5;
 constexpr int PA = 2 * D + 16;        // LDS row pitch (bytes)
 constexpr int ROWS = 64;              // 2 windows x 32 (25 tokens + 7 pad rows)
 
+template <typename LP>       // LP: __bf16 or _Float16 (tokens, weights, probabilities as matrix-pipe operands)
 struct AttnParams {
     const float* x;
     float* out;
-    const __bf16* yhat;   // [M][256]
-    const __bf16* wq;     // fragment order [8][1][16][64][8]
+    const LP* yhat;       // [M][256]
+    const LP* wq;         // fragment order [8][1][16][64][8]
     const float* bq;
-    const __bf16* wkv;    // fragment order [16][1][16][64][8]  (n-tiles 0..7 = K heads, 8..15 = V heads)
+    const LP* wkv;        // fragment order [16][1][16][64][8]  (n-tiles 0..7 = K heads, 8..15 = V heads)
     const float* bkv;
-    const __bf16* wproj;  // fragment order [8][1][16][64][8]
+    const LP* wproj;      // fragment order [8][1][16][64][8]
     const float* bproj;
     const float* relbias; // [8][25][25]
     int H, W, shift, nwin;
@@ -45,11 +43,11 @@ struct AttnParams {
 
 __device__ __forceinline__ int mask_region(int v, int n, int shift) { return v < n - WS ? 0 : (v < n - shift ? 1 : 2); }
 
-template <int S>
-__device__ __forceinline__ bf16x8 cvt8(const f32x16& a) {
-    bf16x8 r;
+template <int S, typename LP>
+__device__ __forceinline__ typename lpv<LP>::x8 cvt8(const f32x16& a) {
+    typename lpv<LP>::x8 r;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = (__bf16)a[8 * S + j];
+    for (int j = 0; j < 8; ++j) r[j] = to_lp<LP>(a[8 * S + j]);
     return r;
 }
 
@@ -59,7 +57,10 @@ __device__ __forceinline__ float dpp_add(float v) { return v + dpp_quad<CTRL>(v)
 // lanes of different quads / octets (the values are already uniform inside them)
 __device__ __forceinline__ float sum16(float v) { return dpp_add<0x140>(dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(v)))); }
 
-__global__ __launch_bounds__(256, 2) void attn_fused_kernel(const AttnParams p) {
+template <typename LP>
+__global__ __launch_bounds__(256, 2) void attn_fused_kernel(const AttnParams<LP> p) {
+    typedef typename lpv<LP>::x8 lp8;
+    typedef typename lpv<LP>::x4 lp4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xs = smem;                      // [64][PA]  LayerNorm(x), bf16
     unsigned char* ys = smem + ROWS * PA;          // [64][PA]  y-hat, bf16; later the attention output
@@ -121,10 +122,10 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const AttnParams p) 
                 const float rstd = ok ? 1.0f / sqrtf(sum16(ss) * (1.0f / 256.0f) + 1e-5f) : 0.f;     // empty rows stage zeros
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    bf16x4 hv;
+                    lp4 hv;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) hv[e] = (__bf16)(xr[b][j][e] * rstd);
-                    *reinterpret_cast<bf16x4*>(xs + r * PA + (l16 + 16 * j) * 8) = hv;
+                    for (int e = 0; e < 4; ++e) hv[e] = to_lp<LP>(xr[b][j][e] * rstd);
+                    *reinterpret_cast<lp4*>(xs + r * PA + (l16 + 16 * j) * 8) = hv;
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const AttnParams p) 
     __syncthreads();
 
     // ---- 2 + 3. the wave's two heads: Q^T, K^T, V, then attention on both windows, all in registers -------------------
-    bf16x4 opk[2][2][4];                               // [head][window][4 d-groups]: O^T packed, written to LDS after the barrier
+    lp4 opk[2][2][4];                               // [head][window][4 d-groups]: O^T packed, written to LDS after the barrier
     // shift mask: bit r of mbits[w] = key (register row r) lies in another region than the lane's query
     unsigned mbits[2] = {0u, 0u};
     if (p.shift > 0) {
@@ -170,53 +171,53 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const AttnParams p) 
             vv[0][r] = vv[1][r] = bvv;
         }
         {
-            const __bf16* wqp = p.wq + (size_t)h * 16 * 512 + lane * 8;
-            const __bf16* wkp = p.wkv + (size_t)h * 16 * 512 + lane * 8;
-            const __bf16* wvp = p.wkv + (size_t)(8 + h) * 16 * 512 + lane * 8;
+            const LP* wqp = p.wq + (size_t)h * 16 * 512 + lane * 8;
+            const LP* wkp = p.wkv + (size_t)h * 16 * 512 + lane * 8;
+            const LP* wvp = p.wkv + (size_t)(8 + h) * 16 * 512 + lane * 8;
             // Software pipeline pinned with full scheduling barriers: weight fragments two k-steps ahead (3-slot ring), token
             // fragments one step ahead, then the 6 MFMAs of the step.  Left alone the scheduler sinks each global_load to
             // right before its use (s_waitcnt vmcnt(0) in front of every MFMA group: seen in the ISA).
-            bf16x8 wqf[3], wkf[3], wvf[3];
+            lp8 wqf[3], wkf[3], wvf[3];
 #pragma unroll
             for (int pre = 0; pre < 2; ++pre) {
-                wqf[pre] = *reinterpret_cast<const bf16x8*>(wqp + ((rot + pre) & 15) * 512);
-                wkf[pre] = *reinterpret_cast<const bf16x8*>(wkp + ((rot + pre) & 15) * 512);
-                wvf[pre] = *reinterpret_cast<const bf16x8*>(wvp + ((rot + pre) & 15) * 512);
+                wqf[pre] = *reinterpret_cast<const lp8*>(wqp + ((rot + pre) & 15) * 512);
+                wkf[pre] = *reinterpret_cast<const lp8*>(wkp + ((rot + pre) & 15) * 512);
+                wvf[pre] = *reinterpret_cast<const lp8*>(wvp + ((rot + pre) & 15) * 512);
             }
-            bf16x8 yn[2], xn[2];
+            lp8 yn[2], xn[2];
 #pragma unroll
             for (int w = 0; w < 2; ++w) {
-                yn[w] = *reinterpret_cast<const bf16x8*>(ys + (w * 32 + fr) * PA + rot * 32 + fk * 16);
-                xn[w] = *reinterpret_cast<const bf16x8*>(xs + (w * 32 + fr) * PA + rot * 32 + fk * 16);
+                yn[w] = *reinterpret_cast<const lp8*>(ys + (w * 32 + fr) * PA + rot * 32 + fk * 16);
+                xn[w] = *reinterpret_cast<const lp8*>(xs + (w * 32 + fr) * PA + rot * 32 + fk * 16);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int cur = i % 3;
-                bf16x8 yc[2], xc[2];
+                lp8 yc[2], xc[2];
 #pragma unroll
                 for (int w = 0; w < 2; ++w) { yc[w] = yn[w]; xc[w] = xn[w]; }
                 if (i + 1 < 16) {
                     const int ko = ((rot + i + 1) & 15) * 32 + fk * 16;
 #pragma unroll
                     for (int w = 0; w < 2; ++w) {
-                        yn[w] = *reinterpret_cast<const bf16x8*>(ys + (w * 32 + fr) * PA + ko);
-                        xn[w] = *reinterpret_cast<const bf16x8*>(xs + (w * 32 + fr) * PA + ko);
+                        yn[w] = *reinterpret_cast<const lp8*>(ys + (w * 32 + fr) * PA + ko);
+                        xn[w] = *reinterpret_cast<const lp8*>(xs + (w * 32 + fr) * PA + ko);
                     }
                 }
-                const bf16x8 wqc = wqf[cur], wkc = wkf[cur], wvc = wvf[cur];
+                const lp8 wqc = wqf[cur], wkc = wkf[cur], wvc = wvf[cur];
                 if (i + 2 < 16) {
                     const int nxt = (i + 2) % 3, ksn = (rot + i + 2) & 15;
-                    wqf[nxt] = *reinterpret_cast<const bf16x8*>(wqp + ksn * 512);
-                    wkf[nxt] = *reinterpret_cast<const bf16x8*>(wkp + ksn * 512);
-                    wvf[nxt] = *reinterpret_cast<const bf16x8*>(wvp + ksn * 512);
+                    wqf[nxt] = *reinterpret_cast<const lp8*>(wqp + ksn * 512);
+                    wkf[nxt] = *reinterpret_cast<const lp8*>(wkp + ksn * 512);
+                    wvf[nxt] = *reinterpret_cast<const lp8*>(wvp + ksn * 512);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int w = 0; w < 2; ++w) {
-                    qT[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wqc, yc[w], qT[w], 0, 0, 0);
-                    kT[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wkc, xc[w], kT[w], 0, 0, 0);
-                    vv[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xc[w], wvc, vv[w], 0, 0, 0);
+                    qT[w] = mfma16(wqc, yc[w], qT[w]);
+                    kT[w] = mfma16(wkc, xc[w], kT[w]);
+                    vv[w] = mfma16(xc[w], wvc, vv[w]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -227,8 +228,8 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const AttnParams p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[r] = 0.f;
             // S^T[key][query] = sum_d K^T[d][key] Q^T[d][query]:  A = (K^T)^T from the accumulator, B = Q^T from the accumulator
-            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cvt8<0>(kT[w]), cvt8<0>(qT[w]), st, 0, 0, 0);
-            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cvt8<1>(kT[w]), cvt8<1>(qT[w]), st, 0, 0, 0);
+            st = mfma16(cvt8<0, LP>(kT[w]), cvt8<0, LP>(qT[w]), st);
+            st = mfma16(cvt8<1, LP>(kT[w]), cvt8<1, LP>(qT[w]), st);
             float mx = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -257,12 +258,12 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const AttnParams p) 
             f32x16 ot;
 #pragma unroll
             for (int r = 0; r < 16; ++r) ot[r] = 0.f;
-            ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cvt8<0>(vv[w]), cvt8<0>(st), ot, 0, 0, 0);
-            ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cvt8<1>(vv[w]), cvt8<1>(st), ot, 0, 0, 0);
+            ot = mfma16(cvt8<0, LP>(vv[w]), cvt8<0, LP>(st), ot);
+            ot = mfma16(cvt8<1, LP>(vv[w]), cvt8<1, LP>(st), ot);
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) opk[hh][w][g][e] = (__bf16)ot[4 * g + e];
+                for (int e = 0; e < 4; ++e) opk[hh][w][g][e] = to_lp<LP>(ot[4 * g + e]);
         }
     }
     __syncthreads();                                   // every wave is done reading the y slab
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const AttnParams p) 
         for (int w = 0; w < 2; ++w)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<bf16x4*>(os + (w * 32 + fr) * PA + ((wave * 2 + hh) * HD + 8 * g + 4 * fk) * 2) = opk[hh][w][g];
+                *reinterpret_cast<lp4*>(os + (w * 32 + fr) * PA + ((wave * 2 + hh) * HD + 8 * g + 4 * fk) * 2) = opk[hh][w][g];
     __syncthreads();
 
     // ---- 4. proj: the wave produces output channels [64 wave, 64 wave + 64) for all 64 rows, + bias + residual ---------
@@ -296,37 +297,37 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const AttnParams p) 
             for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][nn][r] = 0.f;
-        const __bf16* wpp = p.wproj + (size_t)(wave * 2) * 16 * 512 + lane * 8;
+        const LP* wpp = p.wproj + (size_t)(wave * 2) * 16 * 512 + lane * 8;
         const int rot4 = (blockIdx.x * 3) & 15;
-        bf16x8 wf[3][2];
+        lp8 wf[3][2];
         int ks = rot4;
 #pragma unroll
         for (int pre = 0; pre < 2; ++pre)
 #pragma unroll
-            for (int nn = 0; nn < 2; ++nn) wf[pre][nn] = *reinterpret_cast<const bf16x8*>(wpp + (nn * 16 + ((ks + pre) & 15)) * 512);
-        bf16x8 an[2];
-        an[0] = *reinterpret_cast<const bf16x8*>(os + fr * PA + ks * 32 + fk * 16);
-        an[1] = *reinterpret_cast<const bf16x8*>(os + (32 + fr) * PA + ks * 32 + fk * 16);
+            for (int nn = 0; nn < 2; ++nn) wf[pre][nn] = *reinterpret_cast<const lp8*>(wpp + (nn * 16 + ((ks + pre) & 15)) * 512);
+        lp8 an[2];
+        an[0] = *reinterpret_cast<const lp8*>(os + fr * PA + ks * 32 + fk * 16);
+        an[1] = *reinterpret_cast<const lp8*>(os + (32 + fr) * PA + ks * 32 + fk * 16);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int cur = i % 3, nxt = (i + 2) % 3;
-            const bf16x8 a0 = an[0], a1 = an[1];
+            const lp8 a0 = an[0], a1 = an[1];
             if (i + 1 < 16) {
                 const int ko = ((ks + 1) & 15) * 32 + fk * 16;
-                an[0] = *reinterpret_cast<const bf16x8*>(os + fr * PA + ko);
-                an[1] = *reinterpret_cast<const bf16x8*>(os + (32 + fr) * PA + ko);
+                an[0] = *reinterpret_cast<const lp8*>(os + fr * PA + ko);
+                an[1] = *reinterpret_cast<const lp8*>(os + (32 + fr) * PA + ko);
             }
-            const bf16x8 w0 = wf[cur][0], w1 = wf[cur][1];
+            const lp8 w0 = wf[cur][0], w1 = wf[cur][1];
             if (i + 2 < 16) {
 #pragma unroll
-                for (int nn = 0; nn < 2; ++nn) wf[nxt][nn] = *reinterpret_cast<const bf16x8*>(wpp + (nn * 16 + ((ks + 2) & 15)) * 512);
+                for (int nn = 0; nn < 2; ++nn) wf[nxt][nn] = *reinterpret_cast<const lp8*>(wpp + (nn * 16 + ((ks + 2) & 15)) * 512);
             }
             __builtin_amdgcn_sched_barrier(0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w0, acc[0][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w0, acc[1][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w1, acc[0][1], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w1, acc[1][1], 0, 0, 0);
+            acc[0][0] = mfma16(a0, w0, acc[0][0]);
+            acc[1][0] = mfma16(a1, w0, acc[1][0]);
+            acc[0][1] = mfma16(a0, w1, acc[0][1]);
+            acc[1][1] = mfma16(a1, w1, acc[1][1]);
             __builtin_amdgcn_sched_barrier(0);
             ks = (ks + 1) & 15;
         }
@@ -352,22 +353,31 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const AttnParams p) 
 
 }  // namespace
 
-extern "C" int spei_attn_fused_bf16(const float* x, float* out, const void* yhat, const void* wq_frag, const float* bq,
-                                    const void* wkv_frag, const float* bkv, const void* wproj_frag, const float* bproj,
-                                    const float* relbias, int H, int W, int shift, spei_stream_t stream) {
-    SPEI_REQUIRE(x && out && yhat && wq_frag && bq && wkv_frag && bkv && wproj_frag && bproj && relbias, "spei_attn_fused_bf16: null pointer");
-    SPEI_REQUIRE(H > 0 && W > 0 && H % WS == 0 && W % WS == 0, "spei_attn_fused_bf16: %dx%d is not a multiple of the 5x5 window", H, W);
-    SPEI_REQUIRE(shift >= 0 && shift < WS, "spei_attn_fused_bf16: shift=%d", shift);
-    SPEI_REQUIRE((int64_t)H * W < (1ll << 30), "spei_attn_fused_bf16: map too large");
-    SPEI_REQUIRE(((uintptr_t)x | (uintptr_t)out | (uintptr_t)yhat | (uintptr_t)wq_frag | (uintptr_t)wkv_frag | (uintptr_t)wproj_frag) % 16 == 0,
-                 "spei_attn_fused_bf16: 16-byte alignment required");
-    AttnParams p;
-    p.x = x; p.out = out; p.yhat = (const __bf16*)yhat; p.wq = (const __bf16*)wq_frag; p.bq = bq; p.wkv = (const __bf16*)wkv_frag;
-    p.bkv = bkv; p.wproj = (const __bf16*)wproj_frag; p.bproj = bproj; p.relbias = relbias;
+template <typename LP>
+static int attn_launch(const float* x, float* out, const void* yhat, const void* wq, const float* bq, const void* wkv, const float* bkv,
+                       const void* wproj, const float* bproj, const float* relbias, int H, int W, int shift, hipStream_t st) {
+    AttnParams<LP> p;
+    p.x = x; p.out = out; p.yhat = (const LP*)yhat; p.wq = (const LP*)wq; p.bq = bq; p.wkv = (const LP*)wkv;
+    p.bkv = bkv; p.wproj = (const LP*)wproj; p.bproj = bproj; p.relbias = relbias;
     p.H = H; p.W = W; p.shift = shift; p.nwin = (H / WS) * (W / WS);
     const size_t lds = (size_t)2 * ROWS * PA + 2 * ROWS * sizeof(int);
-    ensure_dyn_lds<&attn_fused_kernel>(lds);
-    hipLaunchKernelGGL(attn_fused_kernel, dim3((p.nwin + 1) / 2), dim3(256), lds, (hipStream_t)stream, p);
-    SPEI_CHECK_LAUNCH("spei_attn_fused_bf16");
+    ensure_dyn_lds<&attn_fused_kernel<LP>>(lds);
+    hipLaunchKernelGGL(attn_fused_kernel<LP>, dim3((p.nwin + 1) / 2), dim3(256), lds, st, p);
+    SPEI_CHECK_LAUNCH("spei_attn_fused16");
     return 0;
+}
+
+extern "C" int spei_attn_fused16(int fmt, const float* x, float* out, const void* yhat, const void* wq_frag, const float* bq,
+                                 const void* wkv_frag, const float* bkv, const void* wproj_frag, const float* bproj,
+                                 const float* relbias, int H, int W, int shift, spei_stream_t stream) {
+    SPEI_REQUIRE(x && out && yhat && wq_frag && bq && wkv_frag && bkv && wproj_frag && bproj && relbias, "spei_attn_fused16: null pointer");
+    SPEI_REQUIRE(fmt == SPEI_BF16 || fmt == SPEI_F16, "spei_attn_fused16: fmt=%d", fmt);
+    SPEI_REQUIRE(H > 0 && W > 0 && H % WS == 0 && W % WS == 0, "spei_attn_fused16: %dx%d is not a multiple of the 5x5 window", H, W);
+    SPEI_REQUIRE(shift >= 0 && shift < WS, "spei_attn_fused16: shift=%d", shift);
+    SPEI_REQUIRE((int64_t)H * W < (1ll << 30), "spei_attn_fused16: map too large");
+    SPEI_REQUIRE(((uintptr_t)x | (uintptr_t)out | (uintptr_t)yhat | (uintptr_t)wq_frag | (uintptr_t)wkv_frag | (uintptr_t)wproj_frag) % 16 == 0,
+                 "spei_attn_fused16: 16-byte alignment required");
+    hipStream_t st = (hipStream_t)stream;
+    if (fmt == SPEI_F16) return attn_launch<_Float16>(x, out, yhat, wq_frag, bq, wkv_frag, bkv, wproj_frag, bproj, relbias, H, W, shift, st);
+    return attn_launch<__bf16>(x, out, yhat, wq_frag, bq, wkv_frag, bkv, wproj_frag, bproj, relbias, H, W, shift, st);
 }

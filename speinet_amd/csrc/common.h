@@ -90,6 +90,34 @@ __device__ __forceinline__ float wave_max(float v) { return wave_allreduce<OpMax
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- the two 16-bit operand formats of the matrix pipe -----------------------------------------------------------------
+// bf16 (8-bit significand) and IEEE half (11-bit significand) run v_mfma_f32_32x32x16_* at the same rate with fp32
+// accumulation; kernels are templates on the element type LP, the C-ABI selects with SPEI_BF16 / SPEI_F16.  Half keeps
+// three more bits of every weight and activation (PSNR delta of the 720p forward 8x smaller) at a range of
+// +-65504.  Conversions do NOT saturate: an activation beyond that range becomes +-inf and the frame comes out NaN —
+// loud, where a clamp would be silently wrong (the harness checks its output for non-finite values).
+template <typename T>
+struct lpv {
+    typedef T x8 __attribute__((ext_vector_type(8)));
+    typedef T x4 __attribute__((ext_vector_type(4)));
+    typedef T x2 __attribute__((ext_vector_type(2)));
+};
+__device__ __forceinline__ f32x16 mfma16(lpv<__bf16>::x8 a, lpv<__bf16>::x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma16(lpv<_Float16>::x8 a, lpv<_Float16>::x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// fp32 -> LP, round to nearest even (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 for pairs)
+template <typename LP>
+__device__ __forceinline__ LP to_lp(float v) { return (LP)v; }
+template <typename LP>
+__device__ __forceinline__ typename lpv<LP>::x4 to_lp4(f32x4 v) {
+    typename lpv<LP>::x4 h;
+    h[0] = to_lp<LP>(v[0]); h[1] = to_lp<LP>(v[1]); h[2] = to_lp<LP>(v[2]); h[3] = to_lp<LP>(v[3]);
+    return h;
+}
 // 16-byte register staging type.  NOT HIP's uint4: arrays of that struct type are not scalarised by the compiler and end
 // up in scratch memory (measured: 144-160 B/lane of scratch traffic in the staging loops).
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));

@@ -1,4 +1,4 @@
-// Slab-resident convolution / linear GEMM on the gfx950 bf16 matrix pipe (v_mfma_f32_32x32x16_bf16).
+// Slab-resident convolution / linear GEMM on the gfx950 16-bit matrix pipe (v_mfma_f32_32x32x16_bf16 / _f16).
 //
 // igemm_bf16.hip re-stages the A operand from global memory for every (tap, K-chunk) and pays a load ->
 // ds_write -> barrier round trip per 16..64 MFMAs: at bf16 MFMA rates that loop is latency-bound.  Here each
@@ -21,14 +21,11 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
 struct SlabParams {
     const void* a0;
     const void* a1;
-    const __bf16* wh;    // fragment-ordered
-    const __bf16* wl;
+    const void* wh;      // fragment-ordered, 16-bit elements of the kernel's LP type
+    const void* wl;
     const float* bias;
     void* out;
     const float* res;
@@ -63,28 +60,9 @@ __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + e
 constexpr int G = 2;        // k-steps (of 16) per group
 constexpr int RING = 4;     // groups of B fragments in flight
 
-// one 16-byte global chunk -> LDS: 4 fp32 -> 4 bf16 (8 B) [+ residual], or 8 bf16 unchanged (16 B)
-template <typename TA, bool SPLIT>
-struct Stage;
-template <bool SPLIT>
-struct Stage<float, SPLIT> {
-    static constexpr int CH = 4;                       // channels per chunk
-    typedef f32x4 reg_t;
-    static __device__ __forceinline__ reg_t zero() { return reg_t{0.f, 0.f, 0.f, 0.f}; }
-    static __device__ __forceinline__ void put(unsigned char* slab, int slab_bytes, int off, const reg_t v) {
-        bf16x4 h;
-        h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
-        *reinterpret_cast<bf16x4*>(slab + off) = h;
-        if (SPLIT) {
-            bf16x4 l;
-            l[0] = (__bf16)(v[0] - (float)h[0]); l[1] = (__bf16)(v[1] - (float)h[1]);
-            l[2] = (__bf16)(v[2] - (float)h[2]); l[3] = (__bf16)(v[3] - (float)h[3]);
-            *reinterpret_cast<bf16x4*>(slab + slab_bytes + off) = l;
-        }
-    }
-};
-template <bool SPLIT>
-struct Stage<__bf16, SPLIT> {
+// one 16-byte global chunk -> LDS: 4 fp32 -> 4 LP (8 B) [+ residual], or 8 LP unchanged (16 B)
+template <typename TA, bool SPLIT, typename LP>
+struct Stage {                                         // TA == LP
     static constexpr int CH = 8;
     typedef u32x4 reg_t;
     static __device__ __forceinline__ reg_t zero() { return reg_t{0u, 0u, 0u, 0u}; }
@@ -92,11 +70,31 @@ struct Stage<__bf16, SPLIT> {
         *reinterpret_cast<reg_t*>(slab + off) = v;
     }
 };
+template <bool SPLIT, typename LP>
+struct Stage<float, SPLIT, LP> {
+    static constexpr int CH = 4;                       // channels per chunk
+    typedef f32x4 reg_t;
+    typedef typename lpv<LP>::x4 lp4;
+    static __device__ __forceinline__ reg_t zero() { return reg_t{0.f, 0.f, 0.f, 0.f}; }
+    static __device__ __forceinline__ void put(unsigned char* slab, int slab_bytes, int off, const reg_t v) {
+        const lp4 h = to_lp4<LP>(v);
+        *reinterpret_cast<lp4*>(slab + off) = h;
+        if (SPLIT) {
+            lp4 l;
+            l[0] = (LP)(v[0] - (float)h[0]); l[1] = (LP)(v[1] - (float)h[1]);
+            l[2] = (LP)(v[2] - (float)h[2]); l[3] = (LP)(v[3] - (float)h[3]);
+            *reinterpret_cast<lp4*>(slab + slab_bytes + off) = l;
+        }
+    }
+};
 
-template <int WM, int WN, int TM, int TN, bool SPLIT, typename TA, typename TO>
+// LP: 16-bit operand type (__bf16 or _Float16); TA / TO: float or LP
+template <int WM, int WN, int TM, int TN, bool SPLIT, typename TA, typename TO, typename LP>
 __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParams p) {
     constexpr int NT = 64 * WM * WN;                   // threads: 4 or 8 waves
-    typedef Stage<TA, SPLIT> ST;
+    typedef Stage<TA, SPLIT, LP> ST;
+    typedef typename lpv<LP>::x8 lp8;
+    typedef typename lpv<LP>::x4 lp4;
     typedef typename ST::reg_t sreg_t;
     constexpr int CH = ST::CH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -201,28 +199,28 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
         abase[i] = ((py * p.stride) * p.IW + px * p.stride) * pitch + fk * 16;
     }
     const size_t frag_per_nt = (size_t)T * ks16 * 64 * 8;        // bf16 elements per 32-column n-tile
-    const __bf16* bptr[TN];
-    const __bf16* bptr_lo[TN];
+    const LP* bptr[TN];
+    const LP* bptr_lo[TN];
     auto set_chunk = [&](int nc) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int nt = (nc * WN + wn) * TN + j;
-            bptr[j] = p.wh + nt * frag_per_nt + lane * 8;
-            bptr_lo[j] = SPLIT ? p.wl + nt * frag_per_nt + lane * 8 : nullptr;
+            bptr[j] = static_cast<const LP*>(p.wh) + nt * frag_per_nt + lane * 8;
+            bptr_lo[j] = SPLIT ? static_cast<const LP*>(p.wl) + nt * frag_per_nt + lane * 8 : nullptr;
         }
     };
     set_chunk(0);
 
-    bf16x8 bring[RING][G][TN];
-    bf16x8 bring_lo[SPLIT ? RING : 1][G][TN];
+    lp8 bring[RING][G][TN];
+    lp8 bring_lo[SPLIT ? RING : 1][G][TN];
     auto load_b = [&](int slot, int g) {
 #pragma unroll
         for (int s = 0; s < G; ++s)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const size_t o = (size_t)(g * G + s) * 512;
-                bring[slot][s][j] = *reinterpret_cast<const bf16x8*>(bptr[j] + o);
-                if (SPLIT) bring_lo[slot][s][j] = *reinterpret_cast<const bf16x8*>(bptr_lo[j] + o);
+                bring[slot][s][j] = *reinterpret_cast<const lp8*>(bptr[j] + o);
+                if (SPLIT) bring_lo[slot][s][j] = *reinterpret_cast<const lp8*>(bptr_lo[j] + o);
             }
     };
 
@@ -267,12 +265,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
         // A fragments are software-pipelined one k-step ahead (two register sets) and sched_group_barrier pins
         // "LDS reads of step s+1, then MFMAs of step s": left alone the compiler waits on each ds_read right before its MFMA.
         constexpr int NRD = TM * (SPLIT ? 2 : 1), NMF = TM * TN * (SPLIT ? 3 : 1);
-        bf16x8 an[TM], anl[SPLIT ? TM : 1];
+        lp8 an[TM], anl[SPLIT ? TM : 1];
         auto load_a = [&](int off) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                an[i] = *reinterpret_cast<const bf16x8*>(slab + abase[i] + off);
-                if (SPLIT) anl[i] = *reinterpret_cast<const bf16x8*>(slab + p.slab_bytes + abase[i] + off);
+                an[i] = *reinterpret_cast<const lp8*>(slab + abase[i] + off);
+                if (SPLIT) anl[i] = *reinterpret_cast<const lp8*>(slab + p.slab_bytes + abase[i] + off);
             }
         };
         int go = goff[rg(0)];
@@ -286,7 +284,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
                 go_n1 = goff[rg(min(g + 2, ngroups - 1))];
 #pragma unroll
                 for (int s = 0; s < G; ++s) {
-                    bf16x8 av[TM], avl[SPLIT ? TM : 1];
+                    lp8 av[TM], avl[SPLIT ? TM : 1];
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         av[i] = an[i];
@@ -298,10 +296,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
 #pragma unroll
                         for (int j = 0; j < TN; ++j) {
                             if (SPLIT) {
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avl[i], bring[d][s][j], acc[i][j], 0, 0, 0);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bring_lo[SPLIT ? d : 0][s][j], acc[i][j], 0, 0, 0);
+                                acc[i][j] = mfma16(avl[i], bring[d][s][j], acc[i][j]);
+                                acc[i][j] = mfma16(av[i], bring_lo[SPLIT ? d : 0][s][j], acc[i][j]);
                             }
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bring[d][s][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = mfma16(av[i], bring[d][s][j], acc[i][j]);
                         }
                     __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
@@ -372,9 +370,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
                         } else if (sizeof(TO) == 4) {
                             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + m * (unsigned)p.ldo + ncol0 + ecol) = v;
                         } else {
-                            bf16x4 h;
-                            h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
-                            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(outp) + m * (unsigned)p.ldo + ncol0 + ecol) = h;
+                            *reinterpret_cast<lp4*>(reinterpret_cast<LP*>(outp) + m * (unsigned)p.ldo + ncol0 + ecol) = to_lp4<LP>(v);
                         }
                     }
                 }
@@ -383,20 +379,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
     }   // n chunks
 }
 
-template <int WM, int WN, int TM, int TN, bool SPLIT, typename TA, typename TO>
+template <int WM, int WN, int TM, int TN, bool SPLIT, typename TA, typename TO, typename LP>
 int launch(const SlabParams& p, size_t lds, hipStream_t s) {
-    ensure_dyn_lds<&conv_slab_kernel<WM, WN, TM, TN, SPLIT, TA, TO>>(lds);
+    ensure_dyn_lds<&conv_slab_kernel<WM, WN, TM, TN, SPLIT, TA, TO, LP>>(lds);
     SlabParams q = p;
     q.n_chunks = p.N / (WN * TN * 32);
     static const int dbg = spei_knob("SPEI_SLAB_DBG", 0);
     q.dbg = dbg;
     dim3 grid(p.tiles_x * cdiv(p.Hout, p.TH), 1);
-    hipLaunchKernelGGL((conv_slab_kernel<WM, WN, TM, TN, SPLIT, TA, TO>), grid, dim3(64 * WM * WN), lds, s, q);
-    SPEI_CHECK_LAUNCH("spei_conv_slab_bf16");
+    hipLaunchKernelGGL((conv_slab_kernel<WM, WN, TM, TN, SPLIT, TA, TO, LP>), grid, dim3(64 * WM * WN), lds, s, q);
+    SPEI_CHECK_LAUNCH("spei_conv_slab16");
     return 0;
 }
 
-template <bool SPLIT, typename TA, typename TO>
+template <bool SPLIT, typename TA, typename TO, typename LP>
 int dispatch(SlabParams& p, hipStream_t s) {
     const int pitch = 2 * p.K + 16;
     const int nparts = SPLIT ? 2 : 1;
@@ -437,94 +433,113 @@ int dispatch(SlabParams& p, hipStream_t s) {
     if (p.N % 128 == 0) {
         if (!SPLIT && (w8 & 1)) {
             lds = setup(256);
-            if (lds <= hard && p.IH * p.IW < 2048 && !linear) return launch<2, 4, 4, 1, SPLIT, TA, TO>(p, lds, s);
+            if (lds <= hard && p.IH * p.IW < 2048 && !linear) return launch<2, 4, 4, 1, SPLIT, TA, TO, LP>(p, lds, s);
             lds = setup(128);
-            if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 4, 2, 1, SPLIT, TA, TO>(p, lds, s);
+            if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 4, 2, 1, SPLIT, TA, TO, LP>(p, lds, s);
         }
         lds = setup(128);
         const int64_t tiles128 = (int64_t)p.tiles_x * cdiv(p.Hout, p.TH);
         static const int min_tiles = spei_knob("SPEI_SLAB_MIN_TILES128", 0);
-        if (lds <= budget && tiles128 >= min_tiles && p.IH * p.IW < 2048) return launch<1, 4, 4, 1, SPLIT, TA, TO>(p, lds, s);
+        if (lds <= budget && tiles128 >= min_tiles && p.IH * p.IW < 2048) return launch<1, 4, 4, 1, SPLIT, TA, TO, LP>(p, lds, s);
         lds = setup(64);
-        if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 4, 2, 1, SPLIT, TA, TO>(p, lds, s);
+        if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 4, 2, 1, SPLIT, TA, TO, LP>(p, lds, s);
     } else if (p.N % 64 == 0) {
         if (!SPLIT && (w8 & 2)) {
             lds = setup(256);
-            if (lds <= hard && p.IH * p.IW < 2048) return launch<4, 2, 2, 1, SPLIT, TA, TO>(p, lds, s);
+            if (lds <= hard && p.IH * p.IW < 2048) return launch<4, 2, 2, 1, SPLIT, TA, TO, LP>(p, lds, s);
         }
         lds = setup(128);
-        if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 2, 2, 1, SPLIT, TA, TO>(p, lds, s);
+        if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 2, 2, 1, SPLIT, TA, TO, LP>(p, lds, s);
     } else {
         if (!SPLIT && (w8 & 4)) {
             lds = setup(512);
-            if (lds <= hard && p.IH * p.IW < 2048) return launch<8, 1, 2, 1, SPLIT, TA, TO>(p, lds, s);
+            if (lds <= hard && p.IH * p.IW < 2048) return launch<8, 1, 2, 1, SPLIT, TA, TO, LP>(p, lds, s);
         }
         static const int n32_tile = spei_knob("SPEI_SLAB_N32_TILE", 256);
         lds = setup(256);
-        if (n32_tile == 256 && lds <= budget && p.IH * p.IW < 2048) return launch<4, 1, 2, 1, SPLIT, TA, TO>(p, lds, s);
+        if (n32_tile == 256 && lds <= budget && p.IH * p.IW < 2048) return launch<4, 1, 2, 1, SPLIT, TA, TO, LP>(p, lds, s);
         lds = setup(128);
-        if (lds <= hard && p.IH * p.IW < 2048) return launch<4, 1, 1, 1, SPLIT, TA, TO>(p, lds, s);
+        if (lds <= hard && p.IH * p.IW < 2048) return launch<4, 1, 1, 1, SPLIT, TA, TO, LP>(p, lds, s);
     }
-    spei_set_error("spei_conv_slab_bf16: slab of %zu bytes (K=%d, k=%d, stride %d) does not fit LDS", lds, p.K, p.ks, p.stride);
+    spei_set_error("spei_conv_slab16: slab of %zu bytes (K=%d, k=%d, stride %d) does not fit LDS", lds, p.K, p.ks, p.stride);
     return -1;
 }
 
 }  // namespace
 
-extern "C" int spei_conv_slab_bf16(const void* a0, int lda0, int k0, const void* a1, int lda1, int k1, int a_bf16,
-                                   const void* wfrag_hi, const void* wfrag_lo, const float* bias, void* out, int ldo,
-                                   int out_bf16, const float* residual, int ldr, const float* rowscale, int Hin, int Win,
-                                   int Hout, int Wout, int N, int ksize, int stride, int pad, int act, int ln_input,
-                                   spei_stream_t stream) {
-    SPEI_REQUIRE(a0 && wfrag_hi && out, "spei_conv_slab_bf16: null pointer");
-    SPEI_REQUIRE(k0 > 0 && k0 % 32 == 0 && k1 >= 0 && k1 % 32 == 0, "spei_conv_slab_bf16: k0=%d k1=%d must be multiples of 32", k0, k1);
-    SPEI_REQUIRE(k1 == 0 || a1, "spei_conv_slab_bf16: a1 missing");
-    SPEI_REQUIRE(N > 0 && N % 32 == 0, "spei_conv_slab_bf16: N=%d must be a multiple of 32", N);
-    const int ael = a_bf16 ? 8 : 4;
+// a_fmt / out_fmt: SPEI_F32 or the call's 16-bit format `fmt` (SPEI_BF16 / SPEI_F16)
+template <typename LP>
+static int dispatch_io(SlabParams& p, bool split, bool a16, bool o16, hipStream_t st) {
+    if (split) return dispatch<true, float, float, LP>(p, st);
+    if (a16) return o16 ? dispatch<false, LP, LP, LP>(p, st) : dispatch<false, LP, float, LP>(p, st);
+    return o16 ? dispatch<false, float, LP, LP>(p, st) : dispatch<false, float, float, LP>(p, st);
+}
+static int dispatch_fmt(SlabParams& p, int fmt, bool split, bool a16, bool o16, hipStream_t st) {
+    if (fmt == SPEI_F16) {
+        if (split) { spei_set_error("the split (bf16x3) form is built for bf16 only"); return -1; }
+        return dispatch_io<_Float16>(p, false, a16, o16, st);
+    }
+    return dispatch_io<__bf16>(p, split, a16, o16, st);
+}
+#define SPEI_REQUIRE_FMT(who, fmt, a_fmt, out_fmt)                                                                      \
+    SPEI_REQUIRE(((fmt) == SPEI_BF16 || (fmt) == SPEI_F16) && ((a_fmt) == SPEI_F32 || (a_fmt) == (fmt)) &&              \
+                 ((out_fmt) == SPEI_F32 || (out_fmt) == (fmt)), who ": fmt=%d a_fmt=%d out_fmt=%d", fmt, a_fmt, out_fmt)
+
+extern "C" int spei_conv_slab16(int fmt, const void* a0, int lda0, int k0, const void* a1, int lda1, int k1, int a_fmt,
+                                const void* wfrag_hi, const void* wfrag_lo, const float* bias, void* out, int ldo,
+                                int out_fmt, const float* residual, int ldr, const float* rowscale, int Hin, int Win,
+                                int Hout, int Wout, int N, int ksize, int stride, int pad, int act, int ln_input,
+                                spei_stream_t stream) {
+    SPEI_REQUIRE(a0 && wfrag_hi && out, "spei_conv_slab16: null pointer");
+    SPEI_REQUIRE_FMT("spei_conv_slab16", fmt, a_fmt, out_fmt);
+    const bool a16 = a_fmt != SPEI_F32, o16 = out_fmt != SPEI_F32;
+    SPEI_REQUIRE(k0 > 0 && k0 % 32 == 0 && k1 >= 0 && k1 % 32 == 0, "spei_conv_slab16: k0=%d k1=%d must be multiples of 32", k0, k1);
+    SPEI_REQUIRE(k1 == 0 || a1, "spei_conv_slab16: a1 missing");
+    SPEI_REQUIRE(N > 0 && N % 32 == 0, "spei_conv_slab16: N=%d must be a multiple of 32", N);
+    const int ael = a16 ? 8 : 4;
     SPEI_REQUIRE(lda0 % ael == 0 && (k1 == 0 || lda1 % ael == 0) && ldo >= N && lda0 >= k0 && (k1 == 0 || lda1 >= k1),
-                 "spei_conv_slab_bf16: bad row strides");
-    SPEI_REQUIRE(ksize == 1 || ksize == 3 || ksize == 5, "spei_conv_slab_bf16: ksize=%d", ksize);
-    SPEI_REQUIRE(stride == 1 || stride == 2, "spei_conv_slab_bf16: stride=%d", stride);
-    SPEI_REQUIRE(Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "spei_conv_slab_bf16: empty map");
+                 "spei_conv_slab16: bad row strides");
+    SPEI_REQUIRE(ksize == 1 || ksize == 3 || ksize == 5, "spei_conv_slab16: ksize=%d", ksize);
+    SPEI_REQUIRE(stride == 1 || stride == 2, "spei_conv_slab16: stride=%d", stride);
+    SPEI_REQUIRE(Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "spei_conv_slab16: empty map");
     SPEI_REQUIRE((int64_t)Hout * Wout * (int64_t)(ldo > ldr ? ldo : ldr) < (1ll << 32) && (int64_t)Hin * Win < (1ll << 30),
-                 "spei_conv_slab_bf16: map too large for 32-bit element offsets");
+                 "spei_conv_slab16: map too large for 32-bit element offsets");
     SPEI_REQUIRE(Hout == (Hin + 2 * pad - ksize) / stride + 1 && Wout == (Win + 2 * pad - ksize) / stride + 1,
-                 "spei_conv_slab_bf16: output size %dx%d inconsistent with input %dx%d k%d s%d p%d", Hout, Wout, Hin, Win, ksize, stride, pad);
+                 "spei_conv_slab16: output size %dx%d inconsistent with input %dx%d k%d s%d p%d", Hout, Wout, Hin, Win, ksize, stride, pad);
     SPEI_REQUIRE(((uintptr_t)a0 % 16 == 0) && ((uintptr_t)wfrag_hi % 16 == 0) && (!a1 || (uintptr_t)a1 % 16 == 0) &&
-                 (!wfrag_lo || (uintptr_t)wfrag_lo % 16 == 0), "spei_conv_slab_bf16: operands must be 16-byte aligned");
-    SPEI_REQUIRE(!(wfrag_lo && (a_bf16 || out_bf16)), "spei_conv_slab_bf16: the split (bf16x3) mode keeps activations fp32");
+                 (!wfrag_lo || (uintptr_t)wfrag_lo % 16 == 0), "spei_conv_slab16: operands must be 16-byte aligned");
+    SPEI_REQUIRE(!(wfrag_lo && (a16 || o16 || fmt != SPEI_BF16)), "spei_conv_slab16: the split (bf16x3) mode is bf16 with fp32 activations");
     SPEI_REQUIRE(ldo % 4 == 0 && (!residual || ldr % 4 == 0) && ((uintptr_t)out % 16 == 0) && (!residual || (uintptr_t)residual % 16 == 0),
-                 "spei_conv_slab_bf16: out / residual must be 16-byte aligned with row strides that are multiples of 4");
+                 "spei_conv_slab16: out / residual must be 16-byte aligned with row strides that are multiples of 4");
     SlabParams p;
-    p.a0 = a0; p.a1 = a1; p.wh = (const __bf16*)wfrag_hi; p.wl = (const __bf16*)wfrag_lo; p.bias = bias; p.out = out;
+    p.a0 = a0; p.a1 = a1; p.wh = wfrag_hi; p.wl = wfrag_lo; p.bias = bias; p.out = out;
     p.res = residual; p.rowscale = rowscale;
     p.lda0 = lda0; p.lda1 = lda1; p.k0 = k0; p.k1 = k1; p.ldo = ldo; p.ldr = ldr;
     p.N = N; p.K = k0 + k1;
     p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout;
     p.ks = ksize; p.stride = stride; p.pad = pad; p.act = act;
-    SPEI_REQUIRE(!ln_input || (!a_bf16 && k0 == 256 && k1 == 0 && ksize == 1), "spei_conv_slab_bf16: ln_input needs a 256-wide fp32 linear");
+    SPEI_REQUIRE(!ln_input || (!a16 && k0 == 256 && k1 == 0 && ksize == 1), "spei_conv_slab16: ln_input needs a 256-wide fp32 linear");
     p.ln = ln_input;
     p.ntap = 0; p.o_mul = 1; p.o_row_add = 0; p.o_col_add = 0; p.Wfull = Wout; p.planes = 0;
-    hipStream_t st = (hipStream_t)stream;
-    if (wfrag_lo) return dispatch<true, float, float>(p, st);
-    if (a_bf16) return out_bf16 ? dispatch<false, __bf16, __bf16>(p, st) : dispatch<false, __bf16, float>(p, st);
-    return out_bf16 ? dispatch<false, float, __bf16>(p, st) : dispatch<false, float, float>(p, st);
+    return dispatch_fmt(p, fmt, wfrag_lo != nullptr, a16, o16, (hipStream_t)stream);
 }
 
-extern "C" int spei_convt2_slab_bf16(const void* a0, int lda0, int k0, int a_bf16, const void* wfrag00, const void* wfrag01,
-                                     const void* wfrag10, const void* wfrag11, const float* bias, void* out, int ldo, int out_bf16,
-                                     int Hin, int Win, int N, int act, spei_stream_t stream) {
-    SPEI_REQUIRE(a0 && wfrag00 && wfrag01 && wfrag10 && wfrag11 && out, "spei_convt2_slab_bf16: null pointer");
-    SPEI_REQUIRE(k0 > 0 && k0 % 32 == 0 && N > 0 && N % 32 == 0, "spei_convt2_slab_bf16: K=%d N=%d must be multiples of 32", k0, N);
-    SPEI_REQUIRE(lda0 % (a_bf16 ? 8 : 4) == 0 && lda0 >= k0 && ldo >= N && ldo % 4 == 0, "spei_convt2_slab_bf16: bad row strides");
-    SPEI_REQUIRE(Hin > 0 && Win > 0 && (int64_t)Hin * Win * 4 * ldo < (1ll << 32), "spei_convt2_slab_bf16: bad map size");
+extern "C" int spei_convt2_slab16(int fmt, const void* a0, int lda0, int k0, int a_fmt, const void* wfrag00, const void* wfrag01,
+                                  const void* wfrag10, const void* wfrag11, const float* bias, void* out, int ldo, int out_fmt,
+                                  int Hin, int Win, int N, int act, spei_stream_t stream) {
+    SPEI_REQUIRE(a0 && wfrag00 && wfrag01 && wfrag10 && wfrag11 && out, "spei_convt2_slab16: null pointer");
+    SPEI_REQUIRE_FMT("spei_convt2_slab16", fmt, a_fmt, out_fmt);
+    const bool a16 = a_fmt != SPEI_F32, o16 = out_fmt != SPEI_F32;
+    SPEI_REQUIRE(k0 > 0 && k0 % 32 == 0 && N > 0 && N % 32 == 0, "spei_convt2_slab16: K=%d N=%d must be multiples of 32", k0, N);
+    SPEI_REQUIRE(lda0 % (a16 ? 8 : 4) == 0 && lda0 >= k0 && ldo >= N && ldo % 4 == 0, "spei_convt2_slab16: bad row strides");
+    SPEI_REQUIRE(Hin > 0 && Win > 0 && (int64_t)Hin * Win * 4 * ldo < (1ll << 32), "spei_convt2_slab16: bad map size");
     SPEI_REQUIRE(((uintptr_t)a0 | (uintptr_t)out | (uintptr_t)wfrag00 | (uintptr_t)wfrag01 | (uintptr_t)wfrag10 | (uintptr_t)wfrag11) % 16 == 0,
-                 "spei_convt2_slab_bf16: operands must be 16-byte aligned");
+                 "spei_convt2_slab16: operands must be 16-byte aligned");
     const void* wf[2][2] = {{wfrag00, wfrag01}, {wfrag10, wfrag11}};
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
             SlabParams p;
-            p.a0 = a0; p.a1 = nullptr; p.wh = (const __bf16*)wf[py][px]; p.wl = nullptr; p.bias = bias; p.out = out;
+            p.a0 = a0; p.a1 = nullptr; p.wh = wf[py][px]; p.wl = nullptr; p.bias = bias; p.out = out;
             p.res = nullptr; p.rowscale = nullptr;
             p.lda0 = lda0; p.lda1 = 0; p.k0 = k0; p.k1 = 0; p.ldo = ldo; p.ldr = 0;
             p.N = N; p.K = k0;
@@ -539,29 +554,27 @@ extern "C" int spei_convt2_slab_bf16(const void* a0, int lda0, int k0, int a_bf1
                     ++p.ntap;
                 }
             p.o_mul = 2; p.o_row_add = py; p.o_col_add = px; p.Wfull = 2 * Win; p.planes = 0;
-            hipStream_t st = (hipStream_t)stream;
-            int rc;
-            if (a_bf16) rc = out_bf16 ? dispatch<false, __bf16, __bf16>(p, st) : dispatch<false, __bf16, float>(p, st);
-            else rc = out_bf16 ? dispatch<false, float, __bf16>(p, st) : dispatch<false, float, float>(p, st);
+            const int rc = dispatch_fmt(p, fmt, false, a16, o16, (hipStream_t)stream);
             if (rc) return rc;
         }
     return 0;
 }
 
-extern "C" int spei_conv5_out_slab_bf16(const void* in, int ldi, int in_bf16, const void* wfrag, const float* bias32, float* out_chw,
-                                        int H, int W, spei_stream_t stream) {
-    SPEI_REQUIRE(in && wfrag && bias32 && out_chw && H > 0 && W > 0, "spei_conv5_out_slab_bf16: bad arguments");
-    SPEI_REQUIRE(ldi >= 32 && ldi % (in_bf16 ? 8 : 4) == 0 && ((uintptr_t)in | (uintptr_t)wfrag | (uintptr_t)out_chw) % 16 == 0,
-                 "spei_conv5_out_slab_bf16: alignment / stride");
-    SPEI_REQUIRE((int64_t)H * W < (1ll << 30), "spei_conv5_out_slab_bf16: map too large");
+extern "C" int spei_conv5_out_slab16(int fmt, const void* in, int ldi, int in_fmt, const void* wfrag, const float* bias32, float* out_chw,
+                                     int H, int W, spei_stream_t stream) {
+    SPEI_REQUIRE(in && wfrag && bias32 && out_chw && H > 0 && W > 0, "spei_conv5_out_slab16: bad arguments");
+    SPEI_REQUIRE_FMT("spei_conv5_out_slab16", fmt, in_fmt, SPEI_F32);
+    const bool a16 = in_fmt != SPEI_F32;
+    SPEI_REQUIRE(ldi >= 32 && ldi % (a16 ? 8 : 4) == 0 && ((uintptr_t)in | (uintptr_t)wfrag | (uintptr_t)out_chw) % 16 == 0,
+                 "spei_conv5_out_slab16: alignment / stride");
+    SPEI_REQUIRE((int64_t)H * W < (1ll << 30), "spei_conv5_out_slab16: map too large");
     SlabParams p;
-    p.a0 = in; p.a1 = nullptr; p.wh = (const __bf16*)wfrag; p.wl = nullptr; p.bias = bias32; p.out = out_chw;
+    p.a0 = in; p.a1 = nullptr; p.wh = wfrag; p.wl = nullptr; p.bias = bias32; p.out = out_chw;
     p.res = nullptr; p.rowscale = nullptr;
     p.lda0 = ldi; p.lda1 = 0; p.k0 = 32; p.k1 = 0; p.ldo = 1; p.ldr = 0;
     p.N = 32; p.K = 32;
     p.Hin = H; p.Win = W; p.Hout = H; p.Wout = W;
     p.ks = 5; p.stride = 1; p.pad = 2; p.act = SPEI_ACT_NONE; p.ln = 0;
     p.ntap = 0; p.o_mul = 1; p.o_row_add = 0; p.o_col_add = 0; p.Wfull = W; p.planes = (int64_t)H * W;
-    hipStream_t st = (hipStream_t)stream;
-    return in_bf16 ? dispatch<false, __bf16, float>(p, st) : dispatch<false, float, float>(p, st);
+    return dispatch_fmt(p, fmt, false, a16, false, (hipStream_t)stream);
 }

@@ -26,17 +26,16 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
 constexpr int CMAXSPLIT = 8;
 constexpr int RB_W = 32;                     // reference block: (2 WJ) rows x 32 positions
 constexpr int SLAB_W = RB_W + 2;             // 34 pixels per slab row (1-pixel halo each side)
 
+template <typename LP>       // LP: __bf16 or _Float16
 struct CorrSlabParams {
-    const __bf16* lrh;
-    const __bf16* lrl;
-    const __bf16* refh;
-    const __bf16* refl;
+    const LP* lrh;
+    const LP* lrl;
+    const LP* refh;
+    const LP* refl;
     const float* inv_lr;
     const float* inv_ref;
     float* pval;
@@ -62,8 +61,9 @@ __device__ __forceinline__ void merge2(float& a1, int& i1, float& a2, int& i2, f
 }
 
 // NI: query tile rows (x 32 columns); KC: reference channels per stage; SPLIT: bf16x3; WJ: waves along the reference rows
-template <int NI, int KC, bool SPLIT, int WJ, bool TOP2>
-__global__ __launch_bounds__(128 * WJ) void corr_slab_kernel(const CorrSlabParams p) {
+template <int NI, int KC, bool SPLIT, int WJ, bool TOP2, typename LP>
+__global__ __launch_bounds__(128 * WJ) void corr_slab_kernel(const CorrSlabParams<LP> p) {
+    typedef typename lpv<LP>::x8 lp8;
     static_assert(!(SPLIT && TOP2), "TOP2 is the single-product form");
     constexpr int C = 128;
     constexpr int NT = 128 * WJ;                       // threads
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(128 * WJ) void corr_slab_kernel(const CorrSlabParam
         // compiler reuses three fragment registers and waits on every ds_read right before its MFMA (29 % MFMA rate).
         constexpr int KS = KC / 16, NS = 9 * KS;
         constexpr int NRD = (2 + TN) * NPART, NMF = 2 * TN * (SPLIT ? 3 : 1);
-        bf16x8 fa[2][2], fb[2][TN], fal[2][2], fbl[2][TN];
+        lp8 fa[2][2], fb[2][TN], fal[2][2], fbl[2][TN];
         auto load_frags = [&](int s, int slot) __attribute__((always_inline)) {
             const int t = s / KS, ks = s - t * KS;
             const int ty = t / 3, tx = t - ty * 3;
@@ -197,13 +197,13 @@ __global__ __launch_bounds__(128 * WJ) void corr_slab_kernel(const CorrSlabParam
             const int boff = (ty * SLAB_W + tx) * PITCH_L + ks * 32;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                fa[slot][i] = *reinterpret_cast<const bf16x8*>(ra + abase[i] + aoff);
-                if (SPLIT) fal[slot][i] = *reinterpret_cast<const bf16x8*>(ra + R_BYTES + abase[i] + aoff);
+                fa[slot][i] = *reinterpret_cast<const lp8*>(ra + abase[i] + aoff);
+                if (SPLIT) fal[slot][i] = *reinterpret_cast<const lp8*>(ra + R_BYTES + abase[i] + aoff);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                fb[slot][j] = *reinterpret_cast<const bf16x8*>(lb + bbase[j] + boff);
-                if (SPLIT) fbl[slot][j] = *reinterpret_cast<const bf16x8*>(lb + L_BYTES + bbase[j] + boff);
+                fb[slot][j] = *reinterpret_cast<const lp8*>(lb + bbase[j] + boff);
+                if (SPLIT) fbl[slot][j] = *reinterpret_cast<const lp8*>(lb + L_BYTES + bbase[j] + boff);
             }
         };
         load_frags(0, 0);
@@ -216,10 +216,10 @@ __global__ __launch_bounds__(128 * WJ) void corr_slab_kernel(const CorrSlabParam
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     if (SPLIT) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fbl[cur][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma16(fal[cur][i], fb[cur][j], acc[i][j]);
+                        acc[i][j] = mfma16(fa[cur][i], fbl[cur][j], acc[i][j]);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma16(fa[cur][i], fb[cur][j], acc[i][j]);
                 }
             if (s + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);   // DS reads of step s+1 ...
             __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);                    // ... then the MFMAs of step s
@@ -391,21 +391,22 @@ __global__ __launch_bounds__(256) void corr_slab_final_kernel(const float* __res
     arg[i] = ix == 0x7fffffff ? 0 : ix;
 }
 
-template <int NI, int KC, bool SPLIT, int WJ, bool TOP2 = false>
-void launch_corr(const CorrSlabParams& p, int itiles, int splits, hipStream_t st) {
+template <typename LP, int NI, int KC, bool SPLIT, int WJ, bool TOP2 = false>
+void launch_corr(const CorrSlabParams<LP>& p, int itiles, int splits, hipStream_t st) {
     constexpr int C = 128;
     constexpr int RB_H = 2 * WJ;
     constexpr int NPART = SPLIT ? 2 : 1;
     constexpr int L_BYTES = ((((NI + 2) * SLAB_W) * (2 * C + 16) + 15) / 16) * 16;
     constexpr int R_BYTES = ((((RB_H + 2) * SLAB_W) * (2 * KC + 16) + 15) / 16) * 16;
     const size_t lds = (size_t)NPART * L_BYTES + (size_t)2 * NPART * R_BYTES + (size_t)2 * RB_H * RB_W * sizeof(float);
-    ensure_dyn_lds<&corr_slab_kernel<NI, KC, SPLIT, WJ, TOP2>>(lds);
-    hipLaunchKernelGGL((corr_slab_kernel<NI, KC, SPLIT, WJ, TOP2>), dim3(itiles, splits), dim3(128 * WJ), lds, st, p);
+    ensure_dyn_lds<&corr_slab_kernel<NI, KC, SPLIT, WJ, TOP2, LP>>(lds);
+    hipLaunchKernelGGL((corr_slab_kernel<NI, KC, SPLIT, WJ, TOP2, LP>), dim3(itiles, splits), dim3(128 * WJ), lds, st, p);
 }
 
 }  // namespace
 
-// shared host side of the three forms: bf16 (top-1), bf16x3 (top-1), bf16 top-2
+// shared host side of the forms: 16-bit top-1 (bf16 / half), bf16x3 top-1, 16-bit top-2
+template <typename LP>
 static int corr_slab_run(const void* lr_hi, const void* lr_lo, const void* ref_hi, const void* ref_lo, const float* inv_lr,
                          const float* inv_ref, int Hl, int Wl, int Hr, int Wr, int C, float* S, int32_t* arg, float* S2,
                          int32_t* arg2, float* ws, spei_stream_t stream, const char* who) {
@@ -417,9 +418,10 @@ static int corr_slab_run(const void* lr_hi, const void* lr_lo, const void* ref_h
     SPEI_REQUIRE((int64_t)Hl * Wl < (1ll << 30) && (int64_t)Hr * Wr < (1ll << 30), "%s: map too large", who);
     SPEI_REQUIRE(((uintptr_t)lr_hi | (uintptr_t)ref_hi | (uintptr_t)lr_lo | (uintptr_t)ref_lo) % 16 == 0, "%s: 16-byte alignment required", who);
     const bool split = lr_lo != nullptr;
+    SPEI_REQUIRE(!(split && (top2 || !__is_same(LP, __bf16))), "%s: the split (bf16x3) form is bf16, top-1", who);
     const int NI = split ? 2 : 4;
-    CorrSlabParams p;
-    p.lrh = (const __bf16*)lr_hi; p.lrl = (const __bf16*)lr_lo; p.refh = (const __bf16*)ref_hi; p.refl = (const __bf16*)ref_lo;
+    CorrSlabParams<LP> p;
+    p.lrh = (const LP*)lr_hi; p.lrl = (const LP*)lr_lo; p.refh = (const LP*)ref_hi; p.refl = (const LP*)ref_lo;
     p.inv_lr = inv_lr; p.inv_ref = inv_ref;
     p.Hl = Hl; p.Wl = Wl; p.Hr = Hr; p.Wr = Wr; p.Nl = Hl * Wl;
     p.itiles_x = cdiv(Wl, RB_W);
@@ -441,9 +443,13 @@ static int corr_slab_run(const void* lr_hi, const void* lr_lo, const void* ref_h
     p.pval = ws;
     p.pidx = reinterpret_cast<int32_t*>(ws + (size_t)(top2 ? 2 : 1) * CMAXSPLIT * p.Nl);
     hipStream_t st = (hipStream_t)stream;
-    if (split) launch_corr<2, 32, true, 2>(p, itiles, splits, st);
-    else if (top2) launch_corr<4, 64, false, 4, true>(p, itiles, splits, st);
-    else launch_corr<4, 64, false, 4>(p, itiles, splits, st);
+    if constexpr (__is_same(LP, __bf16)) {
+        if (split) launch_corr<LP, 2, 32, true, 2>(p, itiles, splits, st);
+    }
+    if (!split) {
+        if (top2) launch_corr<LP, 4, 64, false, 4, true>(p, itiles, splits, st);
+        else launch_corr<LP, 4, 64, false, 4>(p, itiles, splits, st);
+    }
     if (top2)
         hipLaunchKernelGGL(corr_top2_final_kernel, dim3(cdiv(p.Nl, 256)), dim3(256), 0, st, p.pval, p.pidx, splits, p.Nl, S, arg, S2, arg2);
     else
@@ -452,17 +458,25 @@ static int corr_slab_run(const void* lr_hi, const void* lr_lo, const void* ref_h
     return 0;
 }
 
-extern "C" int spei_corr_slab_bf16(const void* lr_hi, const void* lr_lo, const void* ref_hi, const void* ref_lo,
-                                   const float* inv_lr, const float* inv_ref, int Hl, int Wl, int Hr, int Wr, int C,
-                                   float* S, int32_t* arg, float* ws, spei_stream_t stream) {
-    return corr_slab_run(lr_hi, lr_lo, ref_hi, ref_lo, inv_lr, inv_ref, Hl, Wl, Hr, Wr, C, S, arg, nullptr, nullptr, ws, stream,
-                         "spei_corr_slab_bf16");
+extern "C" int spei_corr_slab16(int fmt, const void* lr_hi, const void* lr_lo, const void* ref_hi, const void* ref_lo,
+                                const float* inv_lr, const float* inv_ref, int Hl, int Wl, int Hr, int Wr, int C,
+                                float* S, int32_t* arg, float* ws, spei_stream_t stream) {
+    SPEI_REQUIRE(fmt == SPEI_BF16 || fmt == SPEI_F16, "spei_corr_slab16: fmt=%d", fmt);
+    if (fmt == SPEI_F16)
+        return corr_slab_run<_Float16>(lr_hi, lr_lo, ref_hi, ref_lo, inv_lr, inv_ref, Hl, Wl, Hr, Wr, C, S, arg, nullptr, nullptr, ws, stream,
+                                       "spei_corr_slab16");
+    return corr_slab_run<__bf16>(lr_hi, lr_lo, ref_hi, ref_lo, inv_lr, inv_ref, Hl, Wl, Hr, Wr, C, S, arg, nullptr, nullptr, ws, stream,
+                                 "spei_corr_slab16");
 }
 
-extern "C" int spei_corr_slab_top2_bf16(const void* lr_bf16, const void* ref_bf16, const float* inv_lr, const float* inv_ref,
-                                        int Hl, int Wl, int Hr, int Wr, int C, float* S, int32_t* arg, float* S2, int32_t* arg2,
-                                        float* ws, spei_stream_t stream) {
-    SPEI_REQUIRE(S2 && arg2, "spei_corr_slab_top2_bf16: null pointer");
-    return corr_slab_run(lr_bf16, nullptr, ref_bf16, nullptr, inv_lr, inv_ref, Hl, Wl, Hr, Wr, C, S, arg, S2, arg2, ws, stream,
-                         "spei_corr_slab_top2_bf16");
+extern "C" int spei_corr_slab_top2_16(int fmt, const void* lr16, const void* ref16, const float* inv_lr, const float* inv_ref,
+                                      int Hl, int Wl, int Hr, int Wr, int C, float* S, int32_t* arg, float* S2, int32_t* arg2,
+                                      float* ws, spei_stream_t stream) {
+    SPEI_REQUIRE(S2 && arg2, "spei_corr_slab_top2_16: null pointer");
+    SPEI_REQUIRE(fmt == SPEI_BF16 || fmt == SPEI_F16, "spei_corr_slab_top2_16: fmt=%d", fmt);
+    if (fmt == SPEI_F16)
+        return corr_slab_run<_Float16>(lr16, nullptr, ref16, nullptr, inv_lr, inv_ref, Hl, Wl, Hr, Wr, C, S, arg, S2, arg2, ws, stream,
+                                       "spei_corr_slab_top2_16");
+    return corr_slab_run<__bf16>(lr16, nullptr, ref16, nullptr, inv_lr, inv_ref, Hl, Wl, Hr, Wr, C, S, arg, S2, arg2, ws, stream,
+                                 "spei_corr_slab_top2_16");
 }

@@ -1,4 +1,4 @@
-// Fused Swin MLP branch on the gfx950 bf16 matrix pipe:
+// Fused Swin MLP branch on the gfx950 16-bit matrix pipe (bf16 or half operands):
 //
 //     out = x + fc2( GELU( fc1( LayerNorm(x) ) ) )          (reference model/swinir.py:12-29 Mlp, :279 block tail)
 //
@@ -18,20 +18,18 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
 constexpr int D = 256, HID = 512, MT = 128;         // model dim, hidden dim, tokens per workgroup
 constexpr int RT = MT / 32;                         // 32-token row tiles
 constexpr int PA = 2 * D + 16;                      // LDS row pitch (bytes), token slab and hidden-half slab alike
 constexpr int RING = 4;                             // weight fragments in flight per wave
 
+template <typename LP>       // LP: __bf16 or _Float16
 struct MlpParams {
     const float* x;
     float* out;
-    const __bf16* w1;     // fragment order [HID/32][1][D/16][64][8]
+    const LP* w1;         // fragment order [HID/32][1][D/16][64][8]
     const float* b1;
-    const __bf16* w2;     // fragment order [D/32][1][HID/16][64][8]
+    const LP* w2;         // fragment order [D/32][1][HID/16][64][8]
     const float* b2;
     int M;
 };
@@ -64,7 +62,10 @@ __device__ __forceinline__ float dpp_add(float v) { return v + dpp_quad<CTRL>(v)
 // all-reduce over each aligned group of 16 lanes: xor 1, xor 2 (quad_perm), then row_half_mirror / row_mirror
 __device__ __forceinline__ float sum16(float v) { return dpp_add<0x140>(dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(v)))); }
 
-__global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams p) {
+template <typename LP>
+__global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams<LP> p) {
+    typedef typename lpv<LP>::x8 lp8;
+    typedef typename lpv<LP>::x4 lp4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sa = smem;                               // [MT][PA]   normalised tokens, bf16
     unsigned char* sh = smem + MT * PA;                     // [MT][PA]   one half (256 channels) of the hidden activations
@@ -102,10 +103,10 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams p) {
             const float rstd = 1.0f / sqrtf(sum16(ss) * (1.0f / 256.0f) + 1e-5f);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                bf16x4 hv;
+                lp4 hv;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) hv[e] = (__bf16)(xr[b][j][e] * rstd);
-                *reinterpret_cast<bf16x4*>(sa + r * PA + (l16 + 16 * j) * 8) = hv;
+                for (int e = 0; e < 4; ++e) hv[e] = to_lp<LP>(xr[b][j][e] * rstd);
+                *reinterpret_cast<lp4*>(sa + r * PA + (l16 + 16 * j) * 8) = hv;
             }
         }
     }
@@ -113,10 +114,10 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams p) {
     // Every workgroup walks the K dimension of each GEMM from a different k-step (rot): otherwise all 256 CUs request
     // the same weight fragment from the same L2 channel at the same time.
     const int rot = blockIdx.x & 15;
-    bf16x8 ring[RING];
-    const __bf16* wptr = p.w1 + (size_t)wave * 16 * 512 + lane * 8;      // fc1, half 0: hidden tile `wave`
+    lp8 ring[RING];
+    const LP* wptr = p.w1 + (size_t)wave * 16 * 512 + lane * 8;      // fc1, half 0: hidden tile `wave`
 #pragma unroll
-    for (int d = 0; d < RING; ++d) ring[d] = *reinterpret_cast<const bf16x8*>(wptr + ((rot + d) & 15) * 512);
+    for (int d = 0; d < RING; ++d) ring[d] = *reinterpret_cast<const lp8*>(wptr + ((rot + d) & 15) * 512);
     __syncthreads();
 
     f32x16 acc2[RT];                                        // fc2 accumulators: tokens x output channels [32 wave, +32)
@@ -141,35 +142,35 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams p) {
         // then the MFMAs of step s".  Left alone the scheduler sinks every load to right before its use (ds_read +
         // lgkmcnt(0) in front of each MFMA, global_load + vmcnt(0) one step ahead: seen in the ISA) and the loop runs at
         // LDS / L2 latency; sched_group_barrier groups did not take in this fully unrolled region.
-        bf16x8 tn[RT];
+        lp8 tn[RT];
 #pragma unroll
-        for (int i = 0; i < RT; ++i) tn[i] = *reinterpret_cast<const bf16x8*>(abase + i * 32 * PA + rot * 32);
+        for (int i = 0; i < RT; ++i) tn[i] = *reinterpret_cast<const lp8*>(abase + i * 32 * PA + rot * 32);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            bf16x8 tc[RT];
+            lp8 tc[RT];
 #pragma unroll
             for (int i = 0; i < RT; ++i) tc[i] = tn[i];
             if (s + 1 < 16) {
 #pragma unroll
-                for (int i = 0; i < RT; ++i) tn[i] = *reinterpret_cast<const bf16x8*>(abase + i * 32 * PA + ((rot + s + 1) & 15) * 32);
+                for (int i = 0; i < RT; ++i) tn[i] = *reinterpret_cast<const lp8*>(abase + i * 32 * PA + ((rot + s + 1) & 15) * 32);
             }
-            const bf16x8 w = ring[s % RING];
-            if (s + RING < 16) ring[s % RING] = *reinterpret_cast<const bf16x8*>(wptr + ((rot + s + RING) & 15) * 512);
+            const lp8 w = ring[s % RING];
+            if (s + RING < 16) ring[s % RING] = *reinterpret_cast<const lp8*>(wptr + ((rot + s + RING) & 15) * 512);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < RT; ++i) acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, tc[i], acc1[i], 0, 0, 0);
+            for (int i = 0; i < RT; ++i) acc1[i] = mfma16(w, tc[i], acc1[i]);
             __builtin_amdgcn_sched_barrier(0);
         }
         // fc2 weight stream of this half starts under the GELU; the last half fetches ALL its fragments here, so that the
         // residual loads below can queue behind them without any later weight load waiting for those (vmcnt is in order)
         wptr = p.w2 + (size_t)wave * 32 * 512 + (size_t)half * 16 * 512 + lane * 8;
-        bf16x8 wlast[16];
+        lp8 wlast[16];
         if (half == 0) {
 #pragma unroll
-            for (int d = 0; d < RING; ++d) ring[d] = *reinterpret_cast<const bf16x8*>(wptr + ((rot + d) & 15) * 512);
+            for (int d = 0; d < RING; ++d) ring[d] = *reinterpret_cast<const lp8*>(wptr + ((rot + d) & 15) * 512);
         } else {
 #pragma unroll
-            for (int d = 0; d < 16; ++d) wlast[d] = *reinterpret_cast<const bf16x8*>(wptr + ((rot + d) & 15) * 512);
+            for (int d = 0; d < 16; ++d) wlast[d] = *reinterpret_cast<const lp8*>(wptr + ((rot + d) & 15) * 512);
             __syncthreads();                                // fc2 of half 0 is done reading the hidden slab
         }
         // rows c = (r&3) + 8*(r>>2) + 4*fk = 8g + 4fk + e, column = token fr  ->  sh[token][32 wave + c]
@@ -180,9 +181,9 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams p) {
             for (int i = 0; i < RT; ++i) {
                 const f32x2 g01 = gelu2(f32x2{acc1[i][4 * g] + bv[0], acc1[i][4 * g + 1] + bv[1]});
                 const f32x2 g23 = gelu2(f32x2{acc1[i][4 * g + 2] + bv[2], acc1[i][4 * g + 3] + bv[3]});
-                bf16x4 hv;
-                hv[0] = (__bf16)g01[0]; hv[1] = (__bf16)g01[1]; hv[2] = (__bf16)g23[0]; hv[3] = (__bf16)g23[1];
-                *reinterpret_cast<bf16x4*>(sh + (i * 32 + fr) * PA + (wave * 32 + 8 * g + 4 * fk) * 2) = hv;
+                lp4 hv;
+                hv[0] = to_lp<LP>(g01[0]); hv[1] = to_lp<LP>(g01[1]); hv[2] = to_lp<LP>(g23[0]); hv[3] = to_lp<LP>(g23[1]);
+                *reinterpret_cast<lp4*>(sh + (i * 32 + fr) * PA + (wave * 32 + 8 * g + 4 * fk) * 2) = hv;
             }
         }
         if (half == 1) {
@@ -198,27 +199,27 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams p) {
         __syncthreads();
         // ---- 2b. fc2 partial product over this half of the hidden dim ------------------------------------------------------
 #pragma unroll
-        for (int i = 0; i < RT; ++i) tn[i] = *reinterpret_cast<const bf16x8*>(hbase + i * 32 * PA + rot * 32);
+        for (int i = 0; i < RT; ++i) tn[i] = *reinterpret_cast<const lp8*>(hbase + i * 32 * PA + rot * 32);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            bf16x8 tc[RT];
+            lp8 tc[RT];
 #pragma unroll
             for (int i = 0; i < RT; ++i) tc[i] = tn[i];
             if (s + 1 < 16) {
 #pragma unroll
-                for (int i = 0; i < RT; ++i) tn[i] = *reinterpret_cast<const bf16x8*>(hbase + i * 32 * PA + ((rot + s + 1) & 15) * 32);
+                for (int i = 0; i < RT; ++i) tn[i] = *reinterpret_cast<const lp8*>(hbase + i * 32 * PA + ((rot + s + 1) & 15) * 32);
             }
-            const bf16x8 w = half == 0 ? ring[s % RING] : wlast[s];
-            if (half == 0 && s + RING < 16) ring[s % RING] = *reinterpret_cast<const bf16x8*>(wptr + ((rot + s + RING) & 15) * 512);
+            const lp8 w = half == 0 ? ring[s % RING] : wlast[s];
+            if (half == 0 && s + RING < 16) ring[s % RING] = *reinterpret_cast<const lp8*>(wptr + ((rot + s + RING) & 15) * 512);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < RT; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tc[i], w, acc2[i], 0, 0, 0);
+            for (int i = 0; i < RT; ++i) acc2[i] = mfma16(tc[i], w, acc2[i]);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (half == 0) {
             wptr = p.w1 + (size_t)(8 + wave) * 16 * 512 + lane * 8;      // fc1, half 1
 #pragma unroll
-            for (int d = 0; d < RING; ++d) ring[d] = *reinterpret_cast<const bf16x8*>(wptr + ((rot + d) & 15) * 512);
+            for (int d = 0; d < RING; ++d) ring[d] = *reinterpret_cast<const lp8*>(wptr + ((rot + d) & 15) * 512);
         }
     }
 
@@ -242,16 +243,24 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams p) {
 
 }  // namespace
 
-extern "C" int spei_mlp_fused_bf16(const float* x, float* out, const void* w1_frag, const float* b1, const void* w2_frag,
-                                   const float* b2, int64_t M, spei_stream_t stream) {
-    SPEI_REQUIRE(x && out && w1_frag && b1 && w2_frag && b2 && M > 0, "spei_mlp_fused_bf16: bad arguments");
-    SPEI_REQUIRE(M < (1ll << 31), "spei_mlp_fused_bf16: too many tokens");
-    SPEI_REQUIRE(((uintptr_t)x | (uintptr_t)out | (uintptr_t)w1_frag | (uintptr_t)w2_frag) % 16 == 0, "spei_mlp_fused_bf16: 16-byte alignment required");
-    MlpParams p;
-    p.x = x; p.out = out; p.w1 = (const __bf16*)w1_frag; p.b1 = b1; p.w2 = (const __bf16*)w2_frag; p.b2 = b2; p.M = (int)M;
+template <typename LP>
+static int mlp_launch(const float* x, float* out, const void* w1, const float* b1, const void* w2, const float* b2, int64_t M, hipStream_t st) {
+    MlpParams<LP> p;
+    p.x = x; p.out = out; p.w1 = (const LP*)w1; p.b1 = b1; p.w2 = (const LP*)w2; p.b2 = b2; p.M = (int)M;
     const size_t lds = (size_t)2 * MT * PA + HID * sizeof(float);
-    ensure_dyn_lds<&mlp_fused_kernel>(lds);
-    hipLaunchKernelGGL(mlp_fused_kernel, dim3(cdiv(M, MT)), dim3(512), lds, (hipStream_t)stream, p);
-    SPEI_CHECK_LAUNCH("spei_mlp_fused_bf16");
+    ensure_dyn_lds<&mlp_fused_kernel<LP>>(lds);
+    hipLaunchKernelGGL(mlp_fused_kernel<LP>, dim3(cdiv(M, MT)), dim3(512), lds, st, p);
+    SPEI_CHECK_LAUNCH("spei_mlp_fused16");
     return 0;
+}
+
+extern "C" int spei_mlp_fused16(int fmt, const float* x, float* out, const void* w1_frag, const float* b1, const void* w2_frag,
+                                const float* b2, int64_t M, spei_stream_t stream) {
+    SPEI_REQUIRE(x && out && w1_frag && b1 && w2_frag && b2 && M > 0, "spei_mlp_fused16: bad arguments");
+    SPEI_REQUIRE(fmt == SPEI_BF16 || fmt == SPEI_F16, "spei_mlp_fused16: fmt=%d", fmt);
+    SPEI_REQUIRE(M < (1ll << 31), "spei_mlp_fused16: too many tokens");
+    SPEI_REQUIRE(((uintptr_t)x | (uintptr_t)out | (uintptr_t)w1_frag | (uintptr_t)w2_frag) % 16 == 0, "spei_mlp_fused16: 16-byte alignment required");
+    hipStream_t st = (hipStream_t)stream;
+    if (fmt == SPEI_F16) return mlp_launch<_Float16>(x, out, w1_frag, b1, w2_frag, b2, M, st);
+    return mlp_launch<__bf16>(x, out, w1_frag, b1, w2_frag, b2, M, st);
 }

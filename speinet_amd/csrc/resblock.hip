@@ -41,15 +41,14 @@ __host__ __device__ inline GateWs carve(float* ws, int H, int W, int C) {
     return g;
 }
 
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 template <typename T>
-__device__ __forceinline__ f32x4 ld4(const T* p);
-template <>
-__device__ __forceinline__ f32x4 ld4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-template <>
-__device__ __forceinline__ f32x4 ld4<__bf16>(const __bf16* p) {
-    const bf16x4 h = *reinterpret_cast<const bf16x4*>(p);
-    return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+__device__ __forceinline__ f32x4 ld4(const T* p) {                    // fp32, bf16 or half in HBM
+    if constexpr (sizeof(T) == 4) {
+        return *reinterpret_cast<const f32x4*>(p);
+    } else {
+        const typename lpv<T>::x4 h = *reinterpret_cast<const typename lpv<T>::x4*>(p);
+        return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    }
 }
 
 __device__ __forceinline__ f32x4 max4(f32x4 a, f32x4 b) {
@@ -328,7 +327,7 @@ extern "C" int64_t spei_gate_ws_floats(int H, int W, int C) {
     return 2 * ntx * H * C + 2 * nty * W * C + ntx * nty * C;
 }
 
-extern "C" int spei_resblock_gates(const void* x1, int x1_bf16, int H, int W, int C, const float* se_w1, const float* se_b1,
+extern "C" int spei_resblock_gates(const void* x1, int x1_fmt, int H, int W, int C, const float* se_w1, const float* se_b1,
                                    const float* se_w2, const float* se_b2, const float* cw_w, const float* cw_bn,
                                    const float* hc_w, const float* hc_bn, float* s, float* g1, float* g2, float* ws,
                                    spei_stream_t stream) {
@@ -340,11 +339,17 @@ extern "C" int spei_resblock_gates(const void* x1, int x1_bf16, int H, int W, in
     hipStream_t st = (hipStream_t)stream;
     GateWs g = carve(ws, H, W, C);
     dim3 grid1(g.ntx * g.nty);
-    if (x1_bf16) {
+    SPEI_REQUIRE(x1_fmt == SPEI_F32 || x1_fmt == SPEI_BF16 || x1_fmt == SPEI_F16, "spei_resblock_gates: x1_fmt=%d", x1_fmt);
+    if (x1_fmt == SPEI_BF16) {
         const __bf16* xp = (const __bf16*)x1;
         if (C == 32) hipLaunchKernelGGL((gate_stats_kernel<32, __bf16>), grid1, dim3(256), 0, st, xp, H, W, g);
         else if (C == 64) hipLaunchKernelGGL((gate_stats_kernel<64, __bf16>), grid1, dim3(256), 0, st, xp, H, W, g);
         else hipLaunchKernelGGL((gate_stats_kernel<128, __bf16>), grid1, dim3(256), 0, st, xp, H, W, g);
+    } else if (x1_fmt == SPEI_F16) {
+        const _Float16* xp = (const _Float16*)x1;
+        if (C == 32) hipLaunchKernelGGL((gate_stats_kernel<32, _Float16>), grid1, dim3(256), 0, st, xp, H, W, g);
+        else if (C == 64) hipLaunchKernelGGL((gate_stats_kernel<64, _Float16>), grid1, dim3(256), 0, st, xp, H, W, g);
+        else hipLaunchKernelGGL((gate_stats_kernel<128, _Float16>), grid1, dim3(256), 0, st, xp, H, W, g);
     } else {
         const float* xp = (const float*)x1;
         if (C == 32) hipLaunchKernelGGL((gate_stats_kernel<32, float>), grid1, dim3(256), 0, st, xp, H, W, g);
@@ -357,13 +362,15 @@ extern "C" int spei_resblock_gates(const void* x1, int x1_bf16, int H, int W, in
     return 0;
 }
 
-extern "C" int spei_resblock_apply(const float* x, const void* x1, int x1_bf16, const float* s, const float* g1, const float* g2,
+extern "C" int spei_resblock_apply(const float* x, const void* x1, int x1_fmt, const float* s, const float* g1, const float* g2,
                                    const float* extra, float* out, int ldo, int H, int W, int C, spei_stream_t stream) {
     SPEI_REQUIRE(x && x1 && s && g1 && g2 && out, "spei_resblock_apply: null pointer");
     SPEI_REQUIRE(C % 4 == 0 && ldo % 4 == 0 && ldo >= C && H > 0 && W > 0, "spei_resblock_apply: bad shape");
     const int64_t total = (int64_t)H * W * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    if (x1_bf16) hipLaunchKernelGGL(resblock_apply_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (const __bf16*)x1, s, g1, g2, extra, out, ldo, H, W, C);
+    SPEI_REQUIRE(x1_fmt == SPEI_F32 || x1_fmt == SPEI_BF16 || x1_fmt == SPEI_F16, "spei_resblock_apply: x1_fmt=%d", x1_fmt);
+    if (x1_fmt == SPEI_BF16) hipLaunchKernelGGL(resblock_apply_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (const __bf16*)x1, s, g1, g2, extra, out, ldo, H, W, C);
+    else if (x1_fmt == SPEI_F16) hipLaunchKernelGGL(resblock_apply_kernel<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (const _Float16*)x1, s, g1, g2, extra, out, ldo, H, W, C);
     else hipLaunchKernelGGL(resblock_apply_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (const float*)x1, s, g1, g2, extra, out, ldo, H, W, C);
     SPEI_CHECK_LAUNCH("spei_resblock_apply");
     return 0;

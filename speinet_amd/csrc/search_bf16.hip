@@ -14,22 +14,24 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, int ld, __bf16* __restrict__ hi,
-                                                         __bf16* __restrict__ lo, int64_t M, int C) {
+template <typename LP>
+__global__ __launch_bounds__(256) void split16_kernel(const float* __restrict__ x, int ld, LP* __restrict__ hi,
+                                                      LP* __restrict__ lo, int64_t M, int C) {
+    typedef typename lpv<LP>::x4 lp4;
     const int cg = C / 4;
     const int64_t total = M * cg;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % cg) * 4;
         const int64_t m = i / cg;
         const float4 v = *reinterpret_cast<const float4*>(x + m * ld + c);
-        bf16x4 h;
-        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
-        *reinterpret_cast<bf16x4*>(hi + m * C + c) = h;
+        lp4 h;
+        h[0] = (LP)v.x; h[1] = (LP)v.y; h[2] = (LP)v.z; h[3] = (LP)v.w;
+        *reinterpret_cast<lp4*>(hi + m * C + c) = h;
         if (lo) {
-            bf16x4 l;
-            l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
-            l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
-            *reinterpret_cast<bf16x4*>(lo + m * C + c) = l;
+            lp4 l;
+            l[0] = (LP)(v.x - (float)h[0]); l[1] = (LP)(v.y - (float)h[1]);
+            l[2] = (LP)(v.z - (float)h[2]); l[3] = (LP)(v.w - (float)h[3]);
+            *reinterpret_cast<lp4*>(lo + m * C + c) = l;
         }
     }
 }
@@ -247,12 +249,16 @@ int launch_corr(const CorrParams& p, int itiles, int splits, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int spei_split_bf16(const float* x, int ld, void* hi, void* lo, int64_t M, int C, spei_stream_t stream) {
-    SPEI_REQUIRE(x && hi && M > 0 && C > 0 && C % 4 == 0 && ld % 4 == 0 && ld >= C, "spei_split_bf16: bad arguments");
+extern "C" int spei_split16(int fmt, const float* x, int ld, void* hi, void* lo, int64_t M, int C, spei_stream_t stream) {
+    SPEI_REQUIRE(x && hi && M > 0 && C > 0 && C % 4 == 0 && ld % 4 == 0 && ld >= C, "spei_split16: bad arguments");
+    SPEI_REQUIRE(fmt == SPEI_BF16 || fmt == SPEI_F16, "spei_split16: fmt=%d", fmt);
     const int64_t total = M * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(split_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ld, (__bf16*)hi, (__bf16*)lo, M, C);
-    SPEI_CHECK_LAUNCH("spei_split_bf16");
+    if (fmt == SPEI_F16)
+        hipLaunchKernelGGL(split16_kernel<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ld, (_Float16*)hi, (_Float16*)lo, M, C);
+    else
+        hipLaunchKernelGGL(split16_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ld, (__bf16*)hi, (__bf16*)lo, M, C);
+    SPEI_CHECK_LAUNCH("spei_split16");
     return 0;
 }
 

@@ -7,9 +7,6 @@ namespace {
 // ---------------------------------------------------------------------------------------------------
 // LayerNorm over 256 channels: one wave per token, 4 channels per lane, two-pass moments in registers.
 // ---------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
 template <typename TO>
 __global__ __launch_bounds__(256) void layernorm256_kernel(const float* __restrict__ x, TO* __restrict__ y,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -34,9 +31,9 @@ __global__ __launch_bounds__(256) void layernorm256_kernel(const float* __restri
         if (sizeof(TO) == 4) {
             reinterpret_cast<float4*>(y + m * 256)[lane] = o;
         } else {
-            bf16x4 h;
-            h[0] = (__bf16)o.x; h[1] = (__bf16)o.y; h[2] = (__bf16)o.z; h[3] = (__bf16)o.w;
-            reinterpret_cast<bf16x4*>(y + m * 256)[lane] = h;
+            typename lpv<TO>::x4 h;
+            h[0] = (TO)o.x; h[1] = (TO)o.y; h[2] = (TO)o.z; h[3] = (TO)o.w;
+            reinterpret_cast<typename lpv<TO>::x4*>(y + m * 256)[lane] = h;
         }
     }
 }
@@ -57,13 +54,13 @@ __device__ __forceinline__ int mask_region(int v, int n, int shift) {
 }
 
 template <typename T>
-__device__ __forceinline__ float4 load4(const T* p);
-template <>
-__device__ __forceinline__ float4 load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
-template <>
-__device__ __forceinline__ float4 load4<__bf16>(const __bf16* p) {
-    const bf16x4 h = *reinterpret_cast<const bf16x4*>(p);
-    return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+__device__ __forceinline__ float4 load4(const T* p) {                 // fp32, bf16 or half in HBM
+    if constexpr (sizeof(T) == 4) {
+        return *reinterpret_cast<const float4*>(p);
+    } else {
+        const typename lpv<T>::x4 h = *reinterpret_cast<const typename lpv<T>::x4*>(p);
+        return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    }
 }
 
 template <typename T>
@@ -157,24 +154,28 @@ __global__ __launch_bounds__(256) void window_attention_kernel(const T* __restri
 
 }  // namespace
 
-extern "C" int spei_layernorm256(const float* x, void* y, int out_bf16, const float* gamma, const float* beta, int64_t M,
+extern "C" int spei_layernorm256(const float* x, void* y, int out_fmt, const float* gamma, const float* beta, int64_t M,
                                  spei_stream_t stream) {
     SPEI_REQUIRE(x && y && M > 0, "spei_layernorm256: bad arguments");
+    SPEI_REQUIRE(out_fmt == SPEI_F32 || out_fmt == SPEI_BF16 || out_fmt == SPEI_F16, "spei_layernorm256: out_fmt=%d", out_fmt);
     const int64_t blocks = (M + 3) / 4;
     const dim3 grid((unsigned)(blocks < 8192 ? blocks : 8192));
-    if (out_bf16) hipLaunchKernelGGL(layernorm256_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, x, (__bf16*)y, gamma, beta, M);
+    if (out_fmt == SPEI_BF16) hipLaunchKernelGGL(layernorm256_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, x, (__bf16*)y, gamma, beta, M);
+    else if (out_fmt == SPEI_F16) hipLaunchKernelGGL(layernorm256_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, x, (_Float16*)y, gamma, beta, M);
     else hipLaunchKernelGGL(layernorm256_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, (float*)y, gamma, beta, M);
     SPEI_CHECK_LAUNCH("spei_layernorm256");
     return 0;
 }
 
-extern "C" int spei_window_attention(const void* q, const void* kv, int io_bf16, const float* relbias, void* out, int H, int W,
+extern "C" int spei_window_attention(const void* q, const void* kv, int io_fmt, const float* relbias, void* out, int H, int W,
                                      int shift, spei_stream_t stream) {
     SPEI_REQUIRE(q && kv && relbias && out, "spei_window_attention: null pointer");
     SPEI_REQUIRE(H > 0 && W > 0 && H % WS == 0 && W % WS == 0, "spei_window_attention: %dx%d is not a multiple of the 5x5 window", H, W);
     SPEI_REQUIRE(shift >= 0 && shift < WS, "spei_window_attention: shift=%d", shift);
+    SPEI_REQUIRE(io_fmt == SPEI_F32 || io_fmt == SPEI_BF16 || io_fmt == SPEI_F16, "spei_window_attention: io_fmt=%d", io_fmt);
     const dim3 grid(2 * (H / WS) * (W / WS));
-    if (io_bf16) hipLaunchKernelGGL(window_attention_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)q, (const __bf16*)kv, relbias, (__bf16*)out, H, W, shift);
+    if (io_fmt == SPEI_BF16) hipLaunchKernelGGL(window_attention_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)q, (const __bf16*)kv, relbias, (__bf16*)out, H, W, shift);
+    else if (io_fmt == SPEI_F16) hipLaunchKernelGGL(window_attention_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)q, (const _Float16*)kv, relbias, (_Float16*)out, H, W, shift);
     else hipLaunchKernelGGL(window_attention_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)q, (const float*)kv, relbias, (float*)out, H, W, shift);
     SPEI_CHECK_LAUNCH("spei_window_attention");
     return 0;

@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from .pack import PackedW
+from .pack import BF16, F16, F32, LP_DTYPE, PackedW, fmt_of
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 CONV, CONV_T = 0, 1
@@ -23,22 +23,25 @@ CONV, CONV_T = 0, 1
 # Arithmetic of the GEMM-shaped kernels (convolutions, linears, correlation); everything else is always fp32.
 #   "f32"    v_mfma_f32_32x32x2_f32, exact fp32 (the PSNR-parity configuration)
 #   "bf16x3" split-bf16 products on v_mfma_f32_32x32x16_bf16: f32-grade results at 3/16 of the f32 MFMA cost
-#   "bf16"   single bf16 products, fp32 accumulate (the throughput configuration of BASELINE.json configs[1])
-# Correlation arg-max when precision != "f32":
-#   "bf16x3" f32-grade scores;  "bf16" single bf16 products (winner may flip between near-ties);
-#   "bf16r"  single bf16 products carrying the two best candidates per query, then an exact-fp32 re-score of every
-#            query whose bf16 margin is inside the bf16 error bound (spei_corr_rescore): f32-grade winners and S at bf16 cost
-PRECISIONS = ("f32", "bf16x3", "bf16")
-CORR_PRECISIONS = ("bf16x3", "bf16", "bf16r")
+#   "bf16"   single bf16 products, fp32 accumulate (BASELINE.json configs[1] as written: 8-bit significands)
+#   "f16"    single IEEE-half products, fp32 accumulate: the same matrix-pipe rate with 11-bit significands — the
+#            throughput configuration that also holds the 1e-3 dB PSNR bound; range +-65504
+# Correlation arg-max when precision != "f32" (16-bit products use the format of `precision`, bf16 unless "f16"):
+#   "bf16x3" f32-grade scores;  "single" one 16-bit product per MAC (the winner may flip between near-ties);
+#   "top2"   single products keeping the TWO best candidates of every query, then an exact re-score of both on the fp32
+#            maps with fp64 accumulation (spei_corr_rescore): f32-grade winners and S at the cost of the 16-bit kernel
+PRECISIONS = ("f32", "bf16x3", "bf16", "f16")
+CORR_PRECISIONS = ("bf16x3", "single", "top2")
+_CORR_ALIASES = {"bf16": "single", "bf16r": "top2", "f16": "single"}
 
 
 class FMap:
-    """NHWC feature map view (fp32, or bf16 for GEMM-only intermediates): rows = pixels, `C` channels starting at
+    """NHWC feature map view (fp32, or bf16 / half for GEMM-only intermediates): rows = pixels, `C` channels starting at
     column `off` of a [H*W, ld] buffer."""
     __slots__ = ("t", "H", "W", "C", "ld", "off")
 
     def __init__(self, t: torch.Tensor, H: int, W: int, C_: int, off: int = 0):
-        assert t.is_cuda and t.dtype in (torch.float32, torch.bfloat16) and t.is_contiguous() and t.dim() == 2 and t.shape[0] == H * W
+        assert t.is_cuda and t.dtype in (torch.float32, torch.bfloat16, torch.float16) and t.is_contiguous() and t.dim() == 2 and t.shape[0] == H * W
         self.t, self.H, self.W, self.C, self.ld, self.off = t, H, W, C_, t.shape[1], off
         assert off + C_ <= self.ld
 
@@ -47,8 +50,13 @@ class FMap:
         return FMap(torch.empty(H * W, C_, device=device, dtype=dtype), H, W, C_)
 
     @property
-    def bf16(self) -> bool:
-        return self.t.dtype == torch.bfloat16
+    def lp(self) -> bool:
+        """Stored as 16-bit (bf16 or half)."""
+        return self.t.dtype != torch.float32
+
+    @property
+    def fmt(self) -> int:
+        return fmt_of(self.t.dtype)
 
     def view(self, off: int, C_: int) -> "FMap":
         return FMap(self.t, self.H, self.W, C_, self.off + off)
@@ -102,13 +110,14 @@ class Ctx:
     precision / corr_precision   see PRECISIONS / CORR_PRECISIONS above
     device                       the ROCm device every tensor of the call lives on; kernels are launched on torch's current
                                  stream OF THAT DEVICE, and every pointer handed to the C-ABI is checked against it
-    knobs (all default True; parity ablations switch them off one at a time, tools/ablate_parity.py):
-      use_slab        bf16 modes: slab-resident conv / linear kernel (conv_slab_bf16.hip) instead of igemm_bf16.hip
-      bf16_storage    "bf16": tensors that ONLY feed the next GEMM / the attention kernel live in HBM as bf16
-      x1_bf16         "bf16": the ResBlock's conv2 output (read by the gate statistics and the apply pass) is bf16
-      fuse_mlp        "bf16": LayerNorm -> fc1 -> GELU -> fc2 -> +x in one kernel (mlp_fused_bf16.hip)
-      fuse_attn       "bf16": LayerNorm -> q/kv GEMMs -> window attention -> proj -> +x in one kernel
-      commute_upconv  "bf16": relu(conv1x1(bicubic_up(x))) evaluated as relu(bicubic_up(conv1x1(x)))
+    knobs (all default True; parity ablations switch them off one at a time, tools/ablate_parity.py; "16-bit" = the
+    single-product modes "bf16" / "f16"):
+      use_slab        slab-resident conv / linear kernel (conv_slab16.hip) instead of igemm_bf16.hip (bf16 / bf16x3 only)
+      bf16_storage    16-bit: tensors that ONLY feed the next GEMM / the attention kernel live in HBM as 16-bit
+      x1_bf16         16-bit: the ResBlock's conv2 output (read by the gate statistics and the apply pass) is 16-bit
+      fuse_mlp        16-bit: LayerNorm -> fc1 -> GELU -> fc2 -> +x in one kernel (mlp_fused16.hip)
+      fuse_attn       16-bit: LayerNorm -> q/kv GEMMs -> window attention -> proj -> +x in one kernel (attn_fused16.hip)
+      commute_upconv  16-bit: relu(conv1x1(bicubic_up(x))) evaluated as relu(bicubic_up(conv1x1(x)))
     stage        {stage name: {field: value}} overrides applied by `for_stage` (engine: "enc", "swin", "search", "decode")
     profile      None, or {op name: [(start_event, end_event), ...]} filled on the launch stream (bench.py)
     capture      None, or a dict that receives intermediate device tensors by name ("arg", "s": what SearchTransfer
@@ -126,10 +135,13 @@ class Ctx:
                  capture: Optional[dict] = None):
         if precision not in PRECISIONS:
             raise ValueError(f"unknown precision {precision!r}")
+        corr_precision = _CORR_ALIASES.get(corr_precision, corr_precision)
         if corr_precision not in CORR_PRECISIONS:
             raise ValueError(f"unknown correlation precision {corr_precision!r}")
         cur = torch.cuda.current_device() if torch.cuda.is_available() else 0
         device = torch.device("cuda", cur) if device is None else torch.device(device)
+        if precision == "f16" and not use_slab:
+            raise ValueError("the f16 mode is built on the slab kernels only")
         if device.type != "cuda":
             raise RuntimeError("speinet_amd runs on MI355X only (HIP kernels); there is no CPU path")
         if device.index is None:
@@ -177,9 +189,19 @@ class Ctx:
             f"current device cuda:{torch.cuda.current_device()} != call context {self.device}"
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    @property
+    def lp16(self) -> bool:
+        """A single-product 16-bit mode ("bf16" or "f16")."""
+        return self.precision in ("bf16", "f16")
+
+    @property
+    def fmt(self) -> int:
+        """16-bit operand format of the matrix-pipe kernels (SPEI_BF16 / SPEI_F16)."""
+        return F16 if self.precision == "f16" else BF16
+
     def inter_dtype(self) -> torch.dtype:
         """Storage type of GEMM-only intermediates (x-hat, q, kv, attention output, MLP hidden, ResBlock conv1 output)."""
-        return torch.bfloat16 if (self.precision == "bf16" and self.use_slab and self.bf16_storage) else torch.float32
+        return LP_DTYPE[self.fmt] if (self.lp16 and self.use_slab and self.bf16_storage) else torch.float32
 
     # ---- K15 / K1 / first and last conv ------------------------------------------------------------------------
     def any_nonzero(self, x: torch.Tensor, flag: torch.Tensor) -> None:
@@ -205,13 +227,13 @@ class Ctx:
     def conv5_out(self, f: FMap, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, w32=None,
                   b32: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Last conv, NHWC 32 channels -> three NCHW planes.  w32 / b32 (weights zero-padded to 32 output channels,
-        packed): the "bf16" mode runs the layer on the slab kernel."""
+        packed): the 16-bit modes run the layer on the slab kernel."""
         assert out.shape == (3, f.H, f.W) and out.is_contiguous() and out.dtype == torch.float32
-        if self.precision == "bf16" and self.use_slab and w32 is not None and f.C == 32:
-            _lib.check(_lib.lib().spei_conv5_out_slab_bf16(self._fp(f), f.ld, int(f.bf16), self._tp(w32.fhi), self._tp(b32),
-                                                          self._tp(out), f.H, f.W, self._stream()), "spei_conv5_out_slab_bf16")
+        if self.lp16 and self.use_slab and w32 is not None and f.C == 32:
+            _lib.check(_lib.lib().spei_conv5_out_slab16(self.fmt, self._fp(f), f.ld, f.fmt, self._tp(w32.frag(self.fmt)), self._tp(b32),
+                                                       self._tp(out), f.H, f.W, self._stream()), "spei_conv5_out_slab16")
             return out
-        assert not f.bf16
+        assert not f.lp
         _lib.check(_lib.lib().spei_conv5_out(self._fp(f), f.ld, self._tp(w), self._tp(b), self._tp(out), f.H, f.W, f.C, self._stream()),
                    "spei_conv5_out")
         return out
@@ -232,10 +254,11 @@ class Ctx:
         assert out.H == ho and out.W == wo and out.C == N
         k0, k1 = a0.C, (a1.C if a1 is not None else 0)
         slab = prec != "f32" and self.use_slab and mode == CONV
-        assert slab or (mode == CONV_T and prec == "bf16" and self.use_slab) or not (a0.bf16 or out.bf16), \
-            "bf16 activations are only supported by the slab kernel"
-        assert a1 is None or a1.bf16 == a0.bf16
-        assert residual is None or not residual.bf16
+        assert slab or (mode == CONV_T and self.lp16 and self.use_slab) or not (a0.lp or out.lp), \
+            "16-bit activations are only supported by the slab kernel"
+        assert a1 is None or a1.t.dtype == a0.t.dtype
+        assert residual is None or not residual.lp
+        assert all(f.t.dtype in (torch.float32, LP_DTYPE[self.fmt]) for f in (a0, out)), "16-bit tensors must be in the mode's format"
         if torch.is_tensor(w):
             w = PackedW(w, a0.t.device)
         assert not ln_input or (slab and w.fhi is not None), "ln_input is a feature of the slab kernel"
@@ -251,22 +274,23 @@ class Ctx:
                   ksize, stride, pad, mode, act, self._stream())
         srcs = (fp(a0), a0.ld, k0, fp(a1), a1.ld if a1 is not None else 0, k1)
         lib = _lib.lib()
-        if (mode == CONV_T and prec == "bf16" and self.use_slab and ksize == 3 and stride == 2 and a1 is None and residual is None
+        if (mode == CONV_T and self.lp16 and self.use_slab and ksize == 3 and stride == 2 and a1 is None and residual is None
                 and rowscale is None and N % 32 == 0 and k0 % 32 == 0):
             # stride-2 transposed conv = four stride-1 convs (one per output parity) on the slab kernel
-            cf = w.convT_class_frags()
-            _lib.check(lib.spei_convt2_slab_bf16(fp(a0), a0.ld, k0, int(a0.bf16), tp(cf[(0, 0)]), tp(cf[(0, 1)]), tp(cf[(1, 0)]),
-                                                 tp(cf[(1, 1)]), tp(bias), fp(out), out.ld, int(out.bf16), a0.H, a0.W, N, act,
-                                                 self._stream()), "spei_convt2_slab_bf16")
+            cf = w.convT_class_frags(self.fmt)
+            _lib.check(lib.spei_convt2_slab16(self.fmt, fp(a0), a0.ld, k0, a0.fmt, tp(cf[(0, 0)]), tp(cf[(0, 1)]), tp(cf[(1, 0)]),
+                                              tp(cf[(1, 1)]), tp(bias), fp(out), out.ld, out.fmt, a0.H, a0.W, N, act,
+                                              self._stream()), "spei_convt2_slab16")
         elif prec == "f32":
             _lib.check(lib.spei_igemm_f32(*srcs, tp(w.f32), tp(bias), *common), "spei_igemm_f32")
         elif slab and w.fhi is not None:
             dims = (a0.H * a0.W, 1, ho * wo, 1) if (ksize == 1 and stride == 1) else (a0.H, a0.W, ho, wo)
-            _lib.check(lib.spei_conv_slab_bf16(
-                *srcs, int(a0.bf16), tp(w.fhi), tp(w.flo) if prec == "bf16x3" else _vp(0), tp(bias), fp(out), out.ld,
-                int(out.bf16), fp(residual), residual.ld if residual is not None else 0,
-                tp(rowscale), *dims, N, ksize, stride, pad, act, int(ln_input), self._stream()), "spei_conv_slab_bf16")
+            _lib.check(lib.spei_conv_slab16(
+                self.fmt, *srcs, a0.fmt, tp(w.frag(self.fmt)), tp(w.flo) if prec == "bf16x3" else _vp(0), tp(bias), fp(out), out.ld,
+                out.fmt, fp(residual), residual.ld if residual is not None else 0,
+                tp(rowscale), *dims, N, ksize, stride, pad, act, int(ln_input), self._stream()), "spei_conv_slab16")
         else:
+            assert prec != "f16", "f16: N and K must be multiples of 32 (slab kernel)"
             _lib.check(lib.spei_igemm_bf16(*srcs, tp(w.hi), tp(w.lo) if prec == "bf16x3" else _vp(0), tp(bias), *common),
                        "spei_igemm_bf16")
         return out
@@ -295,7 +319,7 @@ class Ctx:
         g1 = torch.empty(x1.H, x1.C, device=dev)
         g2 = torch.empty(x1.W, x1.C, device=dev)
         ws = torch.empty(lib.spei_gate_ws_floats(x1.H, x1.W, x1.C), device=dev)
-        _lib.check(lib.spei_resblock_gates(self._fp(x1), int(x1.bf16), x1.H, x1.W, x1.C, tp(pk["se_w1"]), tp(pk["se_b1"]), tp(pk["se_w2"]),
+        _lib.check(lib.spei_resblock_gates(self._fp(x1), x1.fmt, x1.H, x1.W, x1.C, tp(pk["se_w1"]), tp(pk["se_b1"]), tp(pk["se_w2"]),
                                            tp(pk["se_b2"]), tp(pk["cw_w"]), tp(pk["cw_bn"]), tp(pk["hc_w"]), tp(pk["hc_bn"]),
                                            tp(s), tp(g1), tp(g2), tp(ws), self._stream()), "spei_resblock_gates")
         return s, g1, g2
@@ -312,30 +336,31 @@ class Ctx:
             out = FMap.empty(x.H, x.W, c, x.t.device)
         if extra is not None:
             assert extra.off == 0 and extra.ld == c
-        _lib.check(_lib.lib().spei_resblock_apply(self._fp(x), self._fp(x1), int(x1.bf16), self._tp(s), self._tp(g1), self._tp(g2),
+        _lib.check(_lib.lib().spei_resblock_apply(self._fp(x), self._fp(x1), x1.fmt, self._tp(s), self._tp(g1), self._tp(g2),
                                                   self._fp(extra), self._fp(out), out.ld, x.H, x.W, c, self._stream()),
                    "spei_resblock_apply")
         return out
 
     # ---- Swin (K6-K9) ------------------------------------------------------------------------------------------
     def ln_fused_available(self) -> bool:
-        """LayerNorm folded into the staging of the following 256-wide linear (slab kernel, any bf16 mode)."""
+        """LayerNorm folded into the staging of the following 256-wide linear (slab kernel, every mode but f32)."""
         return self.precision != "f32" and self.use_slab
 
     def attn_fused_available(self) -> bool:
-        return self.precision == "bf16" and self.use_slab and self.fuse_attn and self.bf16_storage
+        return self.lp16 and self.use_slab and self.fuse_attn and self.bf16_storage
 
     def mlp_fused_available(self) -> bool:
-        return self.precision == "bf16" and self.use_slab and self.fuse_mlp
+        return self.lp16 and self.use_slab and self.fuse_mlp
 
     def attn_fused(self, x: torch.Tensor, yhat: torch.Tensor, bk: dict, H: int, W: int, shift: int, out: torch.Tensor) -> torch.Tensor:
         """out = x + proj(window_attention(...))  (reference model/swinir.py:238-278); in place when out is x."""
         assert x.shape == (H * W, 256) and x.dtype == torch.float32 and out.shape == x.shape and out.dtype == torch.float32
-        assert yhat.shape == x.shape and yhat.dtype == torch.bfloat16
+        f = self.fmt
+        assert yhat.shape == x.shape and yhat.dtype == LP_DTYPE[f]
         tp = self._tp
-        _lib.check(_lib.lib().spei_attn_fused_bf16(tp(x), tp(out), tp(yhat), tp(bk["wq"].fhi), tp(bk["bq"]), tp(bk["wkv"].fhi),
-                                                   tp(bk["bkv"]), tp(bk["wproj"].fhi), tp(bk["bproj"]), tp(bk["relbias"]), H, W, shift,
-                                                   self._stream()), "spei_attn_fused_bf16")
+        _lib.check(_lib.lib().spei_attn_fused16(f, tp(x), tp(out), tp(yhat), tp(bk["wq"].frag(f)), tp(bk["bq"]), tp(bk["wkv"].frag(f)),
+                                                tp(bk["bkv"]), tp(bk["wproj"].frag(f)), tp(bk["bproj"]), tp(bk["relbias"]), H, W, shift,
+                                                self._stream()), "spei_attn_fused16")
         return out
 
     def mlp_fused(self, x: torch.Tensor, w1, b1: torch.Tensor, w2, b2: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
@@ -343,8 +368,9 @@ class Ctx:
         assert x.shape[1] == 256 and x.dtype == torch.float32 and out.shape == x.shape and out.dtype == torch.float32
         assert tuple(w1.shape) == (1, 512, 256) and tuple(w2.shape) == (1, 256, 512)
         tp = self._tp
-        _lib.check(_lib.lib().spei_mlp_fused_bf16(tp(x), tp(out), tp(w1.fhi), tp(b1), tp(w2.fhi), tp(b2), x.shape[0], self._stream()),
-                   "spei_mlp_fused_bf16")
+        f = self.fmt
+        _lib.check(_lib.lib().spei_mlp_fused16(f, tp(x), tp(out), tp(w1.frag(f)), tp(b1), tp(w2.frag(f)), tp(b2), x.shape[0], self._stream()),
+                   "spei_mlp_fused16")
         return out
 
     def layernorm(self, x: torch.Tensor, g: Optional[torch.Tensor] = None, b: Optional[torch.Tensor] = None,
@@ -353,7 +379,7 @@ class Ctx:
         if out is None:
             out = torch.empty(x.shape, device=x.device, dtype=out_dtype)
         tp = self._tp
-        _lib.check(_lib.lib().spei_layernorm256(tp(x), tp(out), int(out.dtype == torch.bfloat16), tp(g), tp(b), x.shape[0], self._stream()),
+        _lib.check(_lib.lib().spei_layernorm256(tp(x), tp(out), fmt_of(out.dtype), tp(g), tp(b), x.shape[0], self._stream()),
                    "spei_layernorm256")
         return out
 
@@ -364,7 +390,7 @@ class Ctx:
             out = torch.empty_like(q)
         assert q.dtype == kv.dtype == out.dtype
         tp = self._tp
-        _lib.check(_lib.lib().spei_window_attention(tp(q), tp(kv), int(q.dtype == torch.bfloat16), tp(relbias), tp(out), H, W, shift,
+        _lib.check(_lib.lib().spei_window_attention(tp(q), tp(kv), fmt_of(q.dtype), tp(relbias), tp(out), H, W, shift,
                                                     self._stream()), "spei_window_attention")
         return out
 
@@ -388,28 +414,32 @@ class Ctx:
                                                 lr.C, tp(s), tp(arg), tp(ws), self._stream()), "spei_corr_argmax")
             return s, arg
         split = self.corr_precision == "bf16x3"
-        rescore = self.corr_precision == "bf16r" and self.use_slab and lr.C == 128
+        rescore = self.corr_precision == "top2" and self.use_slab and lr.C == 128
+        f16 = self.fmt
+        assert f16 == BF16 or (not split and self.use_slab and lr.C == 128), "f16 correlation: slab kernel, single / top2"
         parts = []
         for f in (lr, ref):
-            hi = torch.empty(f.H * f.W, f.C, device=dev, dtype=torch.bfloat16)
+            hi = torch.empty(f.H * f.W, f.C, device=dev, dtype=LP_DTYPE[f16])
             lo = torch.empty_like(hi) if split else None
-            _lib.check(lib.spei_split_bf16(fp(f), f.ld, tp(hi), tp(lo), f.H * f.W, f.C, self._stream()), "spei_split_bf16")
+            _lib.check(lib.spei_split16(f16, fp(f), f.ld, tp(hi), tp(lo), f.H * f.W, f.C, self._stream()), "spei_split16")
             parts += [hi, lo]
         if rescore:
             arg2 = torch.empty(n, device=dev, dtype=torch.int32)
             s2 = torch.empty(n, device=dev)
             with _timed(self, "corr_argmax"):
-                _lib.check(lib.spei_corr_slab_top2_bf16(tp(parts[0]), tp(parts[2]), tp(inv_lr), tp(inv_ref), lr.H, lr.W, ref.H, ref.W,
-                                                        lr.C, tp(s), tp(arg), tp(s2), tp(arg2), tp(ws), self._stream()),
-                           "spei_corr_slab_top2_bf16")
+                _lib.check(lib.spei_corr_slab_top2_16(f16, tp(parts[0]), tp(parts[2]), tp(inv_lr), tp(inv_ref), lr.H, lr.W, ref.H, ref.W,
+                                                      lr.C, tp(s), tp(arg), tp(s2), tp(arg2), tp(ws), self._stream()),
+                           "spei_corr_slab_top2_16")
             _lib.check(lib.spei_corr_rescore(fp(lr), lr.ld, fp(ref), ref.ld, tp(inv_lr), tp(inv_ref), lr.H, lr.W, ref.H, ref.W, lr.C,
                                              tp(s), tp(arg), tp(s2), tp(arg2), self._stream()), "spei_corr_rescore")
             return s, arg
-        fn, name = (lib.spei_corr_slab_bf16, "spei_corr_slab_bf16") if (self.use_slab and lr.C == 128) else \
-            (lib.spei_corr_argmax_bf16, "spei_corr_argmax_bf16")
+        args = (tp(parts[0]), tp(parts[1]), tp(parts[2]), tp(parts[3]), tp(inv_lr), tp(inv_ref),
+                lr.H, lr.W, ref.H, ref.W, lr.C, tp(s), tp(arg), tp(ws), self._stream())
         with _timed(self, "corr_argmax"):
-            _lib.check(fn(tp(parts[0]), tp(parts[1]), tp(parts[2]), tp(parts[3]), tp(inv_lr), tp(inv_ref),
-                          lr.H, lr.W, ref.H, ref.W, lr.C, tp(s), tp(arg), tp(ws), self._stream()), name)
+            if self.use_slab and lr.C == 128:
+                _lib.check(lib.spei_corr_slab16(f16, *args), "spei_corr_slab16")
+            else:
+                _lib.check(lib.spei_corr_argmax_bf16(*args), "spei_corr_argmax_bf16")
         return s, arg
 
     def gather_fold(self, ref: FMap, arg: torch.Tensor, H3: int, W3: int, Hr3: int, Wr3: int, s: int) -> FMap:
@@ -433,9 +463,9 @@ class Ctx:
 
     def up_conv1x1_relu(self, f: FMap, w, b: torch.Tensor, n: int, s: int = 2) -> FMap:
         """relu(conv1x1(bicubic_up(f))) (reference model/speinet.py:96-97,108-109, model/SearchTransfer.py:73-76).  Both maps
-        are linear and the bicubic weights sum to 1, so the "bf16" mode runs the conv first, at 1/s^2 of the pixels and with
+        are linear and the bicubic weights sum to 1, so the 16-bit modes run the conv first, at 1/s^2 of the pixels and with
         half the bytes through the upsampler; the f32-grade modes keep the reference's order of operations."""
-        if self.precision == "bf16" and self.commute_upconv:
+        if self.lp16 and self.commute_upconv:
             return self.upsample(self.igemm(f, w, b, n), s, act=ACT_RELU)
         return self.igemm(self.upsample(f, s), w, b, n, act=ACT_RELU)
 

@@ -27,43 +27,55 @@ class GemmW:
         self.t = t if t.dim() == 3 else t.reshape(1, *t.shape)
 
 
+F32, BF16, F16 = 0, 1, 2          # include/speinet_hip.h SPEI_F32 / SPEI_BF16 / SPEI_F16
+LP_DTYPE = {BF16: torch.bfloat16, F16: torch.float16}
+
+
+def fmt_of(dtype) -> int:
+    return {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}[dtype]
+
+
+def _frag(w: torch.Tensor) -> torch.Tensor:
+    """[tap][N][K] 16-bit -> MFMA fragment order for the slab kernels: [n-tile][tap][k-step of 16][lane = h*32 + n%32][8],
+    element (t, n, k) with k = 16*ks + 8*h + j  ->  one coalesced 1 KiB load per B fragment."""
+    t, n, k = w.shape
+    return w.view(t, n // 32, 32, k // 16, 2, 8).permute(1, 0, 3, 4, 2, 5).contiguous()
+
+
 class PackedW:
-    """Device copies of one GEMM weight: f32 for the exact path, bf16 hi / lo (= bf16(w - hi)) for the bf16 pipe."""
-    __slots__ = ("f32", "hi", "lo", "shape", "fhi", "flo", "_ct")
+    """Device copies of one GEMM weight: f32 for the exact path; bf16 hi / lo (= bf16(w - hi)) plain and in fragment
+    order for the bf16 / bf16x3 modes; half in fragment order for the f16 mode (`frag(fmt)`)."""
+    __slots__ = ("f32", "hi", "lo", "shape", "fhi", "flo", "fh16", "_ct")
 
     def __init__(self, t: torch.Tensor, device):
         self.f32 = t.detach().to(device=device, dtype=torch.float32).contiguous()
         self.hi = self.f32.to(torch.bfloat16)
         self.lo = (self.f32 - self.hi.float()).to(torch.bfloat16)
         self.shape = tuple(self.f32.shape)
-        # MFMA fragment order for conv_slab_bf16.hip: [n-tile][tap][k-step of 16][lane = h*32 + n%32][8], element
-        # (t, n, k) with k = 16*ks + 8*h + j  ->  one coalesced 1 KiB load per B fragment
         t, n, k = self.shape
-        self.fhi = self.flo = None
-        self._ct = None
+        self.fhi = self.flo = self.fh16 = None
+        self._ct = {}
         if n % 32 == 0 and k % 32 == 0:
-            frag = lambda w: w.view(t, n // 32, 32, k // 16, 2, 8).permute(1, 0, 3, 4, 2, 5).contiguous()
-            self.fhi, self.flo = frag(self.hi), frag(self.lo)
+            self.fhi, self.flo = _frag(self.hi), _frag(self.lo)
+            self.fh16 = _frag(self.f32.to(torch.float16))
 
+    def frag(self, fmt: int):
+        return self.fh16 if fmt == F16 else self.fhi
 
-def _convT_class_frags(self) -> dict:
-    """Fragment-ordered weights of the four output-parity classes of a 3x3 stride-2 transposed conv (this pack holds
-    [ky*3+kx][Cout][Cin]): out[2y+py][2x+px] = sum_taps in[y+dy][x+dx] W[ky][kx] with parity 0 -> k = 1 (d = 0), parity
-    1 -> k = 0 (d = 1), k = 2 (d = 0) — the tap order spei_convt2_slab_bf16 assumes."""
-    if self._ct is None:
-        assert self.shape[0] == 9
-        ct = {}
-        for py in (0, 1):
-            for px in (0, 1):
-                kys, kxs = ([0, 2] if py else [1]), ([0, 2] if px else [1])
-                w = torch.stack([self.hi[ky * 3 + kx] for ky in kys for kx in kxs])
-                t, n, k = w.shape
-                ct[(py, px)] = w.view(t, n // 32, 32, k // 16, 2, 8).permute(1, 0, 3, 4, 2, 5).contiguous()
-        self._ct = ct
-    return self._ct
-
-
-PackedW.convT_class_frags = _convT_class_frags
+    def convT_class_frags(self, fmt: int = BF16) -> dict:
+        """Fragment-ordered weights of the four output-parity classes of a 3x3 stride-2 transposed conv (this pack holds
+        [ky*3+kx][Cout][Cin]): out[2y+py][2x+px] = sum_taps in[y+dy][x+dx] W[ky][kx] with parity 0 -> k = 1 (d = 0), parity
+        1 -> k = 0 (d = 1), k = 2 (d = 0) — the tap order spei_convt2_slab16 assumes."""
+        if fmt not in self._ct:
+            assert self.shape[0] == 9
+            src = self.f32.to(LP_DTYPE[fmt])
+            ct = {}
+            for py in (0, 1):
+                for px in (0, 1):
+                    kys, kxs = ([0, 2] if py else [1]), ([0, 2] if px else [1])
+                    ct[(py, px)] = _frag(torch.stack([src[ky * 3 + kx] for ky in kys for kx in kxs]))
+            self._ct[fmt] = ct
+        return self._ct[fmt]
 
 
 def conv_w(w: torch.Tensor) -> torch.Tensor:

@@ -1,9 +1,12 @@
-"""GPU suite, bf16 matrix-pipe modes of the GEMM-shaped kernels.
+"""GPU suite, 16-bit matrix-pipe modes of the GEMM-shaped kernels.
 
   bf16x3  split-bf16 products (3 MFMAs): f32-grade.  Tolerance 2e-5 * max|ref| per kernel; end to end the same
           bounds as the f32 path (1e-3 absolute, PSNR delta <= 1e-3 dB) and bit-exact arg-max on the golden cases.
-  bf16    single bf16 products, fp32 accumulate: per kernel 2^-8-ish relative error of each operand, tolerance
-          1.5e-2 * max|ref|; end to end the tolerance is reported and bounded at 0.05 absolute on an O(1) image / 0.1 dB.
+  f16     single IEEE-half products, fp32 accumulate — the THROUGHPUT configuration (bench.py's default, with the "top2"
+          correlation): per kernel 2^-11-ish relative error of each operand, tolerance 2e-3 * max|ref|; end to end
+          |dPSNR| <= 1e-3 dB against the reference's own outputs (the north-star bound) at every golden size.
+  bf16    single bf16 products: per kernel tolerance 1.5e-2 * max|ref|; end to end 0.05 absolute on an O(1) image and
+          1e-2 dB (measured 3e-3 dB at 720p: 8-bit significands of weights and activations).
 """
 import os
 
@@ -22,7 +25,8 @@ from speinet_amd.speinet import SPEINet, default_args  # noqa: E402
 from speinet_amd.synth import synth_frames       # noqa: E402
 
 DEV = "cuda:0"
-TOL = {"bf16x3": 2e-5, "bf16": 1.5e-2}
+TOL = {"bf16x3": 2e-5, "bf16": 1.5e-2, "f16": 2e-3}
+LPD = {"bf16": torch.bfloat16, "f16": torch.float16}
 
 
 def g(golden_dir, name):
@@ -45,7 +49,7 @@ def relerr(a, b):
     return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16", "f16"])
 @pytest.mark.parametrize("cin,cout,k,stride,h,w", [
     (32, 32, 5, 1, 20, 24), (64, 64, 5, 1, 13, 17), (128, 128, 5, 1, 10, 15), (32, 64, 5, 2, 40, 60),
     (64, 128, 5, 2, 22, 18), (128, 256, 3, 1, 10, 15), (256, 256, 3, 1, 9, 11), (256, 128, 3, 1, 10, 15),
@@ -61,7 +65,7 @@ def test_igemm_conv(mode, cin, cout, k, stride, h, w):
     assert e < TOL[mode], f"{mode}: rel err {e:.2e}"
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16", "f16"])
 def test_igemm_concat_transpose_epilogue(mode):
     ops = Ctx(mode, device=DEV)
     h, w = 14, 22
@@ -95,18 +99,52 @@ def test_search_bf16x3_argmax_exact(golden_dir, name):
     assert relerr(t1.nchw(), d["t1"]) < 1e-6
 
 
-def test_search_bf16_flip_rate():
-    """Single-bf16 scores: the winner may flip between near-tied candidates; measure it on a 20x30 map."""
-    ops = Ctx("bf16", "bf16", device=DEV)
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_search_single_flip_rate(mode):
+    """Single 16-bit scores: the winner may flip between near-tied candidates; measure it on a 20x30 map."""
+    ops = Ctx(mode, "single", device=DEV)
     lr3, rf3 = rnd(32, 1, 128, 20, 30), rnd(33, 1, 128, 20, 30)
     rf2, rf1 = rnd(34, 1, 64, 40, 60), rnd(35, 1, 32, 80, 120)
     s0, _, _, _, arg0 = O.search_transfer(lr3, rf3, rf1, rf2, rf3, return_arg=True)
     s, t3, t2, t1, arg = engine.search_transfer(ops, fm(lr3), fm(rf1), fm(rf2), fm(rf3), return_arg=True)
     flips = (arg.cpu().long() != arg0[0]).float().mean().item()
     serr = (s.cpu() - s0.reshape(-1)).abs().max().item()
-    print(f"bf16 correlation: flip rate {flips:.3%}, max |S err| {serr:.2e}")
-    assert serr < 5e-3            # the weight map S itself stays accurate
-    assert flips < 0.25           # random (structure-free) features are the worst case for near-ties
+    print(f"{mode} correlation: flip rate {flips:.3%}, max |S err| {serr:.2e}")
+    assert serr < (5e-3 if mode == "bf16" else 7e-4)          # the weight map S itself stays accurate
+    assert flips < (0.25 if mode == "bf16" else 0.05)         # random (structure-free) features are the worst case for near-ties
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("name", ["g07_search", "g07_search_tie"])
+def test_search_top2_argmax_exact(golden_dir, name, mode):
+    """16-bit pass keeping two candidates + exact fp64 re-score ("top2"): the reference's arg-max bit for bit on the golden
+    cases incl. the crafted exact-tie one (many bit-identical reference patches: the lowest index must win), and S to fp32
+    round-off — the winner no longer depends on 16-bit rounding."""
+    ops = Ctx(mode, "top2", device=DEV)
+    d = g(golden_dir, name)
+    s, t3, t2, t1, arg = engine.search_transfer(ops, fm(d["lr3"]), fm(d["rf1"]), fm(d["rf2"]), fm(d["rf3"]), return_arg=True)
+    assert torch.equal(arg.cpu().long(), d["arg"][0])
+    assert relerr(s.view(1, 1, 10, 15), d["s"]) < 2e-6
+    assert relerr(t1.nchw(), d["t1"]) < 1e-6
+
+
+def test_search_top2_ragged_vs_oracle():
+    """top-2 + re-score on a ragged map (partial query tiles, partial reference blocks, out-of-map rows in the edge blocks)
+    with a reference map of another size than the query map: arg-max equal to the oracle's except on fp32 near-ties."""
+    lr3, rf3 = rnd(61, 1, 128, 37, 45), rnd(62, 1, 128, 29, 51)
+    rf2, rf1 = rnd(63, 1, 64, 58, 102), rnd(64, 1, 32, 116, 204)
+    lu = F.normalize(F.unfold(lr3, (3, 3), padding=1), dim=1)
+    ru = F.normalize(F.unfold(rf3, (3, 3), padding=1).permute(0, 2, 1), dim=2)
+    r = torch.bmm(ru.double(), lu.double())[0]                       # [Nr, Nl]
+    top = torch.topk(r, 2, dim=0)
+    for mode in ("bf16", "f16"):
+        ops = Ctx(mode, "top2", device=DEV)
+        inv_l, inv_r = ops.patch_invnorm(fm(lr3)), ops.patch_invnorm(fm(rf3))
+        s, arg = ops.corr_argmax(fm(lr3), fm(rf3), inv_l, inv_r)
+        diff = arg.cpu().long() != top.indices[0]
+        margin = (top.values[0] - top.values[1])[diff]
+        assert diff.sum().item() <= 2 and (margin < 1e-6).all(), (mode, diff.sum().item(), margin)
+        assert (s.cpu().double() - top.values[0]).abs().max().item() < 1e-6
 
 
 @pytest.fixture(scope="module")
@@ -134,28 +172,31 @@ def test_forward_bf16x3_golden(golden_dir, net, name, b, h, w):
         assert dp <= 1e-3, f"PSNR delta {dp:.2e} dB"
 
 
-@pytest.mark.parametrize("name,b,h,w", [("g10_fwd_100x100", 1, 100, 100), ("g10_fwd_200x200", 1, 200, 200),
-                                        ("g10_fwd_200x200_noref", 1, 200, 200)])
-def test_forward_bf16_golden(golden_dir, net, name, b, h, w):
+@pytest.mark.parametrize("mode,corr,tol_err,tol_db", [("f16", "top2", 1e-3, 1e-3), ("bf16", "top2", 0.05, 1e-2)])
+@pytest.mark.parametrize("name,b,h,w", [("g10_fwd_40x60_mixed", 2, 40, 60), ("g10_fwd_100x100", 1, 100, 100),
+                                        ("g10_fwd_200x200", 1, 200, 200), ("g10_fwd_200x200_noref", 1, 200, 200)])
+def test_forward_16bit_golden(golden_dir, net, name, b, h, w, mode, corr, tol_err, tol_db):
+    """The single-product 16-bit modes against the reference's own outputs.  f16 / top2 is what bench.py times: it must hold
+    the north-star bound (|dPSNR| <= 1e-3 dB) and the 1e-3 absolute bound of the f32-grade modes; bf16 its documented one."""
     d = g(golden_dir, name)
     zr = tuple(int(i) for i in d["zero_ref"]) if "zero_ref" in d else ()
     x = synth_frames(b, h, w, seed=int(d["seed"]), zero_ref=zr)
-    net.precision, net.corr_precision = "bf16", "bf16x3"
+    net.precision, net.corr_precision = mode, corr
     with torch.no_grad():
         out = net(x.to(DEV)).cpu()
-    net.precision = "f32"
+    net.precision, net.corr_precision = "f32", "bf16x3"
     err = (out - d["out"]).abs().max().item()
     rms = (out - d["out"]).pow(2).mean().sqrt().item()
-    tgt = O.to_uint8(x[:1, 1])
-    dp = abs(O.psnr_uint8(O.to_uint8(out), tgt) - O.psnr_uint8(O.to_uint8(d["out"]), tgt))
-    psnr_vs_ref = O.psnr_uint8(O.to_uint8(out), O.to_uint8(d["out"]))
-    print(f"{name} bf16: max abs err {err:.3e}, rms {rms:.3e}, PSNR(out, ref out) {psnr_vs_ref:.1f} dB, |dPSNR vs target| {dp:.2e} dB")
-    assert err < 0.05 and dp < 0.1
+    dp = max(abs(O.psnr_uint8(O.to_uint8(out[i:i + 1]), O.to_uint8(x[i:i + 1, 1])) -
+                 O.psnr_uint8(O.to_uint8(d["out"][i:i + 1]), O.to_uint8(x[i:i + 1, 1]))) for i in range(b))
+    print(f"{name} {mode}/{corr}: max abs err {err:.3e}, rms {rms:.3e}, |dPSNR vs target| {dp:.2e} dB")
+    assert err < tol_err and dp <= tol_db
 
 
-def test_mlp_fused_vs_oracle(synth_sd):
-    """Fused LN -> fc1 -> GELU -> fc2 -> +x kernel against the fp32 formula (bf16 products: 1.5e-2 of max|ref|)."""
-    ops = Ctx("bf16", device=DEV)
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_mlp_fused_vs_oracle(synth_sd, mode):
+    """Fused LN -> fc1 -> GELU -> fc2 -> +x kernel against the fp32 formula (tolerance of the mode, relative to the branch)."""
+    ops = Ctx(mode, device=DEV)
     p = "swin.layers.1.residual_group.blocks.2."
     bk = pack.swin_block(synth_sd, p, 8, 5)
     w1, w2 = pack.PackedW(bk["w1"].t, DEV), pack.PackedW(bk["w2"].t, DEV)
@@ -167,17 +208,18 @@ def test_mlp_fused_vs_oracle(synth_sd):
         xd = x.to(DEV)
         out = ops.mlp_fused(xd, w1, bk["b1"].to(DEV), w2, bk["b2"].to(DEV), out=torch.empty_like(xd))
         e = ((out.cpu() - ref).abs().max() / (ref - x).abs().max()).item()      # relative to the MLP branch itself
-        assert e < 1.5e-2, f"M={m}: rel err {e:.2e}"
+        assert e < TOL[mode], f"M={m}: rel err {e:.2e}"
         inplace = ops.mlp_fused(xd, w1, bk["b1"].to(DEV), w2, bk["b2"].to(DEV), out=xd)
         assert torch.equal(inplace, out)
 
 
 @pytest.mark.parametrize("h,w,shift", [(5, 5, 0), (5, 5, 2), (10, 15, 0), (10, 15, 2), (15, 25, 2), (20, 35, 0), (20, 35, 2),
                                        (180, 320, 2)])       # last: the 720p token map (2304 windows), oracle on the CPU
-def test_attn_fused_vs_oracle(synth_sd, h, w, shift):
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_attn_fused_vs_oracle(synth_sd, h, w, shift, mode):
     """Fused LN -> q/kv -> shifted-window attention -> proj -> +x kernel against the oracle's attention branch
     (model/swinir.py:238-278); odd window counts leave the second window slot of the last workgroup empty."""
-    ops = Ctx("bf16", device=DEV)
+    ops = Ctx(mode, device=DEV)
     p = "swin.layers.2.residual_group.blocks.1."
     bk = {k: (v.to(DEV) if torch.is_tensor(v) else pack.PackedW(v.t, DEV)) for k, v in pack.swin_block(synth_sd, p, 8, 5).items()}
     m = h * w
@@ -194,10 +236,10 @@ def test_attn_fused_vs_oracle(synth_sd, h, w, shift):
         branch = torch.roll(branch, shifts=(shift, shift), dims=(1, 2))
     branch = branch.reshape(m, 256)
     xd = x[0].to(DEV).contiguous()
-    yhat = ops.layernorm(y[0].to(DEV).contiguous(), out_dtype=torch.bfloat16)
+    yhat = ops.layernorm(y[0].to(DEV).contiguous(), out_dtype=LPD[mode])
     out = ops.attn_fused(xd, yhat, bk, h, w, shift, out=torch.empty_like(xd))
     e = ((out.cpu() - x[0] - branch).abs().max() / branch.abs().max()).item()
-    assert torch.isfinite(out).all() and e < 1.5e-2, f"{h}x{w} shift {shift}: rel err {e:.2e}"
+    assert torch.isfinite(out).all() and e < TOL[mode], f"{h}x{w} shift {shift}: rel err {e:.2e}"
     inplace = ops.attn_fused(xd, yhat, bk, h, w, shift, out=xd)
     assert torch.equal(inplace, out)
 
@@ -228,12 +270,12 @@ def test_streams_bit_identical(net, mode, graph):
 def test_forward_large_sizes_modes_agree(net, h, w, b, zero_ref):
     """480x640 (the BSD frame size, BASELINE.json configs[3]; 768 windows, lv3 map 120x160 -> partial tiles in every tiled
     kernel, both routing branches) and 720x1280 (the bench configuration): no oracle run at these sizes, so the three
-    arithmetic modes are checked against each other.  bf16x3 must stay within the f32-grade bound of the f32 path, bf16
-    (with the bench's bf16 correlation at 720p) within its documented bound."""
+    arithmetic modes are checked against each other.  bf16x3 and f16 / top2 (the bench configuration) must stay within
+    the f32-grade bound of the f32 path, bf16 within its documented bound."""
     x = synth_frames(b, h, w, seed=4242, zero_ref=zero_ref).to(DEV)
     outs = {}
     try:
-        for mode, corr in (("f32", "bf16x3"), ("bf16x3", "bf16x3"), ("bf16", "bf16" if h == 720 else "bf16x3")):
+        for mode, corr in (("f32", "bf16x3"), ("bf16x3", "bf16x3"), ("f16", "top2"), ("bf16", "single" if h == 720 else "bf16x3")):
             net.precision, net.corr_precision = mode, corr
             with torch.no_grad():
                 outs[mode] = net(x).cpu()
@@ -242,13 +284,16 @@ def test_forward_large_sizes_modes_agree(net, h, w, b, zero_ref):
     assert all(torch.isfinite(o).all() for o in outs.values())
     e3 = (outs["bf16x3"] - outs["f32"]).abs().max().item()
     e1 = (outs["bf16"] - outs["f32"]).abs().max().item()
-    print(f"{h}x{w}: max |bf16x3 - f32| {e3:.2e}, max |bf16 - f32| {e1:.2e}")
+    eh = (outs["f16"] - outs["f32"]).abs().max().item()
+    print(f"{h}x{w}: max |bf16x3 - f32| {e3:.2e}, max |f16 - f32| {eh:.2e}, max |bf16 - f32| {e1:.2e}")
     assert e3 < (1e-3 if h < 720 else 2e-3) and e1 < 0.05      # 720p: the max is over 2.8 M values (9.3e-4 measured)
+    assert eh < 2e-3
 
 
-def test_conv5_out_slab():
-    """Last conv (32 -> 3 channels, NCHW planes out) on the slab kernel in "bf16" mode; odd sizes -> partial tiles."""
-    ops = Ctx("bf16", device=DEV)
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_conv5_out_slab(mode):
+    """Last conv (32 -> 3 channels, NCHW planes out) on the slab kernel in the 16-bit modes; odd sizes -> partial tiles."""
+    ops = Ctx(mode, device=DEV)
     f = rnd(21, 1, 32, 27, 45)
     wo, bo = rnd(22, 3, 32, 5, 5, scale=0.05), rnd(23, 3, scale=0.1)
     w = pack.conv_w(wo)
@@ -256,7 +301,7 @@ def test_conv5_out_slab():
     b32 = torch.cat((bo, torch.zeros(29))).to(DEV)
     o = torch.full((3, 27, 45), float("nan"), device=DEV)
     ops.conv5_out(fm(f), w.to(DEV), bo.to(DEV), o, w32, b32)
-    assert relerr(o, F.conv2d(f, wo, bo, padding=2)[0]) < TOL["bf16"]
+    assert relerr(o, F.conv2d(f, wo, bo, padding=2)[0]) < TOL[mode]
 
 
 def test_up_conv1x1_relu_commuted():
@@ -265,13 +310,14 @@ def test_up_conv1x1_relu_commuted():
     x = rnd(31, 1, 128, 9, 13)
     wt, b = rnd(32, 64, 128, 1, 1, scale=0.08), rnd(33, 64, scale=0.2)
     ref = F.relu(F.conv2d(F.interpolate(x, scale_factor=2, mode="bicubic"), wt, b))
-    for mode in ("bf16x3", "bf16"):
+    for mode in ("bf16x3", "bf16", "f16"):
         ops = Ctx(mode, device=DEV)
         out = ops.up_conv1x1_relu(fm(x), pack.conv_w(wt).to(DEV), b.to(DEV), 64)
         assert relerr(out.nchw(), ref) < TOL[mode], mode
 
 
-@pytest.mark.parametrize("mode,corr", [("f32", "bf16x3"), ("bf16", "bf16x3"), ("bf16", "bf16")])
+@pytest.mark.parametrize("mode,corr", [("f32", "bf16x3"), ("bf16", "bf16x3"), ("bf16", "single"), ("bf16", "top2"), ("f16", "single"),
+                                       ("f16", "top2")])
 def test_full_size_search_properties(mode, corr):
     """Size-independent properties at the 720p map size (180 x 320 positions, 128 channels; no oracle run at this size):
     a map correlated with itself finds every position at itself with a normalised score of 1, a shifted copy is found at the
@@ -284,7 +330,7 @@ def test_full_size_search_properties(mode, corr):
     s, arg = ops.corr_argmax(f, f, inv, inv)
     ident = torch.arange(h * w, device=DEV, dtype=torch.int32)
     assert torch.equal(arg, ident)
-    assert (s - 1).abs().max().item() < (1e-5 if mode == "f32" else 2e-2 if corr == "bf16" else 1e-4)
+    assert (s - 1).abs().max().item() < (1e-5 if mode == "f32" or corr == "top2" else 1e-4 if corr == "bf16x3" else 2e-2 if mode == "bf16" else 3e-3)
     # query = reference shifted by (3, 5) pixels: interior positions (whose whole 3x3 patch moved along) point back by the shift
     g = FMap(torch.roll(f.t.view(h, w, 128), shifts=(3, 5), dims=(0, 1)).reshape(h * w, 128).contiguous(), h, w, 128)
     _, arg2 = ops.corr_argmax(g, f, ops.patch_invnorm(g), inv)
@@ -297,14 +343,15 @@ def test_full_size_search_properties(mode, corr):
         assert (a - b).abs().max().item() < 1e-5
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "f16"])
 def test_full_size_conv_identity(mode):
     """Identity kernels at the 720p layer sizes (no oracle run at these sizes): a centre-tap identity convolution must return
     its input exactly (bf16-rounded in "bf16" mode: x * 1 + zeros is exact) at every pixel incl. the map border and every
     partial tile; stride 2 returns the even pixels; the transposed conv writes the input to the even output pixels."""
+    # (16-bit modes: x * 1 + zeros is exact, so the output is the input rounded to the mode's format)
     ops = Ctx(mode, device=DEV)
     gen = torch.Generator().manual_seed(9)
-    rnd_in = lambda x: x.bfloat16().float() if mode == "bf16" else x
+    rnd_in = lambda x: x.to(LPD[mode]).float() if mode in LPD else x
     for c, h, w, ks in ((32, 720, 1280, 5), (64, 360, 640, 5), (128, 180, 320, 5), (256, 180, 320, 3)):
         x = torch.randn(h * w, c, generator=gen).to(DEV)
         wt = torch.zeros(ks * ks, c, c)
@@ -328,17 +375,18 @@ def test_full_size_conv_identity(mode):
         assert o[1::2].abs().max().item() == 0 and o[:, 1::2].abs().max().item() == 0
 
 
-def test_full_size_swin_properties(synth_sd):
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_full_size_swin_properties(synth_sd, mode):
     """Size-independent properties of the fused Swin kernels at the 720p token count (180 x 320 = 57600 tokens, 2304
     windows): (i) MLP with fc2 = 0 returns x exactly; (ii) attention with proj = 0 returns x exactly; (iii) with V = a
     constant vector c (zero V weights, bias c) and proj = identity, softmax rows summing to 1 give x + c for every token
-    of every (shifted, masked) window, up to the bf16 rounding of the probabilities."""
-    ops = Ctx("bf16", device=DEV)
+    of every (shifted, masked) window, up to the 16-bit rounding of the probabilities."""
+    ops = Ctx(mode, device=DEV)
     h, w = 180, 320
     m = h * w
     gen = torch.Generator().manual_seed(13)
     x = (torch.randn(m, 256, generator=gen) * 1.2 + 0.3).to(DEV)
-    yhat = ops.layernorm(torch.randn(m, 256, generator=gen).to(DEV), out_dtype=torch.bfloat16)
+    yhat = ops.layernorm(torch.randn(m, 256, generator=gen).to(DEV), out_dtype=LPD[mode])
     p = "swin.layers.3.residual_group.blocks.1."
     raw = pack.swin_block(synth_sd, p, 8, 5)
     bk = {k: (v.to(DEV) if torch.is_tensor(v) else pack.PackedW(v.t, DEV)) for k, v in raw.items()}
@@ -359,32 +407,101 @@ def test_full_size_swin_properties(synth_sd):
                   bproj=torch.zeros(256, device=DEV))
         out = ops.attn_fused(x, yhat, b1, h, w, shift, out=torch.empty_like(x))
         err = (out - x - c.to(DEV)).abs().max().item()
-        assert err < 2e-2, (shift, err)
+        assert err < (2e-2 if mode == "bf16" else 3e-3), (shift, err)
 
 
-@pytest.mark.parametrize("name,b,h,w", [("g14_fwd_720p", 1, 720, 1280), ("g15_fwd_720p_noref", 1, 720, 1280),
-                                        ("g16_fwd_480x640_mixed", 2, 480, 640)])
-def test_forward_full_size_reference_golden(golden_dir, net, name, b, h, w):
-    """The full sizes against the REFERENCE's own outputs (tests/golden/make_golden_720p.py: every 8th pixel of its frames +
-    per-channel statistics): the bench configuration (720p, `_forwardbs`), the same through `_forwardb`, and a mixed-routing
-    batch at the BSD size.  The f32-grade modes stay within the 1e-3 bound of the small golden cases (exact fp32 and
-    bf16x3), the throughput mode within its documented bound."""
+def _golden_case(golden_dir, name):
+    from speinet_amd.synth import synth_frames_edges
     d = np.load(os.path.join(golden_dir, name + ".npz"))
+    b, h, w = d["sub"].shape[0], d["sub"].shape[2] * 8, d["sub"].shape[3] * 8
+    zr = tuple(int(i) for i in d["zero_ref"])
+    if str(d["kind"]) == "edges":
+        x, gt = synth_frames_edges(b, h, w, seed=int(d["seed"]), zero_ref=zr)
+    else:
+        x = synth_frames(b, h, w, seed=int(d["seed"]), zero_ref=zr)
+        gt = x[:, 1]
+    return d, x, gt
+
+
+@pytest.mark.parametrize("name", ["g14_fwd_720p", "g15_fwd_720p_noref", "g16_fwd_480x640_mixed", "g17_fwd_720p_edges"])
+def test_forward_full_size_reference_golden(golden_dir, net, name):
+    """The full sizes against the REFERENCE's own outputs (tests/golden/make_golden_720p.py: every 8th pixel of its frames,
+    per-channel statistics, its PSNR, and what its SearchTransfer decided: arg-max, S, top-2 margin): the bench configuration
+    (720p, `_forwardbs`), the same through `_forwardb`, a mixed-routing batch at the BSD size and an edge-dominated 720p window.
+    Every mode that claims PSNR parity — exact fp32, bf16x3 and f16 / top2, the configuration bench.py times — must hold the
+    north-star bound |dPSNR| <= 1e-3 dB and 1e-3 absolute on the grid; bf16 its documented bound.
+    Arg-max: positions that differ from the reference's own arg-max are counted; for the f32-grade modes every one of them
+    must be a reference near-tie (top-2 margin < 1e-5 in the reference's own fp32 scores: another summation order decides)."""
+    d, x, gt = _golden_case(golden_dir, name)
+    b = x.shape[0]
     sub, mean, std = (torch.from_numpy(d[k]) for k in ("sub", "mean", "std"))
-    x = synth_frames(b, h, w, seed=int(d["seed"]), zero_ref=tuple(int(i) for i in d["zero_ref"])).to(DEV)
+    ref_arg = torch.from_numpy(d["arg"]).long() if "arg" in d.files else None
+    xd = x.to(DEV)
     try:
-        for mode, corr, tol in (("f32", "bf16x3", 1e-3), ("bf16x3", "bf16x3", 1e-3), ("bf16", "bf16", 0.05)):
+        for mode, corr, tol, tol_db in (("f32", "bf16x3", 1e-3, 1e-3), ("bf16x3", "bf16x3", 1e-3, 1e-3), ("f16", "top2", 1e-3, 1e-3),
+                                        ("bf16", "top2", 0.05, 1e-2)):
             net.precision, net.corr_precision = mode, corr
+            outs, flips, hard, serr, si = [], 0, 0, 0.0, 0
             with torch.no_grad():
-                out = net(x).cpu()
+                for i in range(b):
+                    cap = {}
+                    outs.append(net(xd[i:i + 1], capture=cap).cpu())
+                    if "arg" in cap and ref_arg is not None:
+                        diff = cap["arg"].cpu().long() != ref_arg[si]
+                        flips += int(diff.sum())
+                        hard += int((diff & (torch.from_numpy(d["margin"][si]) >= 1e-5)).sum())
+                        serr = max(serr, (cap["s"].cpu() - torch.from_numpy(d["s"][si])).abs().max().item())
+                        si += 1
+                    elif "s_self" in cap:
+                        serr = max(serr, (cap["s_self"].cpu() - torch.from_numpy(d["s_self"][0])).abs().max().item())
+            out = torch.cat(outs)
             err = (out[:, :, ::8, ::8] - sub).abs().max().item()
             dm = (out.mean(dim=(2, 3)) - mean).abs().max().item()
             ds = (out.std(dim=(2, 3)) - std).abs().max().item()
-            # the north-star criterion: PSNR (uint8, 4-pixel crop, against the middle input frame as the stand-in target) of
-            # our frame minus PSNR of the reference's frame: 1e-3 dB for the f32-grade modes
-            dp = max(abs(O.psnr_uint8(O.to_uint8(out[i:i + 1]), O.to_uint8(x[i:i + 1, 1].cpu())) - float(d["psnr"][i])) for i in range(b))
+            dp = max(abs(O.psnr_uint8(O.to_uint8(out[i:i + 1]), O.to_uint8(gt[i:i + 1])) - float(d["psnr"][i])) for i in range(b))
             print(f"{name} vs reference, {mode}/{corr}: max |err| on the 8x8 grid {err:.2e}, |d mean| {dm:.1e}, |d std| {ds:.1e}, "
-                  f"|dPSNR| {dp:.1e} dB")
-            assert err < tol and dm < tol / 10 and ds < tol / 10 and dp <= (1e-3 if mode != "bf16" else 0.1), mode
+                  f"|dPSNR| {dp:.1e} dB, arg-max flips {flips} (not reference near-ties: {hard}), max |dS| {serr:.1e}")
+            assert err < tol and dm < tol / 10 and ds < tol / 10 and dp <= tol_db, mode
+            if mode in ("f32", "bf16x3"):
+                assert hard == 0 and flips <= 40 and serr < 1e-5, (mode, flips, hard, serr)
     finally:
         net.precision, net.corr_precision = "f32", "bf16x3"
+
+
+def test_two_models_two_threads_bit_identical(synth_sd):
+    """SURVEY.md §8b threading row (the reference's nn.DataParallel calls forward from one Python thread per replica,
+    model/__init__.py:19-20): two SPEINet instances with DIFFERENT arithmetic modes driven from two threads at once give
+    the bits they give when run one after the other — the mode lives in the per-call context, not in the process."""
+    import threading
+    nets = []
+    for mode, corr in (("f32", "bf16x3"), ("f16", "top2")):
+        n = SPEINet(args=default_args())
+        n.load_state_dict(synth_sd, strict=True)
+        n = n.to(DEV).eval()
+        n.precision, n.corr_precision = mode, corr
+        nets.append(n)
+    x = synth_frames(2, 60, 80, seed=91, zero_ref=(1,)).to(DEV)
+    with torch.no_grad():
+        serial = [n(x).clone() for n in nets]
+    torch.cuda.synchronize()
+    results, errors = [None, None], []
+
+    def work(i):
+        try:
+            with torch.no_grad(), torch.cuda.stream(torch.cuda.Stream(device=DEV)):
+                outs = [nets[i](x).clone() for _ in range(6)]
+            torch.cuda.synchronize()
+            results[i] = outs
+        except Exception as e:           # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for i in range(2):
+        for o in results[i]:
+            assert torch.equal(o, serial[i]), f"model {i} differs when run concurrently"
+    assert not torch.equal(serial[0], serial[1])          # the two modes really are different arithmetic

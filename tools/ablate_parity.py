@@ -25,22 +25,28 @@ from speinet_amd.synth import state_dict_template, synth_frames, synth_frames_ed
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 BF = {"precision": "bf16"}
+HF = {"precision": "f16"}
 CONFIGS = [
     ("f32", "f32", "bf16x3", {}),
     ("bf16x3 / corr bf16x3", "bf16x3", "bf16x3", {}),
-    ("bf16x3 / corr bf16r", "bf16x3", "bf16r", {}),
-    ("bf16x3 / corr bf16", "bf16x3", "bf16", {}),
+    ("bf16x3 / corr top2(bf16)", "bf16x3", "top2", {}),
+    ("bf16x3 / corr single(bf16)", "bf16x3", "single", {}),
     ("only enc bf16", "bf16x3", "bf16x3", {"stage": {"enc": BF}}),
     ("only swin bf16", "bf16x3", "bf16x3", {"stage": {"swin": BF}}),
     ("only decode bf16", "bf16x3", "bf16x3", {"stage": {"decode": BF}}),
-    ("bf16 / corr bf16x3", "bf16", "bf16x3", {}),
-    ("bf16 / corr bf16r", "bf16", "bf16r", {}),
-    ("bf16 / corr bf16  (round-1 bench mode)", "bf16", "bf16", {}),
-    ("bf16r, x1 fp32", "bf16", "bf16r", {"x1_bf16": False}),
-    ("bf16r, fp32 storage", "bf16", "bf16r", {"bf16_storage": False}),
-    ("bf16r, unfused MLP (erf GELU)", "bf16", "bf16r", {"fuse_mlp": False}),
-    ("bf16r, unfused attention", "bf16", "bf16r", {"fuse_attn": False}),
-    ("bf16r, conv after upsample", "bf16", "bf16r", {"commute_upconv": False}),
+    ("only enc f16", "bf16x3", "bf16x3", {"stage": {"enc": HF}}),
+    ("only swin f16", "bf16x3", "bf16x3", {"stage": {"swin": HF}}),
+    ("only decode f16", "bf16x3", "bf16x3", {"stage": {"decode": HF}}),
+    ("bf16 / corr top2", "bf16", "top2", {}),
+    ("bf16 / corr single  (round-1 bench mode)", "bf16", "single", {}),
+    ("f16 / corr bf16x3", "f16", "bf16x3", {"stage": {"search": {"precision": "bf16x3"}}}),
+    ("f16 / corr top2  (bench mode)", "f16", "top2", {}),
+    ("f16 / corr single", "f16", "single", {}),
+    ("f16 top2, x1 fp32", "f16", "top2", {"x1_bf16": False}),
+    ("f16 top2, fp32 storage", "f16", "top2", {"bf16_storage": False}),
+    ("f16 top2, unfused MLP (erf GELU)", "f16", "top2", {"fuse_mlp": False}),
+    ("f16 top2, unfused attention", "f16", "top2", {"fuse_attn": False}),
+    ("f16 top2, conv after upsample", "f16", "top2", {"commute_upconv": False}),
 ]
 
 
