@@ -157,8 +157,9 @@ def decode(ctx: Ctx, ff: FMap, s: torch.Tensor, t3: FMap, t2: FMap, t1: FMap, P:
     ctx.igemm(s13, *c("search33"), 32, ksize=3, a1=s33, act=ACT_RELU, residual=acc, out=acc)
     ctx.igemm(s23, *c("search33"), 32, ksize=3, a1=s33, act=ACT_RELU, residual=acc, out=acc)
     ob = P["outBlock"]
+    ctx = ctx.for_stage("out")
     f = _resblocks(ctx, acc, ob["blocks"])
-    return ctx.conv5_out(f, ob["tail_w"], ob["tail_b"], out, ob.get("tail_w32"), ob.get("tail_b32"))
+    return ctx.for_stage("tail").conv5_out(f, ob["tail_w"], ob["tail_b"], out, ob.get("tail_w32"), ob.get("tail_b32"))
 
 
 # ---- one sample --------------------------------------------------------------------------------------------

@@ -118,7 +118,8 @@ class Ctx:
       fuse_mlp        16-bit: LayerNorm -> fc1 -> GELU -> fc2 -> +x in one kernel (mlp_fused16.hip)
       fuse_attn       16-bit: LayerNorm -> q/kv GEMMs -> window attention -> proj -> +x in one kernel (attn_fused16.hip)
       commute_upconv  16-bit: relu(conv1x1(bicubic_up(x))) evaluated as relu(bicubic_up(conv1x1(x)))
-    stage        {stage name: {field: value}} overrides applied by `for_stage` (engine: "enc", "swin", "search", "decode")
+    stage        {stage name: {field: value}} overrides applied by `for_stage` (engine: "enc", "swin", "search", "decode", and inside
+                 "decode" the last stack "out" and its final conv "tail")
     profile      None, or {op name: [(start_event, end_event), ...]} filled on the launch stream (bench.py)
     capture      None, or a dict that receives intermediate device tensors by name ("arg", "s": what SearchTransfer
                  decided) for the parity tests; eager launches only
@@ -233,7 +234,8 @@ class Ctx:
             _lib.check(_lib.lib().spei_conv5_out_slab16(self.fmt, self._fp(f), f.ld, f.fmt, self._tp(w32.frag(self.fmt)), self._tp(b32),
                                                        self._tp(out), f.H, f.W, self._stream()), "spei_conv5_out_slab16")
             return out
-        assert not f.lp
+        if f.lp:                                   # the fp32 kernel reads fp32 maps (only reached through a stage override)
+            f = FMap(f.t.float(), f.H, f.W, f.C, f.off)
         _lib.check(_lib.lib().spei_conv5_out(self._fp(f), f.ld, self._tp(w), self._tp(b), self._tp(out), f.H, f.W, f.C, self._stream()),
                    "spei_conv5_out")
         return out

@@ -47,12 +47,26 @@ CONFIGS = [
     ("f16 top2, unfused MLP (erf GELU)", "f16", "top2", {"fuse_mlp": False}),
     ("f16 top2, unfused attention", "f16", "top2", {"fuse_attn": False}),
     ("f16 top2, conv after upsample", "f16", "top2", {"commute_upconv": False}),
+    ("f16, search stage bf16x3", "f16", "top2", {"stage": {"search": {"precision": "bf16x3", "corr_precision": "bf16x3"}}}),
+    ("f16, decode stage bf16x3", "f16", "top2", {"stage": {"decode": {"precision": "bf16x3"}}}),
+    ("f16, swin stage bf16x3", "f16", "top2", {"stage": {"swin": {"precision": "bf16x3"}}}),
+    ("f16, enc stage bf16x3", "f16", "top2", {"stage": {"enc": {"precision": "bf16x3"}}}),
+    ("f16, outBlock + tail bf16x3", "f16", "top2", {"stage": {"out": {"precision": "bf16x3"}}}),
+    ("f16, tail conv f32", "f16", "top2", {"stage": {"tail": {"precision": "f32"}}}),
 ]
 
 
 def load_case(name):
-    d = np.load(os.path.join(GOLDEN, name + ".npz"))
-    kind = str(d["kind"]) if "kind" in d.files else "smooth"
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    kind = str(d["kind"]) if "kind" in d else "smooth"
+    if "sub" not in d:                        # the small cases (g10_*) keep the reference's whole output
+        out = torch.from_numpy(d["out"])
+        b, _, h, w = out.shape
+        zr = tuple(int(i) for i in d["zero_ref"]) if "zero_ref" in d else ()
+        x = synth_frames(b, h, w, seed=int(d["seed"]), zero_ref=zr)
+        d["sub"] = d["out"][:, :, ::8, ::8]
+        d["psnr"] = np.array([O.psnr_uint8(O.to_uint8(out[i:i + 1]), O.to_uint8(x[i:i + 1, 1])) for i in range(b)])
+        return d, x, x[:, 1], zr
     b = d["sub"].shape[0]
     h, w = d["sub"].shape[2] * 8, d["sub"].shape[3] * 8
     zr = tuple(int(i) for i in d["zero_ref"])
@@ -80,9 +94,9 @@ def main():
         d, x, gt, zr = load_case(case)
         xd = x.to(dev)
         sub = torch.from_numpy(d["sub"])
-        ref_arg = torch.from_numpy(d["arg"]).long() if "arg" in d.files else None
-        margin = torch.from_numpy(d["margin"]) if "margin" in d.files else None
-        ref_s = torch.from_numpy(d["s"]) if "s" in d.files else None
+        ref_arg = torch.from_numpy(d["arg"]).long() if "arg" in d else None
+        margin = torch.from_numpy(d["margin"]) if "margin" in d else None
+        ref_s = torch.from_numpy(d["s"]) if "s" in d else None
         for label, prec, corr, knobs in CONFIGS:
             if want and not any(wd in label for wd in want):
                 continue
@@ -93,6 +107,8 @@ def main():
                 for i in range(x.shape[0]):                       # one sample at a time: capture is per SearchTransfer call
                     cap = {}
                     outs.append(net(xd[i:i + 1], capture=cap).cpu())
+                    if "s_self" in cap and "s_self" in d:
+                        serr = max(serr, (cap["s_self"].cpu() - torch.from_numpy(d["s_self"][0])).abs().max().item())
                     if "arg" in cap and ref_arg is not None:
                         a = cap["arg"].cpu().long()
                         diff = a != ref_arg[si]
