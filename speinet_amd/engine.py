@@ -105,11 +105,17 @@ def swin(ctx: Ctx, sx: SwinX, feat: FMap, sw: dict, out: FMap) -> FMap:
 
 
 # ---- SearchTransfer / SelfTransfer (reference model/SearchTransfer.py) ---------------------------------
-def search_transfer(ctx: Ctx, f_fusion: FMap, lv1: FMap, lv2: FMap, lv3: FMap, return_arg=False):
+# Each is split around the correlation arg-max kernel (the dominant kernel of the path): `*_plan` prepares it, the caller
+# launches `plan` (engine._tail does; bench.py places that launch between two captured graph segments to time it live with
+# HIP events), `*_finish` consumes what it decided.
+def search_plan(ctx: Ctx, f_fusion: FMap, lv3: FMap):
     ctx = ctx.for_stage("search")
-    inv_l = ctx.patch_invnorm(f_fusion)
-    inv_r = ctx.patch_invnorm(lv3)
-    s, arg = ctx.corr_argmax(f_fusion, lv3, inv_l, inv_r)
+    return ctx.corr_plan(f_fusion, lv3, ctx.patch_invnorm(f_fusion), ctx.patch_invnorm(lv3))
+
+
+def search_finish(ctx: Ctx, plan, f_fusion: FMap, lv1: FMap, lv2: FMap, lv3: FMap, return_arg=False):
+    ctx = ctx.for_stage("search")
+    s, arg = plan.s, plan.arg
     if ctx.capture is not None:
         ctx.capture.update(arg=arg, s=s)
     h3, w3 = f_fusion.H, f_fusion.W
@@ -121,16 +127,33 @@ def search_transfer(ctx: Ctx, f_fusion: FMap, lv1: FMap, lv2: FMap, lv3: FMap, r
     return s, t3, t2, t1
 
 
-def self_transfer(ctx: Ctx, f_fusion: FMap, P: dict):
+def search_transfer(ctx: Ctx, f_fusion: FMap, lv1: FMap, lv2: FMap, lv3: FMap, return_arg=False):
+    plan = search_plan(ctx, f_fusion, lv3)
+    plan.launch()
+    return search_finish(ctx, plan, f_fusion, lv1, lv2, lv3, return_arg)
+
+
+def self_plan(ctx: Ctx, f_fusion: FMap):
     ctx = ctx.for_stage("search")
     ref = ctx.rot90(f_fusion)
-    s, _ = ctx.corr_argmax(f_fusion, ref, ctx.patch_invnorm(f_fusion), ctx.patch_invnorm(ref))
+    return ctx.corr_plan(f_fusion, ref, ctx.patch_invnorm(f_fusion), ctx.patch_invnorm(ref))
+
+
+def self_finish(ctx: Ctx, plan, f_fusion: FMap, P: dict):
+    ctx = ctx.for_stage("search")
+    s = plan.s
     if ctx.capture is not None:
         ctx.capture.update(s_self=s)
     p1, p2 = P["SelfTransfer.search1"], P["SelfTransfer.search2"]
     t2 = ctx.up_conv1x1_relu(f_fusion, p1["w"], p1["b"], 64)
     t1 = ctx.up_conv1x1_relu(t2, p2["w"], p2["b"], 32)
     return s, f_fusion, t2, t1
+
+
+def self_transfer(ctx: Ctx, f_fusion: FMap, P: dict):
+    plan = self_plan(ctx, f_fusion)
+    plan.launch()
+    return self_finish(ctx, plan, f_fusion, P)
 
 
 # ---- decode (reference model/speinet.py:92-120) -----------------------------------------------------------
@@ -173,7 +196,19 @@ def _lanes(ctx: Ctx, sides) -> list:
 
 
 def forward_sample(ctx: Ctx, x: torch.Tensor, P: dict, n_seq: int, has_ref: bool, out: torch.Tensor, sides=()) -> torch.Tensor:
-    """x [n_seq+2, 3, H, W] (contiguous, cuda) -> out [3, H, W].
+    """x [n_seq+2, 3, H, W] (contiguous, cuda) -> out [3, H, W]."""
+    return _run(forward_sample_steps(ctx, x, P, n_seq, has_ref, out, sides), out)
+
+
+def _run(steps, out):
+    for plan in steps:           # one yield: the prepared correlation arg-max
+        plan.launch()
+    return out
+
+
+def forward_sample_steps(ctx: Ctx, x: torch.Tensor, P: dict, n_seq: int, has_ref: bool, out: torch.Tensor, sides=()):
+    """Generator form of `forward_sample`: runs everything up to the correlation arg-max, yields its prepared launch (the caller
+    launches it), then runs the rest.  All side-stream work is joined before the yield.
 
     f_mid, the neighbour-frame swin fusions and the 1x1 `fusion` conv (speinet.py:75-90,129-134), then
     SearchTransfer / SelfTransfer and the decoder (:92-148)."""
@@ -206,17 +241,19 @@ def forward_sample(ctx: Ctx, x: torch.Tensor, P: dict, n_seq: int, has_ref: bool
             del e, feat
     for s_ in lanes[1:]:
         main.wait_stream(s_)                      # join
-    return _tail(ctx, cat, lv, P, out)
+    yield from _tail(ctx, cat, lv, P, out)
 
 
-def _tail(ctx: Ctx, cat: FMap, lv, P: dict, out: torch.Tensor) -> torch.Tensor:
+def _tail(ctx: Ctx, cat: FMap, lv, P: dict, out: torch.Tensor):
     fw = P["fusion"]
     ff = ctx.igemm(cat, fw["w"], fw["b"], 128)
+    plan = search_plan(ctx, ff, lv[2]) if lv is not None else self_plan(ctx, ff)
+    yield plan
     if lv is not None:
-        s, t3, t2, t1 = search_transfer(ctx, ff, *lv)
+        s, t3, t2, t1 = search_finish(ctx, plan, ff, *lv)
     else:
-        s, t3, t2, t1 = self_transfer(ctx, ff, P)
-    return decode(ctx, ff, s, t3, t2, t1, P, out)
+        s, t3, t2, t1 = self_finish(ctx, plan, ff, P)
+    decode(ctx, ff, s, t3, t2, t1, P, out)
 
 
 # ---- cross-window reuse --------------------------------------------------------------------
@@ -241,6 +278,10 @@ def reference_pyramid(ctx: Ctx, frame: torch.Tensor, P: dict):
 
 
 def fuse_and_decode(ctx: Ctx, f_mid: FMap, feats: list, lv, P: dict, n_seq: int, out: torch.Tensor, sides=()) -> torch.Tensor:
+    return _run(fuse_and_decode_steps(ctx, f_mid, feats, lv, P, n_seq, out, sides), out)
+
+
+def fuse_and_decode_steps(ctx: Ctx, f_mid: FMap, feats: list, lv, P: dict, n_seq: int, out: torch.Tensor, sides=()):
     """Everything after the encoders: the neighbour-frame fusions (on the side lanes), `fusion`, SearchTransfer (lv = the
     reference pyramid) or SelfTransfer (lv = None), decoder.  f_mid / feats: [H/4*W/4, 128] maps."""
     h3, w3 = f_mid.H, f_mid.W
@@ -260,4 +301,4 @@ def fuse_and_decode(ctx: Ctx, f_mid: FMap, feats: list, lv, P: dict, n_seq: int,
             swin(ctx, sx, feat, P["swin"], out=cat.view(128 * slot, 128))
     for s_ in lanes[1:]:
         main.wait_stream(s_)
-    return _tail(ctx, cat, lv, P, out)
+    yield from _tail(ctx, cat, lv, P, out)

@@ -104,6 +104,26 @@ class _timed:
         return False
 
 
+class CorrPlan:
+    """A prepared K11 launch (see Ctx.corr_plan): `launch()` runs the arg-max kernel — bracketed by the profile events — and
+    whatever must follow it on the same stream (the exact re-score of the "top2" form)."""
+    __slots__ = ("ctx", "s", "arg", "kernel", "main", "post", "keep")
+
+    def __init__(self, ctx, s, arg, kernel, main, post, keep):
+        self.ctx, self.s, self.arg, self.kernel, self.main, self.post, self.keep = ctx, s, arg, kernel, main, post, keep
+
+    def launch(self, profile: Optional[dict] = None) -> None:
+        ctx = self.ctx if profile is None else self.ctx.replace(profile=profile)
+        st = ctx._stream()
+        if ctx.profile is not None:
+            ctx.profile["corr_kernel"] = self.kernel
+        with _timed(ctx, "corr_argmax"):
+            for fn, name, args in self.main:
+                _lib.check(fn(*args, st), name)
+        for fn, name, args in self.post:
+            _lib.check(fn(*args, st), name)
+
+
 class Ctx:
     """Everything one forward call needs to know besides its tensors.  Immutable; `replace` derives a variant.
 
@@ -402,7 +422,10 @@ class Ctx:
         _lib.check(_lib.lib().spei_patch_invnorm(self._fp(f), f.ld, self._tp(inv), f.H, f.W, f.C, self._stream()), "spei_patch_invnorm")
         return inv
 
-    def corr_argmax(self, lr: FMap, ref: FMap, inv_lr: torch.Tensor, inv_ref: torch.Tensor):
+    def corr_plan(self, lr: FMap, ref: FMap, inv_lr: torch.Tensor, inv_ref: torch.Tensor) -> "CorrPlan":
+        """Everything of K11 except the arg-max kernel itself: output / workspace allocation and the one-off 16-bit
+        conversion of the two maps.  `plan.launch()` then runs the dominant kernel of the path (timed by `profile`), so a
+        caller can place it between two captured graph segments and bracket it with HIP events (bench.py)."""
         lib = _lib.lib()
         dev = lr.t.device
         tp, fp = self._tp, self._fp
@@ -410,11 +433,11 @@ class Ctx:
         s = torch.empty(n, device=dev)
         arg = torch.empty(n, device=dev, dtype=torch.int32)
         ws = torch.empty(lib.spei_corr_ws_floats(n), device=dev)
+        dims = (lr.H, lr.W, ref.H, ref.W, lr.C)
         if self.precision == "f32":
-            with _timed(self, "corr_argmax"):
-                _lib.check(lib.spei_corr_argmax(fp(lr), lr.ld, fp(ref), ref.ld, tp(inv_lr), tp(inv_ref), lr.H, lr.W, ref.H, ref.W,
-                                                lr.C, tp(s), tp(arg), tp(ws), self._stream()), "spei_corr_argmax")
-            return s, arg
+            args = (fp(lr), lr.ld, fp(ref), ref.ld, tp(inv_lr), tp(inv_ref), *dims, tp(s), tp(arg), tp(ws))
+            return CorrPlan(self, s, arg, "corr_argmax_kernel (f32 MFMA)", [(lib.spei_corr_argmax, "spei_corr_argmax", args)], [],
+                            (lr, ref, inv_lr, inv_ref, ws))
         split = self.corr_precision == "bf16x3"
         rescore = self.corr_precision == "top2" and self.use_slab and lr.C == 128
         f16 = self.fmt
@@ -425,24 +448,28 @@ class Ctx:
             lo = torch.empty_like(hi) if split else None
             _lib.check(lib.spei_split16(f16, fp(f), f.ld, tp(hi), tp(lo), f.H * f.W, f.C, self._stream()), "spei_split16")
             parts += [hi, lo]
+        fname = "f16" if f16 == F16 else "bf16"
         if rescore:
             arg2 = torch.empty(n, device=dev, dtype=torch.int32)
             s2 = torch.empty(n, device=dev)
-            with _timed(self, "corr_argmax"):
-                _lib.check(lib.spei_corr_slab_top2_16(f16, tp(parts[0]), tp(parts[2]), tp(inv_lr), tp(inv_ref), lr.H, lr.W, ref.H, ref.W,
-                                                      lr.C, tp(s), tp(arg), tp(s2), tp(arg2), tp(ws), self._stream()),
-                           "spei_corr_slab_top2_16")
-            _lib.check(lib.spei_corr_rescore(fp(lr), lr.ld, fp(ref), ref.ld, tp(inv_lr), tp(inv_ref), lr.H, lr.W, ref.H, ref.W, lr.C,
-                                             tp(s), tp(arg), tp(s2), tp(arg2), self._stream()), "spei_corr_rescore")
-            return s, arg
-        args = (tp(parts[0]), tp(parts[1]), tp(parts[2]), tp(parts[3]), tp(inv_lr), tp(inv_ref),
-                lr.H, lr.W, ref.H, ref.W, lr.C, tp(s), tp(arg), tp(ws), self._stream())
-        with _timed(self, "corr_argmax"):
-            if self.use_slab and lr.C == 128:
-                _lib.check(lib.spei_corr_slab16(f16, *args), "spei_corr_slab16")
-            else:
-                _lib.check(lib.spei_corr_argmax_bf16(*args), "spei_corr_argmax_bf16")
-        return s, arg
+            main = (lib.spei_corr_slab_top2_16, "spei_corr_slab_top2_16",
+                    (f16, tp(parts[0]), tp(parts[2]), tp(inv_lr), tp(inv_ref), *dims, tp(s), tp(arg), tp(s2), tp(arg2), tp(ws)))
+            post = (lib.spei_corr_rescore, "spei_corr_rescore",
+                    (fp(lr), lr.ld, fp(ref), ref.ld, tp(inv_lr), tp(inv_ref), *dims, tp(s), tp(arg), tp(s2), tp(arg2)))
+            return CorrPlan(self, s, arg, f"corr_slab_kernel<top2, {fname}>", [main], [post], (lr, ref, inv_lr, inv_ref, ws, parts, s2, arg2))
+        args = (tp(parts[0]), tp(parts[1]), tp(parts[2]), tp(parts[3]), tp(inv_lr), tp(inv_ref), *dims, tp(s), tp(arg), tp(ws))
+        if self.use_slab and lr.C == 128:
+            main = (lib.spei_corr_slab16, "spei_corr_slab16", (f16, *args))
+            kname = f"corr_slab_kernel<{'bf16x3' if split else 'top1, ' + fname}>"
+        else:
+            main = (lib.spei_corr_argmax_bf16, "spei_corr_argmax_bf16", args)
+            kname = f"corr_bf16_kernel<{'bf16x3' if split else 'bf16'}>"
+        return CorrPlan(self, s, arg, kname, [main], [], (lr, ref, inv_lr, inv_ref, ws, parts))
+
+    def corr_argmax(self, lr: FMap, ref: FMap, inv_lr: torch.Tensor, inv_ref: torch.Tensor):
+        plan = self.corr_plan(lr, ref, inv_lr, inv_ref)
+        plan.launch()
+        return plan.s, plan.arg
 
     def gather_fold(self, ref: FMap, arg: torch.Tensor, H3: int, W3: int, Hr3: int, Wr3: int, s: int) -> FMap:
         assert ref.H == Hr3 * s and ref.W == Wr3 * s
