@@ -119,6 +119,15 @@ int spei_attn_fused16(int fmt, const float* x, float* out, const void* yhat, con
                       const void* wkv_frag, const float* bkv, const void* wproj_frag, const float* bproj,
                       const float* relbias, int H, int W, int shift, spei_stream_t stream);
 
+/* One whole cross-window Swin block (model/swinir.py:238-281) in a single persistent launch: the attention branch of
+ * spei_attn_fused16 followed by the MLP branch of spei_mlp_fused16 on the same rows, x read once and written once, the
+ * intermediate x1 = x + proj(...) never leaves the registers; groups of three windows per 512-thread workgroup, one
+ * workgroup per CU.  Arguments as for the two kernels it replaces; x and out may alias. */
+int spei_swin_block16(int fmt, const float* x, float* out, const void* yhat, const void* wq_frag, const float* bq,
+                      const void* wkv_frag, const float* bkv, const void* wproj_frag, const float* bproj,
+                      const float* relbias, const void* w1_frag, const float* b1, const void* w2_frag, const float* b2,
+                      int H, int W, int shift, spei_stream_t stream);
+
 /* K3 — ResBlock gates (model/block.py:8-24 SE, 71-96 ZPool+AttentionGate1/2, 108-124 TripletAttention).
  * x1: conv2 output [H][W][C] stored as x1_fmt (SPEI_F32 / SPEI_BF16 / SPEI_F16).  Workspace `ws` floats: spei_gate_ws_floats(H,W,C).
  * Produces s[C], g1[H][C], g2[W][C] such that ResBlock = x + x1*s + (x1*g1 + x1*g2).

@@ -38,6 +38,7 @@ struct AttnParams {
     const LP* wproj;      // fragment order [8][1][16][64][8]
     const float* bproj;
     const float* relbias; // [8][25][25]
+    long long* stamps;    // tuning build: phase stamps, else NULL
     int H, W, shift, nwin;
 };
 
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const AttnParams<LP>
     const int fr = lane & 31, fk = lane >> 5;
     const int nwx = p.W / WS;
 
+    SPEI_STAMP(p.stamps, 0);
     if (tid < ROWS) {
         const int w = tid >> 5, t = tid & 31;
         const int win = blockIdx.x * 2 + w;
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const AttnParams<LP>
         }
     }
     __syncthreads();
+    SPEI_STAMP(p.stamps, 1);
 
     // ---- 2 + 3. the wave's two heads: Q^T, K^T, V, then attention on both windows, all in registers -------------------
     lp4 opk[2][2][4];                               // [head][window][4 d-groups]: O^T packed, written to LDS after the barrier
@@ -222,6 +225,7 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const AttnParams<LP>
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        SPEI_STAMP(p.stamps, 2 + 2 * hh);
 #pragma unroll
         for (int w = 0; w < 2; ++w) {
             f32x16 st;
@@ -265,8 +269,10 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const AttnParams<LP>
 #pragma unroll
                 for (int e = 0; e < 4; ++e) opk[hh][w][g][e] = to_lp<LP>(ot[4 * g + e]);
         }
+        SPEI_STAMP(p.stamps, 3 + 2 * hh);
     }
     __syncthreads();                                   // every wave is done reading the y slab
+    SPEI_STAMP(p.stamps, 6);
     // rows d = (r&3) + 8*(r>>2) + 4*fk = 8g + 4fk + e, column = query token fr  ->  os[token][h*32 + d]
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh)
@@ -276,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const AttnParams<LP>
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<lp4*>(os + (w * 32 + fr) * PA + ((wave * 2 + hh) * HD + 8 * g + 4 * fk) * 2) = opk[hh][w][g];
     __syncthreads();
+    SPEI_STAMP(p.stamps, 7);
 
     // ---- 4. proj: the wave produces output channels [64 wave, 64 wave + 64) for all 64 rows, + bias + residual ---------
     {
@@ -331,6 +338,7 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const AttnParams<LP>
             __builtin_amdgcn_sched_barrier(0);
             ks = (ks + 1) & 15;
         }
+        SPEI_STAMP(p.stamps, 8);
 #pragma unroll
         for (int nn = 0; nn < 2; ++nn) {
             const float bias = p.bproj[(wave * 2 + nn) * HD + fr];
@@ -348,6 +356,7 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(const AttnParams<LP>
                 }
             }
         }
+        SPEI_STAMP(p.stamps, 9);
     }
 }
 
@@ -360,6 +369,7 @@ static int attn_launch(const float* x, float* out, const void* yhat, const void*
     p.x = x; p.out = out; p.yhat = (const LP*)yhat; p.wq = (const LP*)wq; p.bq = bq; p.wkv = (const LP*)wkv;
     p.bkv = bkv; p.wproj = (const LP*)wproj; p.bproj = bproj; p.relbias = relbias;
     p.H = H; p.W = W; p.shift = shift; p.nwin = (H / WS) * (W / WS);
+    p.stamps = spei_stamp_buffer();
     const size_t lds = (size_t)2 * ROWS * PA + 2 * ROWS * sizeof(int);
     ensure_dyn_lds<&attn_fused_kernel<LP>>(lds);
     hipLaunchKernelGGL(attn_fused_kernel<LP>, dim3((p.nwin + 1) / 2), dim3(256), lds, st, p);

@@ -32,8 +32,17 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 #ifdef SPEI_TUNING
 #include <stdlib.h>
 static inline int spei_knob(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+// In-kernel phase stamps (tools/stamp_phases.py): SPEI_STAMP_PTR = device address of a long long[workgroups][16] buffer the
+// caller allocated; wave 0 of a workgroup writes s_memtime at each SPEI_STAMP(i).  Compiled out of the shipping build.
+static inline long long* spei_stamp_buffer() { const char* v = getenv("SPEI_STAMP_PTR"); return v ? (long long*)strtoull(v, nullptr, 0) : nullptr; }
+#define SPEI_STAMP(buf, i)                                                                            \
+    do {                                                                                              \
+        if ((buf) && threadIdx.x == 0) (buf)[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 #else
 static constexpr int spei_knob(const char*, int dflt) { return dflt; }
+static inline long long* spei_stamp_buffer() { return nullptr; }
+#define SPEI_STAMP(buf, i) do { } while (0)
 #endif
 
 // Raise a kernel's dynamic-LDS limit before its first launch with `lds` bytes ON THE CURRENT DEVICE.  The attribute is

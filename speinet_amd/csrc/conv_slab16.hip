@@ -51,6 +51,7 @@ struct SlabParams {
     int64_t planes;          // > 0: write output channels 0..2 as three fp32 NCHW planes of this many pixels (last conv)
     int ln;                  // 1: LayerNorm(256) without affine is applied to every input row while it is staged
                              //    (fp32 input, K == 256: one wave-instruction loads exactly one token row)
+    int stagger, stagger_slots;   // first-round start delay (units of 64 cycles) per co-resident workgroup slot
     int dbg;                 // ablation switches for tools/ablate_slab.py (0 in production): 1 no staging loads,
                              // 4 no epilogue stores
 };
@@ -105,6 +106,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int fr = lane & 31, fk = lane >> 5;
+    if (p.stagger > 0) {
+        // Workgroups that start together stay in lockstep (all stage, then all compute, then all store: HBM idles while the
+        // matrix pipe runs and vice versa).  Delay the k-th co-resident workgroup of a CU by k * stagger in the first round;
+        // later workgroups start whenever one finishes and inherit the offset.
+        const int slot = blockIdx.x / 256;
+        if (slot < p.stagger_slots)
+            for (int i = 0; i < slot * p.stagger; i += 64) __builtin_amdgcn_s_sleep(64);
+    }
     const int tile_y = blockIdx.x / p.tiles_x, tile_x = blockIdx.x - tile_y * p.tiles_x;
     const int oy0 = tile_y * p.TH, ox0 = tile_x * p.TW;
     const int ks16 = p.K / 16;
@@ -386,6 +395,8 @@ int launch(const SlabParams& p, size_t lds, hipStream_t s) {
     q.n_chunks = p.N / (WN * TN * 32);
     static const int dbg = spei_knob("SPEI_SLAB_DBG", 0);
     q.dbg = dbg;
+    static const int stagger = spei_knob("SPEI_SLAB_STAGGER", 0), slots = spei_knob("SPEI_SLAB_SLOTS", 3);
+    q.stagger = stagger; q.stagger_slots = slots;
     dim3 grid(p.tiles_x * cdiv(p.Hout, p.TH), 1);
     hipLaunchKernelGGL((conv_slab_kernel<WM, WN, TM, TN, SPLIT, TA, TO, LP>), grid, dim3(64 * WM * WN), lds, s, q);
     SPEI_CHECK_LAUNCH("spei_conv_slab16");
@@ -424,40 +435,47 @@ int dispatch(SlabParams& p, hipStream_t s) {
         p.goff_bytes = ((ngroups * (int)sizeof(int) + 15) / 16) * 16;
         return (size_t)nparts * p.slab_bytes + (size_t)p.goff_bytes;
     };
-    const size_t budget = 96 * 1024;
+    static const int budget_kb = spei_knob("SPEI_SLAB_BUDGET", 96);
+    const size_t budget = (size_t)budget_kb * 1024;
     const size_t hard = 160 * 1024 - 512;
-    // 8-wave workgroups (two waves per SIMD share one slab) for the non-split mode; knobs for tools/ablate_slab.py:
-    // SPEI_SLAB_W8=<bitmask> 1: N%128 layers, 2: N%64 layers, 4: N=32 layers
-    static const int w8 = spei_knob("SPEI_SLAB_W8", 0);
     size_t lds;
-    if (p.N % 128 == 0) {
-        if (!SPLIT && (w8 & 1)) {
-            lds = setup(256);
-            if (lds <= hard && p.IH * p.IW < 2048 && !linear) return launch<2, 4, 4, 1, SPLIT, TA, TO, LP>(p, lds, s);
-            lds = setup(128);
-            if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 4, 2, 1, SPLIT, TA, TO, LP>(p, lds, s);
+    // Experimental tile shapes (tuning build only: SPEI_SLAB_CFG_N32 / _N64 / _N128 pick one by number; 0 = shipping choice).
+    // TM x TN output tiles per wave decide how many MFMAs each operand fragment feeds: an A fragment (LDS) feeds TN, a B
+    // fragment (1 KiB from L2) feeds TM.
+#ifdef SPEI_TUNING
+    if (!SPLIT) {
+        static const int c32 = spei_knob("SPEI_SLAB_CFG_N32", 0), c64 = spei_knob("SPEI_SLAB_CFG_N64", 0), c128 = spei_knob("SPEI_SLAB_CFG_N128", 0);
+        const bool ok2d = !linear;
+        if (p.N == 32 && c32 && ok2d) {
+            if (c32 == 1) { lds = setup(256); if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 1, 4, 1, SPLIT, TA, TO, LP>(p, lds, s); }
+            if (c32 == 2) { lds = setup(512); if (lds <= hard && p.IH * p.IW < 2048) return launch<4, 1, 4, 1, SPLIT, TA, TO, LP>(p, lds, s); }
+            if (c32 == 3) { lds = setup(128); if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 1, 4, 1, SPLIT, TA, TO, LP>(p, lds, s); }
         }
+        if (p.N % 64 == 0 && p.N % 128 != 0 && c64 && ok2d) {
+            if (c64 == 1) { lds = setup(128); if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 2, 4, 1, SPLIT, TA, TO, LP>(p, lds, s); }
+            if (c64 == 2) { lds = setup(256); if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 1, 4, 2, SPLIT, TA, TO, LP>(p, lds, s); }
+            if (c64 == 3) { lds = setup(256); if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 2, 4, 1, SPLIT, TA, TO, LP>(p, lds, s); }
+            if (c64 == 4) { lds = setup(128); if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 1, 4, 2, SPLIT, TA, TO, LP>(p, lds, s); }
+        }
+        if (p.N % 128 == 0 && c128 && ok2d) {
+            if (c128 == 1) { lds = setup(128); if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 2, 4, 2, SPLIT, TA, TO, LP>(p, lds, s); }
+            if (c128 == 2) { lds = setup(256); if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 2, 4, 2, SPLIT, TA, TO, LP>(p, lds, s); }
+            if (c128 == 3) { lds = setup(128); if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 4, 4, 1, SPLIT, TA, TO, LP>(p, lds, s); }
+            if (c128 == 4) { lds = setup(256); if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 4, 4, 1, SPLIT, TA, TO, LP>(p, lds, s); }
+        }
+    }
+#endif
+    if (p.N % 128 == 0) {
         lds = setup(128);
-        const int64_t tiles128 = (int64_t)p.tiles_x * cdiv(p.Hout, p.TH);
-        static const int min_tiles = spei_knob("SPEI_SLAB_MIN_TILES128", 0);
-        if (lds <= budget && tiles128 >= min_tiles && p.IH * p.IW < 2048) return launch<1, 4, 4, 1, SPLIT, TA, TO, LP>(p, lds, s);
+        if (lds <= budget && p.IH * p.IW < 2048) return launch<1, 4, 4, 1, SPLIT, TA, TO, LP>(p, lds, s);
         lds = setup(64);
         if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 4, 2, 1, SPLIT, TA, TO, LP>(p, lds, s);
     } else if (p.N % 64 == 0) {
-        if (!SPLIT && (w8 & 2)) {
-            lds = setup(256);
-            if (lds <= hard && p.IH * p.IW < 2048) return launch<4, 2, 2, 1, SPLIT, TA, TO, LP>(p, lds, s);
-        }
         lds = setup(128);
         if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 2, 2, 1, SPLIT, TA, TO, LP>(p, lds, s);
     } else {
-        if (!SPLIT && (w8 & 4)) {
-            lds = setup(512);
-            if (lds <= hard && p.IH * p.IW < 2048) return launch<8, 1, 2, 1, SPLIT, TA, TO, LP>(p, lds, s);
-        }
-        static const int n32_tile = spei_knob("SPEI_SLAB_N32_TILE", 256);
         lds = setup(256);
-        if (n32_tile == 256 && lds <= budget && p.IH * p.IW < 2048) return launch<4, 1, 2, 1, SPLIT, TA, TO, LP>(p, lds, s);
+        if (lds <= budget && p.IH * p.IW < 2048) return launch<4, 1, 2, 1, SPLIT, TA, TO, LP>(p, lds, s);
         lds = setup(128);
         if (lds <= hard && p.IH * p.IW < 2048) return launch<4, 1, 1, 1, SPLIT, TA, TO, LP>(p, lds, s);
     }

@@ -31,6 +31,7 @@ struct MlpParams {
     const float* b1;
     const LP* w2;         // fragment order [D/32][1][HID/16][64][8]
     const float* b2;
+    long long* stamps;    // tuning build: phase stamps, else NULL
     int M;
 };
 
@@ -75,6 +76,7 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams<LP> p) {
     const int fr = lane & 31, fk = lane >> 5;
     const int m0 = blockIdx.x * MT;
 
+    SPEI_STAMP(p.stamps, 0);
     bias1[tid] = p.b1[tid];
 
     // ---- 1. LayerNorm(256): 16 lanes per token, 32 tokens per pass; every load is issued before the first reduction ----
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams<LP> p) {
 #pragma unroll
     for (int d = 0; d < RING; ++d) ring[d] = *reinterpret_cast<const lp8*>(wptr + ((rot + d) & 15) * 512);
     __syncthreads();
+    SPEI_STAMP(p.stamps, 1);
 
     f32x16 acc2[RT];                                        // fc2 accumulators: tokens x output channels [32 wave, +32)
 #pragma unroll
@@ -161,6 +164,7 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams<LP> p) {
             for (int i = 0; i < RT; ++i) acc1[i] = mfma16(w, tc[i], acc1[i]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        SPEI_STAMP(p.stamps, 2 + 3 * half);
         // fc2 weight stream of this half starts under the GELU; the last half fetches ALL its fragments here, so that the
         // residual loads below can queue behind them without any later weight load waiting for those (vmcnt is in order)
         wptr = p.w2 + (size_t)wave * 32 * 512 + (size_t)half * 16 * 512 + lane * 8;
@@ -197,6 +201,7 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams<LP> p) {
                 }
         }
         __syncthreads();
+        SPEI_STAMP(p.stamps, 3 + 3 * half);
         // ---- 2b. fc2 partial product over this half of the hidden dim ------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < RT; ++i) tn[i] = *reinterpret_cast<const lp8*>(hbase + i * 32 * PA + rot * 32);
@@ -216,6 +221,7 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams<LP> p) {
             for (int i = 0; i < RT; ++i) acc2[i] = mfma16(tc[i], w, acc2[i]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        SPEI_STAMP(p.stamps, 4 + 3 * half);
         if (half == 0) {
             wptr = p.w1 + (size_t)(8 + wave) * 16 * 512 + lane * 8;      // fc1, half 1
 #pragma unroll
@@ -238,6 +244,7 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams<LP> p) {
                 if (m < p.M) *reinterpret_cast<f32x4*>(p.out + (size_t)m * D + wave * 32 + ecol) = f32x4{a[0], a[1], a[2], a[3]} + res[i][k];
             }
         }
+        SPEI_STAMP(p.stamps, 8);
     }
 }
 
@@ -247,6 +254,7 @@ template <typename LP>
 static int mlp_launch(const float* x, float* out, const void* w1, const float* b1, const void* w2, const float* b2, int64_t M, hipStream_t st) {
     MlpParams<LP> p;
     p.x = x; p.out = out; p.w1 = (const LP*)w1; p.b1 = b1; p.w2 = (const LP*)w2; p.b2 = b2; p.M = (int)M;
+    p.stamps = spei_stamp_buffer();
     const size_t lds = (size_t)2 * MT * PA + HID * sizeof(float);
     ensure_dyn_lds<&mlp_fused_kernel<LP>>(lds);
     hipLaunchKernelGGL(mlp_fused_kernel<LP>, dim3(cdiv(M, MT)), dim3(512), lds, st, p);

@@ -137,6 +137,10 @@ class Ctx:
       x1_bf16         16-bit: the ResBlock's conv2 output (read by the gate statistics and the apply pass) is 16-bit
       fuse_mlp        16-bit: LayerNorm -> fc1 -> GELU -> fc2 -> +x in one kernel (mlp_fused16.hip)
       fuse_attn       16-bit: LayerNorm -> q/kv GEMMs -> window attention -> proj -> +x in one kernel (attn_fused16.hip)
+      fuse_block      (default OFF) 16-bit, with fuse_mlp and fuse_attn: the whole Swin block as ONE persistent launch
+                      (swin_block16.hip).  Correct and tested, but measured slower than the two launches it replaces (150 vs
+                      133-142 us per block at 720p, and as a 1-workgroup-per-CU kernel it shuts out the other stream's
+                      kernels: 32.9 vs 30.7 ms per frame) — kept as the base for cross-group prefetching, DESIGN.md §6
       commute_upconv  16-bit: relu(conv1x1(bicubic_up(x))) evaluated as relu(bicubic_up(conv1x1(x)))
     stage        {stage name: {field: value}} overrides applied by `for_stage` (engine: "enc", "swin", "search", "decode", and inside
                  "decode" the last stack "out" and its final conv "tail")
@@ -147,12 +151,12 @@ class Ctx:
     ACT_NONE, ACT_RELU, ACT_GELU = ACT_NONE, ACT_RELU, ACT_GELU
     CONV, CONV_T = CONV, CONV_T
     _FIELDS = ("precision", "corr_precision", "device", "use_slab", "bf16_storage", "x1_bf16", "fuse_mlp", "fuse_attn",
-               "commute_upconv", "stage", "profile", "capture")
+               "fuse_block", "commute_upconv", "stage", "profile", "capture")
     __slots__ = _FIELDS
 
     def __init__(self, precision: str = "f32", corr_precision: str = "bf16x3", device=None, use_slab: bool = True,
                  bf16_storage: bool = True, x1_bf16: bool = True, fuse_mlp: bool = True, fuse_attn: bool = True,
-                 commute_upconv: bool = True, stage: Optional[dict] = None, profile: Optional[dict] = None,
+                 fuse_block: bool = False, commute_upconv: bool = True, stage: Optional[dict] = None, profile: Optional[dict] = None,
                  capture: Optional[dict] = None):
         if precision not in PRECISIONS:
             raise ValueError(f"unknown precision {precision!r}")
@@ -171,7 +175,7 @@ class Ctx:
         object.__setattr__(self, "corr_precision", corr_precision)
         object.__setattr__(self, "device", device)
         for k, v in (("use_slab", use_slab), ("bf16_storage", bf16_storage), ("x1_bf16", x1_bf16), ("fuse_mlp", fuse_mlp),
-                     ("fuse_attn", fuse_attn), ("commute_upconv", commute_upconv)):
+                     ("fuse_attn", fuse_attn), ("fuse_block", fuse_block), ("commute_upconv", commute_upconv)):
             object.__setattr__(self, k, bool(v))
         object.__setattr__(self, "stage", dict(stage) if stage else {})
         object.__setattr__(self, "profile", profile)
@@ -373,6 +377,21 @@ class Ctx:
 
     def mlp_fused_available(self) -> bool:
         return self.lp16 and self.use_slab and self.fuse_mlp
+
+    def block_fused_available(self) -> bool:
+        return self.attn_fused_available() and self.mlp_fused_available() and self.fuse_block
+
+    def swin_block(self, x: torch.Tensor, yhat: torch.Tensor, bk: dict, H: int, W: int, shift: int, out: torch.Tensor) -> torch.Tensor:
+        """out = x1 + mlp(norm2(x1)), x1 = x + attention(norm1(x), yhat)  (reference model/swinir.py:238-281); in place when out is x."""
+        f = self.fmt
+        assert x.shape == (H * W, 256) and x.dtype == torch.float32 and out.shape == x.shape and out.dtype == torch.float32
+        assert yhat.shape == x.shape and yhat.dtype == LP_DTYPE[f]
+        tp = self._tp
+        _lib.check(_lib.lib().spei_swin_block16(f, tp(x), tp(out), tp(yhat), tp(bk["wq"].frag(f)), tp(bk["bq"]), tp(bk["wkv"].frag(f)),
+                                                tp(bk["bkv"]), tp(bk["wproj"].frag(f)), tp(bk["bproj"]), tp(bk["relbias"]),
+                                                tp(bk["w1"].frag(f)), tp(bk["b1"]), tp(bk["w2"].frag(f)), tp(bk["b2"]), H, W, shift,
+                                                self._stream()), "spei_swin_block16")
+        return out
 
     def attn_fused(self, x: torch.Tensor, yhat: torch.Tensor, bk: dict, H: int, W: int, shift: int, out: torch.Tensor) -> torch.Tensor:
         """out = x + proj(window_attention(...))  (reference model/swinir.py:238-278); in place when out is x."""

@@ -255,6 +255,47 @@ def test_attn_fused_vs_oracle(synth_sd, h, w, shift, mode):
     assert torch.equal(inplace, out)
 
 
+@pytest.mark.parametrize("h,w,shift", [(5, 5, 0), (5, 10, 2), (10, 15, 0), (10, 15, 2), (20, 35, 2), (180, 320, 2), (180, 320, 0)])
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_swin_block_fused_vs_oracle(synth_sd, h, w, shift, mode):
+    """The whole Swin block as one persistent kernel (swin_block16.hip) against the oracle's block (model/swinir.py:238-281:
+    attention branch, then MLP branch) and against the two-kernel path it replaces; window counts that are not multiples of
+    the 3-window group leave empty window slots in the last group; 180x320 = the 720p token map (2304 windows, 3 groups per
+    workgroup on 256 CUs)."""
+    ops = Ctx(mode, device=DEV)
+    p = "swin.layers.4.residual_group.blocks.3."
+    bk = {k: (v.to(DEV) if torch.is_tensor(v) else pack.PackedW(v.t, DEV)) for k, v in pack.swin_block(synth_sd, p, 8, 5).items()}
+    m = h * w
+    x = rnd(500 + m + shift, 1, m, 256, scale=1.3) + 0.2
+    y = rnd(600 + m + shift, 1, m, 256, scale=0.9) - 0.1
+    # oracle: x1 = x + attention(norm1(x), norm1(y)); out = x1 + mlp(norm2(x1))
+    ln = lambda t, n: F.layer_norm(t, (256,), synth_sd[p + n + ".weight"], synth_sd[p + n + ".bias"], 1e-5)
+    xn, yn = ln(x, "norm1").view(1, h, w, 256), ln(y, "norm1").view(1, h, w, 256)
+    if shift:
+        xn, yn = (torch.roll(t, shifts=(-shift, -shift), dims=(1, 2)) for t in (xn, yn))
+    xw, yw = (O.window_partition(t, 5).view(-1, 25, 256) for t in (xn, yn))
+    mask = O.shift_mask(h, w, 5, shift) if shift else None
+    br = O.window_reverse(O.window_attention(xw, yw, synth_sd, p + "attn.", 8, 5, mask).view(-1, 5, 5, 256), 5, h, w)
+    if shift:
+        br = torch.roll(br, shifts=(shift, shift), dims=(1, 2))
+    x1 = x[0] + br.reshape(m, 256)
+    mlp = F.linear(F.gelu(F.linear(ln(x1, "norm2"), synth_sd[p + "mlp.fc1.weight"], synth_sd[p + "mlp.fc1.bias"])),
+                   synth_sd[p + "mlp.fc2.weight"], synth_sd[p + "mlp.fc2.bias"])
+    ref = x1 + mlp
+    xd = x[0].to(DEV).contiguous()
+    yhat = ops.layernorm(y[0].to(DEV).contiguous(), out_dtype=LPD[mode])
+    out = ops.swin_block(xd, yhat, bk, h, w, shift, out=torch.empty_like(xd))
+    scale = (ref - x[0]).abs().max().item()
+    e = (out.cpu() - ref).abs().max().item() / scale
+    two = ops.mlp_fused(ops.attn_fused(xd, yhat, bk, h, w, shift, out=torch.empty_like(xd)), bk["w1"], bk["b1"], bk["w2"], bk["b2"],
+                        out=torch.empty_like(xd))
+    e2 = (out - two).abs().max().item() / scale
+    assert torch.isfinite(out).all() and e < TOL[mode], f"{h}x{w} shift {shift}: rel err vs oracle {e:.2e}"
+    assert e2 < TOL[mode], f"{h}x{w} shift {shift}: rel diff to the two-kernel path {e2:.2e}"
+    inplace = ops.swin_block(xd, yhat, bk, h, w, shift, out=xd)
+    assert torch.equal(inplace, out)
+
+
 @pytest.mark.parametrize("graph", [False, True])
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_streams_bit_identical(net, mode, graph):

@@ -6,7 +6,8 @@ import torch
 from speinet_amd import pack
 from speinet_amd.ops import Ctx
 from speinet_amd.ops import FMap
-ops = Ctx(os.environ.get("PREC", "bf16"))
+ops = Ctx(os.environ.get("PREC", "f16"))
+LP = torch.float16 if ops.precision == "f16" else torch.bfloat16
 dev = "cuda:0"
 shapes = [  # name, H, W, Cin, Cout, ks, stride, residual
     ("lv1 conv5 32->32", 720, 1280, 32, 32, 5, 1, False),
@@ -19,11 +20,11 @@ shapes = [  # name, H, W, Cin, Cout, ks, stride, residual
 ]
 IN_BF16 = os.environ.get("IN_BF16", "0") == "1"      # ResBlock conv2: bf16 in, bf16 out
 for name, h, w, ci, co, ks, st, res in shapes:
-    x = FMap(torch.randn(h * w, ci, device=dev).to(torch.bfloat16 if (IN_BF16 and ks == 5) else torch.float32), h, w, ci)
+    x = FMap(torch.randn(h * w, ci, device=dev).to(LP if (IN_BF16 and ks == 5) else torch.float32), h, w, ci)
     wt = pack.PackedW(torch.randn(ks * ks, co, ci) * 0.05, dev)
     b = torch.randn(co, device=dev)
     r = FMap(torch.randn(h * w, co, device=dev), h, w, co) if res else None
-    out = FMap(torch.empty(h * w, co, device=dev, dtype=torch.bfloat16 if ks == 5 else torch.float32), h, w, co)   # as in the ResBlocks
+    out = FMap(torch.empty(h * w, co, device=dev, dtype=LP if ks == 5 else torch.float32), h, w, co)   # as in the ResBlocks
     for _ in range(3):
         ops.igemm(x, wt, b, co, ksize=ks, stride=st, residual=r, out=out)
     torch.cuda.synchronize()

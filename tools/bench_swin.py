@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Time the two fused Swin-block kernels (attention branch, MLP branch) alone at the 720p lv3 size (180x320 tokens)."""
+"""Time the Swin-block kernels alone at the 720p lv3 size (180x320 tokens): the fused attention branch, the fused MLP
+branch, and the whole block as one persistent kernel.  PREC=bf16|f16 (default f16)."""
 import os
 import sys
 
@@ -12,31 +13,32 @@ from speinet_amd.synth import state_dict_template, synth_state_dict    # noqa: E
 
 H, W = 180, 320
 dev = "cuda:0"
-ops = Ctx("bf16", device=dev)
+ops = Ctx(os.environ.get("PREC", "f16"), device=dev)
+LP = torch.float16 if ops.precision == "f16" else torch.bfloat16
 sd = synth_state_dict(state_dict_template())
 p = "swin.layers.0.residual_group.blocks.1."
 bk = {k: (v.to(dev) if torch.is_tensor(v) else pack.PackedW(v.t, dev)) for k, v in pack.swin_block(sd, p, 8, 5).items()}
 x = torch.randn(H * W, 256, device=dev)
-yhat = torch.randn(H * W, 256, device=dev).bfloat16()
+yhat = torch.randn(H * W, 256, device=dev).to(LP)
 out = torch.empty_like(x)
-for shift in (0, 2):
-    for _ in range(3):
-        ops.attn_fused(x, yhat, bk, H, W, shift, out)
+
+
+def timeit(name, fn, n=30):
+    for _ in range(5):
+        fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(20):
-        ops.attn_fused(x, yhat, bk, H, W, shift, out)
+    for _ in range(n):
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    print(f"attn_fused shift={shift}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us")
-for _ in range(3):
-    ops.mlp_fused(x, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out)
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(20):
-    ops.mlp_fused(x, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out)
-e1.record()
-torch.cuda.synchronize()
-print(f"mlp_fused: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us")
+    print(f"{name:28s} {e0.elapsed_time(e1) / n * 1e3:7.1f} us")
+
+
+for shift in (0, 2):
+    timeit(f"attn_fused shift={shift}", lambda: ops.attn_fused(x, yhat, bk, H, W, shift, out))
+timeit("mlp_fused", lambda: ops.mlp_fused(x, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out))
+for shift in (0, 2):
+    timeit(f"attn + mlp shift={shift}", lambda: ops.mlp_fused(ops.attn_fused(x, yhat, bk, H, W, shift, out), bk["w1"], bk["b1"], bk["w2"], bk["b2"], out))
+    timeit(f"swin_block shift={shift}", lambda: ops.swin_block(x, yhat, bk, H, W, shift, out))

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Where does a fused Swin kernel spend its time?  Needs the tuning build (`python -m speinet_amd.build --tuning`): wave 0 of
+every workgroup stamps s_memtime (100 MHz-independent shader clock ticks) at phase boundaries into a buffer whose address is
+passed through SPEI_STAMP_PTR.  Prints the median per-phase durations in microseconds (at the measured clock) and the spread
+of workgroup start / end times across the launch.
+
+    python tools/stamp_phases.py attn|mlp|block      (block: the first of the three groups of every workgroup)
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+which = sys.argv[1] if len(sys.argv) > 1 else "attn"
+H, W = 180, 320
+dev = "cuda:0"
+torch.cuda.set_device(0)
+nwg = 4096
+stamps = torch.zeros(nwg, 16, dtype=torch.int64, device=dev)
+os.environ["SPEI_STAMP_PTR"] = str(stamps.data_ptr())
+
+from speinet_amd import pack                                            # noqa: E402
+from speinet_amd.ops import Ctx                                         # noqa: E402
+from speinet_amd.synth import state_dict_template, synth_state_dict     # noqa: E402
+
+ops = Ctx("f16", device=dev)
+sd = synth_state_dict(state_dict_template())
+p = "swin.layers.0.residual_group.blocks.1."
+bk = {k: (v.to(dev) if torch.is_tensor(v) else pack.PackedW(v.t, dev)) for k, v in pack.swin_block(sd, p, 8, 5).items()}
+x = torch.randn(H * W, 256, device=dev)
+yhat = torch.randn(H * W, 256, device=dev).half()
+out = torch.empty_like(x)
+
+
+def run():
+    if which == "attn":
+        ops.attn_fused(x, yhat, bk, H, W, 2, out)
+    elif which == "block":
+        ops.swin_block(x, yhat, bk, H, W, 2, out)
+    else:
+        ops.mlp_fused(x, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out)
+
+
+for _ in range(5):
+    run()
+torch.cuda.synchronize()
+stamps.zero_()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+run()
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) * 1e3
+s = stamps.cpu()
+used = s[:, 0] > 0
+s = s[used]
+n = s.shape[0]
+t0 = s[:, 0].min()
+span = (s.max() - t0).item()
+tick_us = 0.01               # s_memrealtime: 100 MHz reference clock, common to all XCDs
+print(f"{which}: {us:.1f} us by HIP events, {n} workgroups, first-start..last-end {span * tick_us:.1f} us")
+last = max(i for i in range(16) if (s[:, i] > 0).any())
+for i in range(1, last + 1):
+    if not (s[:, i] > 0).any():
+        continue
+    j = max(k for k in range(i) if (s[:, k] > 0).any())
+    d = (s[:, i] - s[:, j]).float() * tick_us
+    print(f"  phase {j}->{i}: median {d.median():7.2f} us   p10 {d.quantile(0.1):7.2f}   p90 {d.quantile(0.9):7.2f}")
+tot = (s[:, last] - s[:, 0]).float() * tick_us
+st = (s[:, 0] - t0).float() * tick_us
+print(f"  workgroup lifetime: median {tot.median():.2f} us (p10 {tot.quantile(0.1):.2f}, p90 {tot.quantile(0.9):.2f}); start times: "
+      f"p25 {st.quantile(0.25):.1f} p50 {st.quantile(0.5):.1f} p75 {st.quantile(0.75):.1f} max {st.max():.1f} us")
