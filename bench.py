@@ -26,6 +26,9 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                  (F = 20.64 TFLOP) against the same peak.  `traffic` / `path_hbm_bytes_per_frame`: HBM bytes from
                  rocprofv3 PMC passes made OFFLINE with tools/pmc_traffic.py (FETCH_SIZE doubled as the guide prescribes for
                  wide coalesced reads on gfx950) and read from profiles/ — `traffic_source` names the file, null if absent.
+  harness        (N = 1, unless --no-harness) end-to-end frames/s of the inference harness (speinet_amd.inference, the counterpart of
+                 inference_SPEINet.py) on a synthetic 720p clip ON DISK: PNG decode, selection, upload, forward with cross-window
+                 encoder reuse, uint8, PSNR / SSIM, PNG encode — what a user of the reference's script gets per frame.
   cpu_baseline   the oracle (CPU restatement of the reference, PyTorch fp32) timed on this host's cores, rank 0, N = 1:
                  ONE 720p frame, no warm-up (about a minute).  If a 360x640 probe predicts more than --cpu-budget seconds
                  the probe itself is reported, scaled by the FLOP formula of BASELINE.md §2 and labelled "extrapolated".
@@ -116,6 +119,7 @@ def main():
     ap.add_argument("--corr-precision", choices=["bf16x3", "single", "top2"], default="top2",
                     help="correlation arg-max when --precision is not f32: top2 = 16-bit pass keeping two candidates + exact "
                          "re-score; single = 16-bit winner; bf16x3 = f32-grade scores (bf16 / bf16x3 only), 2.4x the kernel time")
+    ap.add_argument("--no-harness", action="store_true", help="skip the end-to-end harness measurement (40 frames on disk, ~15 s)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying hipGraph segments")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams for the independent neighbour-frame / reference branches of a frame")
     ap.add_argument("--branch", choices=["bs", "b"], default="bs", help="bs: with sharp reference (SearchTransfer); b: SelfTransfer")
@@ -225,6 +229,11 @@ def main():
                          "path_hbm_frac": (path_hbm * fps / world / 8e12) if path_hbm else None},
             "checksum": float(gathered[:, 0].sum().item()),
         }
+        if world == 1 and not args.no_harness and (h, w) == (H, W) and args.precision != "f32":
+            from speinet_amd.inference import harness_throughput
+            del net, frames
+            torch.cuda.empty_cache()
+            line["harness"] = harness_throughput(40, args.precision)
         mode = "none" if args.no_cpu_baseline else args.cpu_baseline
         if world == 1 and mode != "none":
             line["cpu_baseline"] = cpu_baseline(1234, mode, args.cpu_budget)

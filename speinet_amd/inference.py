@@ -108,18 +108,25 @@ class Logger:
 
 
 class FrameCache:
-    """Decode-once cache of frame files, filled by a thread pool: `request(paths)` schedules decodes, `get(path)` blocks
-    until that file is decoded.  Bounded LRU (a 720p RGB frame is 2.8 MB)."""
+    """Decode-once, upload-once cache of frame files.  `request(paths)` schedules decodes on the thread pool, `get(path)`
+    blocks until that file is decoded (host uint8 [H,W,3]); `get_dev(path)` returns the frame on the device, uploaded once
+    however many windows share it (a frame is a neighbour twice, a middle frame once and often a reference).  Uploads go
+    through a small ring of page-locked staging buffers allocated once: a copy from pageable memory makes the host wait for
+    everything queued on the stream before it (one full GPU drain per window), and allocating page-locked memory per frame
+    synchronises the device.  Bounded LRUs (a 720p RGB frame is 2.8 MB)."""
+    RING = 8
 
-    def __init__(self, pool: ThreadPoolExecutor, capacity: int = 96):
-        self.pool, self.capacity = pool, capacity
+    def __init__(self, pool: ThreadPoolExecutor, capacity: int = 96, device=None):
+        self.pool, self.capacity, self.device = pool, capacity, device
         self.items: "collections.OrderedDict[str, Future]" = collections.OrderedDict()
+        self.dev: "collections.OrderedDict[str, torch.Tensor]" = collections.OrderedDict()
+        self._ring, self._events, self._n = [], [], 0
 
     def request(self, paths) -> None:
         for p in paths:
             if p in self.items:
                 self.items.move_to_end(p)
-            else:
+            elif p not in self.dev:
                 self.items[p] = self.pool.submit(_imread, p)
         while len(self.items) > self.capacity:
             self.items.popitem(last=False)
@@ -127,6 +134,33 @@ class FrameCache:
     def get(self, path: str) -> np.ndarray:
         self.request([path])
         return self.items[path].result()
+
+    def _upload(self, arr: np.ndarray) -> torch.Tensor:
+        n = arr.size
+        if not self._ring or self._ring[0].numel() < n:
+            self._ring = [torch.empty(n, dtype=torch.uint8, pin_memory=True) for _ in range(self.RING)]
+            self._events = [None] * self.RING
+        i = self._n % self.RING
+        self._n += 1
+        if self._events[i] is not None:
+            self._events[i].synchronize()                 # the copy issued RING uploads ago: long finished
+        stage = self._ring[i][:n].view(arr.shape)
+        stage.numpy()[...] = arr
+        t = stage.to(self.device, non_blocking=True)
+        self._events[i] = torch.cuda.Event()
+        self._events[i].record()
+        return t
+
+    def get_dev(self, path: str) -> torch.Tensor:
+        t = self.dev.get(path)
+        if t is None:
+            self.request([path])
+            t = self.dev[path] = self._upload(self.items.pop(path).result())
+            while len(self.dev) > self.capacity:
+                self.dev.popitem(last=False)
+        else:
+            self.dev.move_to_end(path)
+        return t
 
 
 class Inference:
@@ -184,7 +218,7 @@ class Inference:
         lengths = [len(glob.glob(os.path.join(a.data_path, "blur", c, "*"))) for c in clips]
         mine = shard_clips_by_length(lengths, self.world)[self.rank]
         stats = torch.zeros(3, dtype=torch.float64)             # sum psnr, sum ssim, frames
-        cache = FrameCache(self.io_pool)
+        cache = FrameCache(self.io_pool, device=self.device)
         with torch.no_grad():
             for ci in mine:
                 clip = clips[ci]
@@ -208,20 +242,26 @@ class Inference:
                         self.logger.write_log('> {}-{} PSNR={:.5}, SSIM={:.4} pre_time:{:.3}s, forward_time:{:.3}s, post_time:{:.3}s, total_time:{:.3}s'
                                               .format(clip, name, psnr, ssim, t_pre, t_fwd, t_post, t_pre + t_fwd + t_post))
 
+                inflight = collections.deque()                  # one event per enqueued window
                 for k, (w, gseq) in enumerate(zip(wins, gt_seqs)):
+                    # keep the host at most two windows ahead of the GPU: enough slack to hide its own work, and a worker that
+                    # fetches a finished frame waits ~2 windows, not the whole queue (the post pool would otherwise spend its
+                    # time blocked on results instead of encoding PNGs)
+                    if len(inflight) >= 2:
+                        inflight.popleft().synchronize()
                     t0 = time.time()
                     for ahead in needs[k:k + 1 + self.prefetch]:
                         cache.request(ahead)
-                    imgs = [cache.get(p) for p in needs[k]]
+                    imgs = [cache.get_dev(p) for p in needs[k]]            # uint8 [H,W,3] on the device, uploaded once per file
                     gt = imgs.pop()
                     h, wd = imgs[self.n_seq // 2].shape[:2]
                     nh, nw = h - h % 20, wd - wd % 20           # the model needs multiples of 20 (reference crops to 4)
                     imgs = [im[:nh, :nw] for im in imgs]
                     if w["zero_pre"]:
-                        imgs[-2] = np.zeros_like(imgs[-2])
+                        imgs[-2] = torch.zeros_like(imgs[-2])
                     if w["zero_sub"]:
-                        imgs[-1] = np.zeros_like(imgs[-1])
-                    x = selection.numpy2tensor_device(imgs, self.device)
+                        imgs[-1] = torch.zeros_like(imgs[-1])
+                    x = selection.uint8_frames_to_input(imgs)
                     t1 = time.time()
                     if a.reuse:
                         keys = list(needs[k][:self.n_seq]) + [("zero", nh, nw) if w["zero_pre"] else w["pre"],
@@ -230,8 +270,12 @@ class Inference:
                     else:
                         out = self.net(x, routing=[bool(w["zero_pre"])])
                     out_u8 = out.mul(255.0).clamp(0, 255).round()[0].to(torch.uint8).permute(1, 2, 0).contiguous()   # = tensor2numpy, on the GPU
-                    gt_u8 = torch.from_numpy(gt[:nh, :nw].copy()).to(self.device, non_blocking=True)
+                    gt_u8 = gt[:nh, :nw]
                     psnr, ssim = metrics_gpu(out_u8[4:-4, 4:-4], gt_u8[4:-4, 4:-4])     # border crop: inference_SPEINet.py:405-410
+                    if self.device.type == "cuda":
+                        ev = torch.cuda.Event()
+                        ev.record()
+                        inflight.append(ev)
                     t2 = time.time()
                     save_to = os.path.join(a.result_path, clip, w["name"] + ".png") if a.save_image else ""
                     pending.append((w["name"], self.post_pool.submit(self._post, out_u8, psnr, ssim, save_to), t1 - t0, t2 - t1, t0))
@@ -247,6 +291,53 @@ class Inference:
         if self.rank == 0 and tot[2] > 0:
             self.logger.write_log("# Total AVG-PSNR={:.5}, AVG-SSIM={:.4}".format(tot[0].item() / tot[2].item(), tot[1].item() / tot[2].item()))
         return tot
+
+
+def synth_clip(root: str, n: int = 40, h: int = 720, w: int = 1280, seed: int = 5) -> str:
+    """Write a synthetic n-frame clip in the reference's data layout (<root>/data/{blur,gt}/clip0/%06d.png + label/clip0.npy,
+    every 6th frame labelled sharp) and return <root>/data: the input of `harness_throughput` and of tools/harness_bench.py."""
+    from PIL import Image
+    from .synth import synth_frames
+    x = synth_frames(1, h, w, seed=seed)[0]
+    for sub in ("blur", "gt"):
+        os.makedirs(os.path.join(root, "data", sub, "clip0"), exist_ok=True)
+    for i in range(n):
+        img = (torch.roll(x[i % 5], shifts=(3 * i, -5 * i), dims=(1, 2)).permute(1, 2, 0).numpy() * 255).round().astype(np.uint8)
+        for sub in ("blur", "gt"):
+            Image.fromarray(img).save(os.path.join(root, "data", sub, "clip0", f"{i:06d}.png"), compress_level=1)
+    os.makedirs(os.path.join(root, "data", "label"), exist_ok=True)
+    np.save(os.path.join(root, "data", "label", "clip0.npy"), np.asarray([1 if i % 6 == 0 else 0 for i in range(n)]))
+    return os.path.join(root, "data")
+
+
+def harness_throughput(frames: int = 40, precision: str = "f16", h: int = 720, w: int = 1280) -> dict:
+    """End-to-end frames/s of this harness on a synthetic clip ON DISK: PNG decode -> selection -> upload -> forward (with
+    cross-window encoder reuse) -> uint8 -> PSNR / SSIM -> PNG encode, everything the reference's loop does per frame
+    (inference_SPEINet.py:364-429).  One untimed pass first (graph capture, page cache), then one timed pass."""
+    import re
+    import shutil
+    import tempfile
+    root = tempfile.mkdtemp(prefix="speinet_clip_")
+    try:
+        data = synth_clip(root, frames, h, w)
+        a = build_args(["--data_path", data, "--model_path", "synthetic", "--result_path", os.path.join(root, "res"), "--precision", precision])
+        inf = Inference(a)
+        inf.logger.echo = False
+        inf.infer()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        tot = inf.infer()
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        n = int(tot[2])
+        lines = [ln for f in glob.glob(os.path.join(root, "res", "inference_log*")) for ln in open(f) if ln.startswith(">")][-n:]
+        mean = lambda key: sum(float(re.search(key + r":([\d.e-]+)s", ln).group(1)) for ln in lines) / max(1, len(lines))
+        return {"value": n / dt, "unit": "frames/s", "frames": n, "seconds": dt, "precision": precision,
+                "mean_ms": {k: 1e3 * mean(k) for k in ("pre_time", "forward_time", "post_time")},
+                "what": f"speinet_amd.inference on a synthetic {w}x{h} clip on disk, PNG decode/encode, PSNR and SSIM included, "
+                        "cross-window encoder reuse on"}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 PRESETS = {   # inference_SPEINet.py:626-697 (paths only fill in what the command line left at its default)

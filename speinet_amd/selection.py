@@ -126,6 +126,11 @@ def numpy2tensor_device(images: Sequence[np.ndarray], device, rgb_range: float =
     return u8.permute(0, 3, 1, 2).float().mul_(rgb_range / 255).unsqueeze(0).contiguous()
 
 
+def uint8_frames_to_input(frames: Sequence[torch.Tensor], rgb_range: float = 1.0) -> torch.Tensor:
+    """Device-side `numpy2tensor`: uint8 [H,W,3] frames already on the device -> [1, n, 3, H, W] float32 (same values)."""
+    return torch.stack(list(frames)).permute(0, 3, 1, 2).float().mul_(rgb_range / 255).unsqueeze(0).contiguous()
+
+
 def tensor2numpy(t: torch.Tensor, rgb_range: float = 1.0) -> np.ndarray:
     img = t.mul(255 / rgb_range).clamp(0, 255).round()[0]
     return np.transpose(img.cpu().numpy(), (1, 2, 0)).astype(np.uint8)

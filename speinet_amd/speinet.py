@@ -326,19 +326,25 @@ class SPEINet(nn.Module):
         n, mid = self.n_sequence, self.n_sequence // 2
         tag = (h, w) + self._mode_key(x.device)
 
+        # the per-frame encoder pieces: eager launches, or (use_graph) one captured graph per piece and frame shape — a new
+        # frame then costs three replays instead of ~150 launches from Python (the harness was host-bound on them)
+        G = self._graphed if self.use_graph else (lambda name, ins, fn: fn(*ins))
+
         def raw(i):
-            return cache.get((tag, keys[i], "raw")) or cache.put((tag, keys[i], "raw"), engine.encode_raw(ctx, x[0, i], P))
+            return cache.get((tag, keys[i], "raw")) or cache.put(
+                (tag, keys[i], "raw"), G(("raw", h, w), [x[0, i]], lambda fr: [engine.encode_raw(ctx, fr, P)])[0])
 
         def summed(i, iters):
             k = (tag, keys[i], iters)
-            return cache.get(k) or cache.put(k, engine.encode_sum(ctx, x[0, i], iters, raw(i), P))
+            return cache.get(k) or cache.put(
+                k, G(("sum", iters, h, w), [x[0, i], raw(i)], lambda fr, e: [engine.encode_sum(ctx, fr, iters, e, P)])[0])
 
         f_mid = summed(mid, 5)
         feats = [summed(i, 1) for i in range(n) if i != mid]
         lv = None
         if not zero_ref:
             k = (tag, keys[n + 1], "ref")
-            lv = cache.get(k) or cache.put(k, engine.reference_pyramid(ctx, x[0, n + 1], P))
+            lv = cache.get(k) or cache.put(k, tuple(G(("pyr", h, w), [x[0, n + 1]], lambda fr: list(engine.reference_pyramid(ctx, fr, P)))))
         out = torch.empty(1, 3, h, w, device=x.device, dtype=torch.float32)
         if not self.use_graph:
             engine.fuse_and_decode(ctx, f_mid, feats, lv, P, n, out[0], sides)
@@ -365,8 +371,7 @@ class SPEINet(nn.Module):
             with torch.cuda.graph(g2, pool=g1.pool()):
                 for _ in steps:
                     raise RuntimeError("fuse_and_decode_steps yielded twice")
-            if len(self._graphs) >= 4:
-                self._graphs.clear()
+            self._trim_graphs()
             g = self._graphs[gkey] = ((g1, plan, g2), s_mid, s_feats, s_lv, s_out)
         (g1, plan, g2), s_mid, s_feats, s_lv, s_out = g
         s_mid.t.copy_(f_mid.t)
@@ -379,6 +384,37 @@ class SPEINet(nn.Module):
         plan.launch()
         g2.replay()
         return s_out.clone()
+
+    def _trim_graphs(self, limit: int = 12) -> None:
+        if len(self._graphs) >= limit:
+            self._graphs.clear()
+
+    def _graphed(self, name: tuple, inputs: list, fn) -> list:
+        """`fn(*inputs) -> [FMap, ...]` through a hipGraph captured once per (name, mode): inputs (tensors or FMaps) are copied
+        into the graph's static buffers, the outputs are returned as fresh copies (they go into the caller's cache)."""
+        from .ops import FMap
+        dev = inputs[0].device if torch.is_tensor(inputs[0]) else inputs[0].t.device
+        key = ("piece",) + name + self._mode_key(dev)
+        buf = lambda v: v if torch.is_tensor(v) else v.t
+        g = self._graphs.get(key)
+        if g is None:
+            clone = lambda v: v.clone() if torch.is_tensor(v) else FMap(v.t.clone(), v.H, v.W, v.C, v.off)
+            s_in = [clone(v) for v in inputs]
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):           # warm-up off the capture
+                fn(*s_in)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                s_out = fn(*s_in)
+            self._trim_graphs()
+            g = self._graphs[key] = (graph, s_in, s_out)
+        graph, s_in, s_out = g
+        for d, v in zip(s_in, inputs):
+            buf(d).copy_(buf(v))
+        graph.replay()
+        return [FMap(f.t.clone(), f.H, f.W, f.C, f.off) for f in s_out]
 
     def _forward_graph(self, ctx: ops.Ctx, x: torch.Tensor, P: dict, zero_ref: list, profile: Optional[dict] = None) -> torch.Tensor:
         """Replay the ~1500 launches of a frame as hipGraphs (captured once per shape / routing / precision): the per-launch
@@ -412,8 +448,7 @@ class SPEINet(nn.Module):
                     for _ in steps:                 # resumes after the yield; there is no second one
                         raise RuntimeError("forward_sample_steps yielded twice")
                 segs.append((g1, plan, g2))
-            if len(self._graphs) >= 4:
-                self._graphs.clear()
+            self._trim_graphs()
             g = self._graphs[key] = (segs, static_x, static_out)
         segs, static_x, static_out = g
         static_x.copy_(x)
