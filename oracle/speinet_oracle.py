@@ -391,6 +391,25 @@ def forward(x: torch.Tensor, sd: SD, cfg: Cfg = Cfg()) -> torch.Tensor:
     return out
 
 
+def forward_swint(x: torch.Tensor, sd: SD, cfg: Cfg = Cfg()) -> torch.Tensor:
+    """The `swint` variant, ``model/swint.py:51-67``: encoders without the RL prior, swin(f_mid, f_i) per neighbour frame,
+    the 1x1 ``conv`` over the concatenation (n_sequence == 1: f_mid + swin(f_mid, f_mid)), then the plain decoder
+    outBlock(decoder_first(decoder_second(.))).  x [B, >= n_sequence, 3, H, W] -> [B, 3, H, W]."""
+    n = cfg.n_sequence
+    f_mid = enc(x[:, n // 2], sd, cfg)
+    f_fusion = f_mid
+    for i in range(n):
+        if i == n // 2:
+            continue
+        f_fusion = torch.cat((f_fusion, swin(f_mid, enc(x[:, i], sd, cfg), sd, cfg)), dim=1)
+    if n == 1:
+        f_fusion = f_fusion + swin(f_mid, f_mid, sd, cfg)
+    f = _c(f_fusion, sd, "conv")
+    f = _dec_stage(f, sd, "recons_net.decoder_second.", cfg.n_resblock)
+    f = _dec_stage(f, sd, "recons_net.decoder_first.", cfg.n_resblock)
+    return out_block(f, sd, cfg)
+
+
 # --------------------------------------------------------------------------------------------
 # metric helpers used by the harness (inference_SPEINet.py:477-500)
 # --------------------------------------------------------------------------------------------

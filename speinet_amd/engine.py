@@ -306,3 +306,42 @@ def fuse_and_decode_steps(ctx: Ctx, f_mid: FMap, feats: list, lv, P: dict, n_seq
     for s_ in lanes[1:]:
         main.wait_stream(s_)
     yield from _tail(ctx, cat, lv, P, out)
+
+
+# ---- the `swint` variant (reference model/swint.py:51-67) ---------------------------------------------------------------------
+def forward_swint(ctx: Ctx, x: torch.Tensor, P: dict, n_seq: int, out: torch.Tensor, sides=()) -> torch.Tensor:
+    """x [>= n_seq, 3, H, W] -> out [3, H, W]: encoders without the RL prior, one swin call per neighbour frame, the 1x1
+    `conv` over the concatenation, then the plain decoder (no SearchTransfer).  n_seq == 1: f_mid + swin(f_mid, f_mid)."""
+    h, w = x.shape[-2:]
+    h3, w3 = h // 4, w // 4
+    dev = x.device
+    lanes = _lanes(ctx, sides)
+    main = lanes[0]
+    for s_ in lanes[1:]:
+        s_.wait_stream(main)
+    cat = FMap(torch.empty(h3 * w3, 128 * n_seq, device=dev), h3, w3, 128 * n_seq)
+    f_mid = enc(ctx, x[n_seq // 2], P, out=cat.view(0, 128))
+    sx = SwinX(ctx, f_mid, P["swin"])
+    if n_seq == 1:
+        f_trans = FMap.empty(h3, w3, 128, dev)
+        swin(ctx, sx, f_mid, P["swin"], out=f_trans)
+        cat = FMap(ctx.add(f_mid.t, f_trans.t), h3, w3, 128)
+    else:
+        ready = torch.cuda.Event()
+        ready.record(main)
+        for slot, i in enumerate([i for i in range(n_seq) if i != n_seq // 2], start=1):
+            lane = lanes[(slot - 1) % len(lanes)]
+            if lane is not main:
+                lane.wait_event(ready)
+            with torch.cuda.stream(lane):
+                swin(ctx, sx, enc(ctx, x[i], P), P["swin"], out=cat.view(128 * slot, 128))
+        for s_ in lanes[1:]:
+            main.wait_stream(s_)
+    fw = P["conv"]
+    ff = ctx.igemm(cat, fw["w"], fw["b"], 128)
+    dctx = ctx.for_stage("decode")
+    dec1 = dec_stage(dctx, dec_stage(dctx, ff, P["decoder_second"]), P["decoder_first"])
+    ob = P["outBlock"]
+    octx = dctx.for_stage("out")
+    f = _resblocks(octx, dec1, ob["blocks"])
+    return octx.for_stage("tail").conv5_out(f, ob["tail_w"], ob["tail_b"], out, ob.get("tail_w32"), ob.get("tail_b32"))

@@ -139,8 +139,38 @@ def swin_block(sd: SD, p: str, heads: int, ws: int) -> dict:
     }
 
 
+def _to_device(o, device):
+    if isinstance(o, GemmW):
+        return PackedW(o.t, device)
+    if torch.is_tensor(o):
+        return o.detach().to(device=device, dtype=torch.float32).contiguous()
+    if isinstance(o, dict):
+        return {k: _to_device(v, device) for k, v in o.items()}
+    if isinstance(o, list):
+        return [_to_device(v, device) for v in o]
+    return o
+
+
+def pack_swint(sd: SD, cfg, device) -> dict:
+    """Packed tensors of the `swint` variant (reference model/swint.py): the same encoder / decoder stacks and SwinIR, one
+    1x1 fusion conv named `conv`, no SearchTransfer glue."""
+    out = _pack_common(sd, cfg)
+    out["conv"] = {"w": G(conv_w(sd["conv.weight"])), "b": sd["conv.bias"]}
+    return _to_device(out, device)
+
+
 def pack_all(sd: SD, cfg, device) -> dict:
-    """Every packed tensor the forward pass needs, on `device`, fp32 contiguous."""
+    """Every packed tensor the SPEINet forward pass needs, on `device`, fp32 contiguous."""
+    out = _pack_common(sd, cfg)
+    for name in ("conv_lv1", "conv_lv2", "conv_lv3", "fusion", "search1", "search2", "search3", "search13", "search33", "search43"):
+        out[name] = {"w": G(conv_w(sd[name + ".weight"])), "b": sd[name + ".bias"]}
+    for name in ("search1", "search2"):
+        out["SelfTransfer." + name] = {"w": G(conv_w(sd[f"SelfTransfer.{name}.weight"])), "b": sd[f"SelfTransfer.{name}.bias"]}
+    return _to_device(out, device)
+
+
+def _pack_common(sd: SD, cfg) -> dict:
+    """recons_net stacks + SwinIR (shared by model/speinet.py and model/swint.py), still on the host side."""
     out: dict = {}
     nrb = cfg.n_resblock
 
@@ -170,11 +200,6 @@ def pack_all(sd: SD, cfg, device) -> dict:
     d["tail_b32"] = torch.cat((d["tail_b"], torch.zeros(29, dtype=d["tail_b"].dtype, device=d["tail_b"].device)))
     out["outBlock"] = d
 
-    for name in ("conv_lv1", "conv_lv2", "conv_lv3", "fusion", "search1", "search2", "search3", "search13", "search33", "search43"):
-        out[name] = {"w": G(conv_w(sd[name + ".weight"])), "b": sd[name + ".bias"]}
-    for name in ("search1", "search2"):
-        out["SelfTransfer." + name] = {"w": G(conv_w(sd[f"SelfTransfer.{name}.weight"])), "b": sd[f"SelfTransfer.{name}.bias"]}
-
     r = float(cfg.rgb_range)
     sw = {
         "conv_first_w": G(conv_w(sd["swin.conv_first.weight"] * r)), "conv_first_b": sd["swin.conv_first.bias"],
@@ -191,16 +216,4 @@ def pack_all(sd: SD, cfg, device) -> dict:
             "conv_w": G(conv_w(sd[p + "conv.weight"])), "conv_b": sd[p + "conv.bias"],
         })
     out["swin"] = sw
-
-    def to_dev(o):
-        if isinstance(o, GemmW):
-            return PackedW(o.t, device)
-        if torch.is_tensor(o):
-            return o.detach().to(device=device, dtype=torch.float32).contiguous()
-        if isinstance(o, dict):
-            return {k: to_dev(v) for k, v in o.items()}
-        if isinstance(o, list):
-            return [to_dev(v) for v in o]
-        return o
-
-    return to_dev(out)
+    return out

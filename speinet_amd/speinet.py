@@ -180,7 +180,11 @@ class SPEINet(nn.Module):
         if args is None:
             args = default_args()
         if in_channels != 3 or out_channels != 3 or n_feat != 32 or n_sequence != 3:
-            raise ValueError("speinet_amd builds the published configuration: 3 colours, n_feat=32, n_sequence=3")
+            # n_sequence == 1 (reference model/speinet.py:87-89) cannot run in the reference either: its forward tests frame 3 and
+            # reads the sharp frame at index n_sequence + 1 of an [B, n_sequence + 2, ...] input (:71, :124).  The single-frame
+            # form that does run is model/swint.py with n_sequence = 1 -> speinet_amd.swint.
+            raise ValueError("speinet_amd builds the published configuration: 3 colours, n_feat=32, n_sequence=3 "
+                             "(n_sequence 1 / 5: see speinet_amd.swint)")
         if args.window_size != 5 or args.embed_dim != 256 or any(h != 8 for h in args.num_heads):
             raise ValueError("speinet_amd kernels are built for window 5, embed_dim 256, 8 heads")
         if getattr(args, "resi_connection", "1conv") != "1conv":
