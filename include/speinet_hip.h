@@ -209,6 +209,35 @@ int spei_upsample_bicubic(const float* in, int ldi, float* out, int ldo, int H, 
 /* K14 — out = a + b over n floats. */
 int spei_add(const float* a, const float* b, float* out, int64_t n, spei_stream_t stream);
 
+/* ---- backward kernels: first slice of the training step (the reference obtains these from torch.autograd
+ * inside trainer/trainer_swint_hsa_nsf.py:34-40 `loss.backward()`).  fp32, fixed-order reductions (bitwise reproducible).
+ * The DATA gradient of a convolution is spei_igemm_f32(mode = SPEI_CONV_TRANSPOSED) on dY with w[t][k][n] = W[t][n][k]. ---- */
+
+/* Weight (and bias) gradient of Conv2d(K -> N, k, stride, pad = k/2) (model/block.py:26-47, recons_video_ori.py:28-71):
+ * dw[t][n][k] = sum_m dy[m][n] * x[src(m,t)][k], dbias[n] = sum_m dy[m][n] (dbias may be NULL).  x [Hin*Win][ldx] NHWC,
+ * dy [Hout*Wout][ldy]; ws: spei_wgrad_ws_floats(...) floats.  N <= 256; K, N need not be multiples of 32. */
+int64_t spei_wgrad_ws_floats(int Hout, int Wout, int N, int K, int ksize);
+int spei_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* ws, int Hin, int Win,
+                        int Hout, int Wout, int N, int K, int ksize, int stride, int pad, spei_stream_t stream);
+
+/* ReLU backward on the output of a fused conv + ReLU: dz = dy where y > 0, else 0 (n floats, n % 4 == 0). */
+int spei_relu_bwd(const float* y, const float* dy, float* dz, int64_t n, spei_stream_t stream);
+
+/* Plane statistics of the ResBlock gates, training form (model/block.py:71-73 ZPool over W and over H, :8-24 SE pooling):
+ * prod == 0: rowmax, rowmean [H][C] (over x), colmax, colmean [W][C] (over y), mean [C] of a [H][W][C];
+ * prod == 1: the plain sums of a * b over x, over y and over the map into rowmean / colmean / mean (rowmax = colmax = NULL):
+ * with a = dOut and b = x1 these are the gradients of g1, g2 and s of out = x + x1 * (s + g1 + g2).
+ * ws: spei_plane_ws_floats(H, W, C) floats.  C in {32, 64, 128}. */
+int64_t spei_plane_ws_floats(int H, int W, int C);
+int spei_plane_stats(const float* a, const float* b, int prod, int H, int W, int C, float* rowmax, float* rowmean, float* colmax,
+                     float* colmean, float* mean, float* ws, spei_stream_t stream);
+
+/* Backward of the gated residual sum through x1 (model/block.py:136-140): dx1 = dOut * (s + g1 + g2) + the pooled statistics'
+ * gradients routed back (means spread evenly, maxima to the arg-max element).  dx = dOut needs no kernel. */
+int spei_resblock_apply_bwd(const float* dout, const float* x1, const float* s, const float* g1, const float* g2, const float* rowmax,
+                            const float* colmax, const float* d_rowmax, const float* d_rowmean, const float* d_colmax,
+                            const float* d_colmean, const float* d_mean, float* dx1, int H, int W, int C, spei_stream_t stream);
+
 /* Row a11 — LD sharpness detector features (inference_SPEINet.py:54-189).  spei_det_gray: [N][3][H][W] fp32 0..255 ->
  * gray [N][H][W] in 0..1 (ITU-R 601 weights).  spei_det_features: gray -> out [N][6] = LAP1, MIS3, WAV1, GRA7, STA3, DCT3
  * with window size k (odd; the reference uses 11).  ws: spei_det_ws_floats(N,H,W,k) floats. */

@@ -53,6 +53,12 @@ SIGNATURES = {
     "spei_rot90": (I, [P, I, P, I, I, I, P]),
     "spei_upsample_bicubic": (I, [P, I, P, I, I, I, I, I, I, P]),
     "spei_add": (I, [P, P, P, L, P]),
+    "spei_wgrad_ws_floats": (L, [I, I, I, I, I]),
+    "spei_conv_wgrad_f32": (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "spei_relu_bwd": (I, [P, P, P, L, P]),
+    "spei_plane_ws_floats": (L, [I, I, I]),
+    "spei_plane_stats": (I, [P, P, I, I, I, I, P, P, P, P, P, P, P]),
+    "spei_resblock_apply_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
     "spei_det_gray": (I, [P, P, I, I, I, P]),
     "spei_det_ws_floats": (L, [I, I, I, I]),
     "spei_det_features": (I, [P, P, P, I, I, I, I, P]),

@@ -1,0 +1,325 @@
+// Backward kernels, first slice of the training step (reference trainer/trainer_swint_hsa_nsf.py:18-51 calls
+// loss.backward() on the same graph): everything the encoder / decoder stacks of recons_net need — convolution weight and
+// bias gradients, the ResBlock's gated residual sum backward and the statistics its gates are built from.  fp32 throughout
+// (gradients are compared with the reference's fp32 autograd); every reduction is two-stage with a fixed combination order, so
+// gradients are bitwise reproducible run to run.  The data gradient of a convolution needs no kernel of its own: it is the
+// transposed convolution spei_igemm_f32(mode = SPEI_CONV_TRANSPOSED) of dY with the weights' last two axes swapped.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// conv weight gradient:  dW[t][n][k] = sum_m dY[m][n] * X[src(m, t)][k]     (m = output pixel, zero outside the input map)
+// One 32 x 32 tile of one tap per workgroup and pixel chunk on v_mfma_f32_32x32x2_f32: A = dY^T (row n, reduction index =
+// pixel), B = X (reduction index = pixel, column k).  Both operands are read straight from global memory: a lane reads one
+// float of a pixel row, 32 consecutive lanes one 128-byte row segment.
+// ---------------------------------------------------------------------------------------------------------------------
+struct WgradParams {
+    const float* x;
+    const float* dy;
+    float* part;          // [nchunks][T][N][K]
+    int ldx, ldy, K, N, Hin, Win, Hout, Wout, ks, stride, pad, chunk_px, ntn, ntk;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+    __shared__ float red[4][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fk = lane >> 5;
+    int tile = blockIdx.x;
+    const int kt = tile % p.ntk; tile /= p.ntk;
+    const int nt = tile % p.ntn;
+    const int t = tile / p.ntn;
+    const int ty = t / p.ks, tx = t - ty * p.ks;
+    const int n = nt * 32 + fr, k = kt * 32 + fr;
+    const int M = p.Hout * p.Wout;
+    const int c0 = blockIdx.y * p.chunk_px;
+    const int per_wave = p.chunk_px / 4;                    // chunk_px is a multiple of 8
+    const int m0 = c0 + wave * per_wave, m1 = min(M, m0 + per_wave);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    int m = m0 + fk;
+    int oy = m / p.Wout, ox = m - oy * p.Wout;
+    for (int mm = m0; mm < m1; mm += 2) {
+        float a = 0.f, b = 0.f;
+        if (m < m1) {
+            if (n < p.N) a = p.dy[(size_t)m * p.ldy + n];
+            const int iy = oy * p.stride - p.pad + ty, ix = ox * p.stride - p.pad + tx;
+            if (k < p.K && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) b = p.x[((size_t)iy * p.Win + ix) * p.ldx + k];
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        m += 2;
+        ox += 2;
+        while (ox >= p.Wout) { ox -= p.Wout; ++oy; }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    if (wave == 0) {
+        const int T = p.ks * p.ks;
+        float* dst = p.part + (((size_t)blockIdx.y * T + t) * p.N) * p.K;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
+            const int row = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;       // n
+            if (row < p.N && k < p.K) dst[(size_t)row * p.K + k] = v;
+        }
+    }
+}
+
+// out[i] = sum over `nparts` partials, fixed order
+__global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t count, int nparts) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.f;
+    for (int c = 0; c < nparts; ++c) s += part[(size_t)c * count + i];
+    out[i] = s;
+}
+
+// column sums of a [M][ld] matrix (bias gradient): part[chunk][n]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ y, int ld, int N, int64_t M, int rows_per_block,
+                                                     float* __restrict__ part) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const int tpr = N < 256 ? N : 256;                    // threads per row (N <= 256)
+    const int rsub = tid / tpr, c = tid - rsub * tpr, rpp = 256 / tpr;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    float s = 0.f;
+    if (rsub < rpp)
+        for (int64_t r = r0 + rsub; r < r1; r += rpp) s += y[r * ld + c];
+    red[tid] = (rsub < rpp) ? s : 0.f;
+    __syncthreads();
+    if (tid < tpr) {
+        float a = 0.f;
+        for (int j = 0; j < rpp; ++j) a += red[j * tpr + tid];
+        part[(size_t)blockIdx.x * N + tid] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ReLU backward on a fused conv + ReLU output:  dz = dy where y > 0 else 0
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dz, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 a = reinterpret_cast<const float4*>(y)[i], d = reinterpret_cast<const float4*>(dy)[i];
+    reinterpret_cast<float4*>(dz)[i] = make_float4(a.x > 0.f ? d.x : 0.f, a.y > 0.f ? d.y : 0.f, a.z > 0.f ? d.z : 0.f, a.w > 0.f ? d.w : 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ResBlock gate statistics for training (model/block.py:71-73 ZPool, :8-24 SE pooling), and the sums its backward needs.
+//   stats:   rowmax / rowmean [H][C] over x, colmax / colmean [W][C] over y, mean [C] of a = x1              (PROD = false)
+//   bwd:     rowsum [H][C], colsum [W][C], total [C] of a * b  (a = dOut, b = x1: the gradients of g1, g2 and s)  (PROD = true)
+// Stage 1: a block owns an R x 64-pixel... tile of TR rows x TC columns, threads = channels x columns; stage 2 combines the tile
+// partials in a fixed order.  C <= 128, C % 4 == 0.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int GT = 32;        // tile rows = tile columns
+
+template <bool PROD>
+__global__ __launch_bounds__(256) void plane_stats_kernel(const float* __restrict__ a, const float* __restrict__ b, int H, int W, int C,
+                                                          float* __restrict__ rowp_max, float* __restrict__ rowp_sum,
+                                                          float* __restrict__ colp_max, float* __restrict__ colp_sum, int ntx, int nty) {
+    // thread -> (channel c, column group): with C channels, 256 / C columns are processed side by side
+    const int tid = threadIdx.x;
+    const int c = tid % C, cg = tid / C, ncg = 256 / C;
+    const int tx = blockIdx.x % ntx, ty = blockIdx.x / ntx;
+    const int x0 = tx * GT, y0 = ty * GT;
+    __shared__ float smax[256], ssum[256];
+    // column partials: each thread owns columns x0 + cg, x0 + cg + ncg, ... ; row partials need a cross-thread combine per row
+    for (int xx = cg; xx < GT; xx += ncg) {
+        const int x = x0 + xx;
+        float cm = -INFINITY, cs = 0.f;
+        if (x < W)
+            for (int yy = 0; yy < GT && y0 + yy < H; ++yy) {
+                const size_t o = ((size_t)(y0 + yy) * W + x) * C + c;
+                const float v = PROD ? a[o] * b[o] : a[o];
+                cm = fmaxf(cm, v);
+                cs += v;
+            }
+        if (x < W) {
+            if (!PROD) colp_max[((size_t)ty * W + x) * C + c] = cm;
+            colp_sum[((size_t)ty * W + x) * C + c] = cs;
+        }
+    }
+    for (int yy = 0; yy < GT; ++yy) {
+        const int y = y0 + yy;
+        float rm = -INFINITY, rs = 0.f;
+        if (y < H)
+            for (int xx = cg; xx < GT && x0 + xx < W; xx += ncg) {
+                const size_t o = ((size_t)y * W + x0 + xx) * C + c;
+                const float v = PROD ? a[o] * b[o] : a[o];
+                rm = fmaxf(rm, v);
+                rs += v;
+            }
+        smax[tid] = rm;
+        ssum[tid] = rs;
+        __syncthreads();
+        if (cg == 0 && y < H) {
+            float m = smax[c], s = ssum[c];
+            for (int j = 1; j < ncg; ++j) { m = fmaxf(m, smax[j * C + c]); s += ssum[j * C + c]; }
+            if (!PROD) rowp_max[((size_t)tx * H + y) * C + c] = m;
+            rowp_sum[((size_t)tx * H + y) * C + c] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// stage 2: lines [L][C] from `nt` partials [nt][L][C]; scale applied to the sum (1/W for a mean, 1 for a plain sum)
+__global__ __launch_bounds__(256) void plane_combine_kernel(const float* __restrict__ pmax, const float* __restrict__ psum, int nt, int64_t LC,
+                                                            float scale, float* __restrict__ omax, float* __restrict__ osum) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= LC) return;
+    float m = -INFINITY, s = 0.f;
+    for (int k = 0; k < nt; ++k) {
+        if (pmax) m = fmaxf(m, pmax[(size_t)k * LC + i]);
+        s += psum[(size_t)k * LC + i];
+    }
+    if (omax) omax[i] = m;
+    osum[i] = s * scale;
+}
+
+// total[c] = scale * sum over lines of line_sum[l][c]   (one block, fixed order)
+__global__ __launch_bounds__(256) void lines_total_kernel(const float* __restrict__ lines, int L, int C, float scale, float* __restrict__ total) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x, c = tid % C, g = tid / C, ng = 256 / C;
+    float s = 0.f;
+    for (int l = g; l < L; l += ng) s += lines[(size_t)l * C + c];
+    red[tid] = s;
+    __syncthreads();
+    if (g == 0) {
+        float a = 0.f;
+        for (int j = 0; j < ng; ++j) a += red[j * C + c];
+        total[c] = a * scale;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// gated residual sum backward:  out = x + x1 * (s[c] + g1[y][c] + g2[x][c])
+//   dx1 = dOut * (s + g1 + g2)
+//       + d_rowmean[y][c] / W + d_colmean[x][c] / H + d_mean[c] / (H W)                       (mean pools)
+//       + d_rowmax[y][c] [x1 == rowmax[y][c]] + d_colmax[x][c] [x1 == colmax[x][c]]           (max pools: the arg-max element)
+// (dx = dOut is the caller's tensor itself.)
+// ---------------------------------------------------------------------------------------------------------------------
+struct ApplyBwdParams {
+    const float *dout, *x1, *s, *g1, *g2, *rowmax, *colmax, *d_rowmax, *d_rowmean, *d_colmax, *d_colmean, *d_mean;
+    float* dx1;
+    int H, W, C;
+};
+
+__global__ __launch_bounds__(256) void resblock_apply_bwd_kernel(const ApplyBwdParams p) {
+    const int cg = p.C / 4;
+    const int64_t total = (int64_t)p.H * p.W * cg;
+    const float iw = 1.0f / (float)p.W, ih = 1.0f / (float)p.H, ihw = 1.0f / ((float)p.H * (float)p.W);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % cg) * 4;
+        const int64_t pix = i / cg;
+        const int x = (int)(pix % p.W), y = (int)(pix / p.W);
+        const size_t o = pix * p.C + c, ro = (size_t)y * p.C + c, co = (size_t)x * p.C + c;
+        const f32x4 d = *reinterpret_cast<const f32x4*>(p.dout + o), v = *reinterpret_cast<const f32x4*>(p.x1 + o);
+        const f32x4 gate = *reinterpret_cast<const f32x4*>(p.s + c) + (*reinterpret_cast<const f32x4*>(p.g1 + ro) + *reinterpret_cast<const f32x4*>(p.g2 + co));
+        f32x4 r = d * gate + *reinterpret_cast<const f32x4*>(p.d_rowmean + ro) * iw + *reinterpret_cast<const f32x4*>(p.d_colmean + co) * ih +
+                  *reinterpret_cast<const f32x4*>(p.d_mean + c) * ihw;
+        const f32x4 rm = *reinterpret_cast<const f32x4*>(p.rowmax + ro), cm = *reinterpret_cast<const f32x4*>(p.colmax + co);
+        const f32x4 drm = *reinterpret_cast<const f32x4*>(p.d_rowmax + ro), dcm = *reinterpret_cast<const f32x4*>(p.d_colmax + co);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (v[e] == rm[e]) r[e] += drm[e];
+            if (v[e] == cm[e]) r[e] += dcm[e];
+        }
+        *reinterpret_cast<f32x4*>(p.dx1 + o) = r;
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t spei_wgrad_ws_floats(int Hout, int Wout, int N, int K, int ksize) {
+    return (int64_t)64 * ksize * ksize * N * K + 64 * 256;
+}
+
+extern "C" int spei_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* ws, int Hin, int Win,
+                                   int Hout, int Wout, int N, int K, int ksize, int stride, int pad, spei_stream_t stream) {
+    SPEI_REQUIRE(x && dy && dw && ws, "spei_conv_wgrad_f32: null pointer");
+    SPEI_REQUIRE(N > 0 && K > 0 && N <= 256 && ldx >= K && ldy >= N, "spei_conv_wgrad_f32: N=%d K=%d ldx=%d ldy=%d", N, K, ldx, ldy);
+    SPEI_REQUIRE(ksize == 1 || ksize == 3 || ksize == 5, "spei_conv_wgrad_f32: ksize=%d", ksize);
+    SPEI_REQUIRE(stride == 1 || stride == 2, "spei_conv_wgrad_f32: stride=%d", stride);
+    SPEI_REQUIRE(Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && (int64_t)Hout * Wout < (1ll << 30), "spei_conv_wgrad_f32: bad map size");
+    SPEI_REQUIRE(Hout == (Hin + 2 * pad - ksize) / stride + 1 && Wout == (Win + 2 * pad - ksize) / stride + 1,
+                 "spei_conv_wgrad_f32: output size %dx%d inconsistent with input %dx%d k%d s%d p%d", Hout, Wout, Hin, Win, ksize, stride, pad);
+    hipStream_t st = (hipStream_t)stream;
+    const int M = Hout * Wout, T = ksize * ksize;
+    WgradParams p;
+    p.x = x; p.dy = dy; p.part = ws; p.ldx = ldx; p.ldy = ldy; p.K = K; p.N = N;
+    p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout; p.ks = ksize; p.stride = stride; p.pad = pad;
+    int chunk = cdiv(M, 64);
+    chunk = ((chunk + 7) / 8) * 8;
+    if (chunk < 64) chunk = 64;
+    p.chunk_px = chunk;
+    const int nchunks = cdiv(M, chunk);
+    p.ntn = cdiv(N, 32); p.ntk = cdiv(K, 32);
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(T * p.ntn * p.ntk, nchunks), dim3(256), 0, st, p);
+    const int64_t count = (int64_t)T * N * K;
+    hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(count, 256)), dim3(256), 0, st, ws, dw, count, nchunks);
+    if (dbias) {
+        float* bpart = ws + (size_t)64 * T * N * K;
+        const int rows = cdiv(M, 64);
+        const int nb = cdiv(M, rows);
+        hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, st, dy, ldy, N, (int64_t)M, rows, bpart);
+        hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(256), 0, st, bpart, dbias, (int64_t)N, nb);
+    }
+    SPEI_CHECK_LAUNCH("spei_conv_wgrad_f32");
+    return 0;
+}
+
+extern "C" int spei_relu_bwd(const float* y, const float* dy, float* dz, int64_t n, spei_stream_t stream) {
+    SPEI_REQUIRE(y && dy && dz && n > 0 && n % 4 == 0, "spei_relu_bwd: bad arguments");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, y, dy, dz, n / 4);
+    SPEI_CHECK_LAUNCH("spei_relu_bwd");
+    return 0;
+}
+
+extern "C" int64_t spei_plane_ws_floats(int H, int W, int C) {
+    const int64_t ntx = (W + GT - 1) / GT, nty = (H + GT - 1) / GT;
+    return 2 * (ntx * H * C + nty * W * C);
+}
+
+// prod == 0: rowmax, rowmean [H][C], colmax, colmean [W][C], mean [C] of a.   prod == 1: rowmax = colmax = NULL; rowmean / colmean /
+// mean receive the plain SUMS of a * b over x, over y and over the map.
+extern "C" int spei_plane_stats(const float* a, const float* b, int prod, int H, int W, int C, float* rowmax, float* rowmean, float* colmax,
+                                float* colmean, float* mean, float* ws, spei_stream_t stream) {
+    SPEI_REQUIRE(a && rowmean && colmean && mean && ws && (!prod || b) && (prod || (rowmax && colmax)), "spei_plane_stats: null pointer");
+    SPEI_REQUIRE((C == 32 || C == 64 || C == 128) && H > 0 && W > 0, "spei_plane_stats: C=%d (32/64/128 built)", C);
+    hipStream_t st = (hipStream_t)stream;
+    const int ntx = (W + GT - 1) / GT, nty = (H + GT - 1) / GT;
+    float* rpm = ws;
+    float* rps = rpm + (size_t)ntx * H * C;
+    float* cpm = rps + (size_t)ntx * H * C;
+    float* cps = cpm + (size_t)nty * W * C;
+    if (prod) hipLaunchKernelGGL(plane_stats_kernel<true>, dim3(ntx * nty), dim3(256), 0, st, a, b, H, W, C, rpm, rps, cpm, cps, ntx, nty);
+    else hipLaunchKernelGGL(plane_stats_kernel<false>, dim3(ntx * nty), dim3(256), 0, st, a, b, H, W, C, rpm, rps, cpm, cps, ntx, nty);
+    const int64_t hc = (int64_t)H * C, wc = (int64_t)W * C;
+    // rows: plain sums first (the channel total is the sum of the row sums), then scaled to means when asked for
+    hipLaunchKernelGGL(plane_combine_kernel, dim3(cdiv(hc, 256)), dim3(256), 0, st, prod ? nullptr : rpm, rps, ntx, hc, 1.0f, prod ? nullptr : rowmax, rowmean);
+    hipLaunchKernelGGL(lines_total_kernel, dim3(1), dim3(256), 0, st, rowmean, H, C, prod ? 1.0f : 1.0f / ((float)H * (float)W), mean);
+    if (!prod) hipLaunchKernelGGL(plane_combine_kernel, dim3(cdiv(hc, 256)), dim3(256), 0, st, nullptr, rps, ntx, hc, 1.0f / (float)W, nullptr, rowmean);
+    hipLaunchKernelGGL(plane_combine_kernel, dim3(cdiv(wc, 256)), dim3(256), 0, st, prod ? nullptr : cpm, cps, nty, wc, prod ? 1.0f : 1.0f / (float)H,
+                       prod ? nullptr : colmax, colmean);
+    SPEI_CHECK_LAUNCH("spei_plane_stats");
+    return 0;
+}
+
+extern "C" int spei_resblock_apply_bwd(const float* dout, const float* x1, const float* s, const float* g1, const float* g2, const float* rowmax,
+                                       const float* colmax, const float* d_rowmax, const float* d_rowmean, const float* d_colmax,
+                                       const float* d_colmean, const float* d_mean, float* dx1, int H, int W, int C, spei_stream_t stream) {
+    SPEI_REQUIRE(dout && x1 && s && g1 && g2 && rowmax && colmax && d_rowmax && d_rowmean && d_colmax && d_colmean && d_mean && dx1,
+                 "spei_resblock_apply_bwd: null pointer");
+    SPEI_REQUIRE(C % 4 == 0 && H > 0 && W > 0, "spei_resblock_apply_bwd: bad shape");
+    ApplyBwdParams p;
+    p.dout = dout; p.x1 = x1; p.s = s; p.g1 = g1; p.g2 = g2; p.rowmax = rowmax; p.colmax = colmax; p.d_rowmax = d_rowmax;
+    p.d_rowmean = d_rowmean; p.d_colmax = d_colmax; p.d_colmean = d_colmean; p.d_mean = d_mean; p.dx1 = dx1; p.H = H; p.W = W; p.C = C;
+    const int64_t total = (int64_t)H * W * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(resblock_apply_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    SPEI_CHECK_LAUNCH("spei_resblock_apply_bwd");
+    return 0;
+}
