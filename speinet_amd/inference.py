@@ -204,9 +204,12 @@ class Inference:
         feats = torch.cat([detector.focus_measures(imgs[i:i + 16].to(self.device), 11) for i in range(0, len(imgs), 16)])
         return detector.predict(feats)
 
-    def _post(self, out_u8: torch.Tensor, psnr: torch.Tensor, ssim: torch.Tensor, save_to: str):
+    def _post(self, out_u8: torch.Tensor, psnr: torch.Tensor, ssim: torch.Tensor, save_to: str, finite: torch.Tensor):
         """Worker thread: fetch the frame and its two metrics from the GPU, encode the PNG."""
         t0 = time.time()
+        if not bool(finite.item()):
+            raise FloatingPointError(f"non-finite values in the deblurred frame {save_to or ''}: an activation left the range of the "
+                                     "16-bit operand format (half: +-65504); rerun with --precision bf16x3 or f32")
         psnr, ssim = float(psnr.item()), float(ssim.item())
         if save_to:
             _imwrite(save_to, out_u8.cpu().numpy())
@@ -269,6 +272,7 @@ class Inference:
                         out = self.net.forward_window(x, keys, enc_cache, zero_ref=bool(w["zero_pre"]))
                     else:
                         out = self.net(x, routing=[bool(w["zero_pre"])])
+                    finite = torch.isfinite(out).all()               # checked by the worker: half operands do not saturate (ops.py)
                     out_u8 = out.mul(255.0).clamp(0, 255).round()[0].to(torch.uint8).permute(1, 2, 0).contiguous()   # = tensor2numpy, on the GPU
                     gt_u8 = gt[:nh, :nw]
                     psnr, ssim = metrics_gpu(out_u8[4:-4, 4:-4], gt_u8[4:-4, 4:-4])     # border crop: inference_SPEINet.py:405-410
@@ -278,7 +282,7 @@ class Inference:
                         inflight.append(ev)
                     t2 = time.time()
                     save_to = os.path.join(a.result_path, clip, w["name"] + ".png") if a.save_image else ""
-                    pending.append((w["name"], self.post_pool.submit(self._post, out_u8, psnr, ssim, save_to), t1 - t0, t2 - t1, t0))
+                    pending.append((w["name"], self.post_pool.submit(self._post, out_u8, psnr, ssim, save_to, finite), t1 - t0, t2 - t1, t0))
                     flush(block=len(pending) > 2 * self.prefetch)
                 flush(block=True)
                 self.logger.write_log("# Video:{} AVG-PSNR={:.5}, AVG-SSIM={:.4}".format(clip, sum(vp) / len(vp), sum(vs) / len(vs)))

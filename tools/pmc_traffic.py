@@ -2,7 +2,8 @@
 """HBM traffic of the correlation kernel from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; collected separately, as
 MI355X_MICROARCH.md prescribes) -> profiles/<name>.json.
 
-   python tools/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out json> "<command note>"
+   python tools/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out json> "<command note>" [key] [commit]
+   key: "<precision>/<corr precision>" entry bench.py looks up (default f16/top2)
 """
 import csv
 import glob
@@ -31,12 +32,13 @@ write_kb, _, _ = counter(sys.argv[2], "WRITE_SIZE", "corr_slab_kernel")
 # gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE counts 32-byte units of 64-byte requests
 # as one: wide coalesced reads report half their bytes -> double it; WRITE_SIZE is taken as reported.  Units are KiB.
 hbm = (2.0 * fetch_kb + write_kb) * 1024.0
-out = {"bf16/bf16": {"kernel": kname.replace("(anonymous namespace)::", "")[:80], "launches_averaged": n,
+KEY = sys.argv[5] if len(sys.argv) > 5 else "f16/top2"
+out = {"commit": sys.argv[6] if len(sys.argv) > 6 else "n/a", KEY: {"kernel": kname.replace("(anonymous namespace)::", "")[:80], "launches_averaged": n,
                      "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb, "hbm_bytes_per_launch": hbm,
                      "note": sys.argv[4] + "; FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md "
-                             "HBM section); algorithmic compulsory bytes = 2 maps x 14.7 MB bf16 + 0.7 MB outputs"}}
+                             "HBM section); algorithmic compulsory bytes = 2 maps x 14.7 MB (16-bit) + 0.9 MB outputs"}}
 # whole frame: every dispatch of the run (n frames = n launches of the correlation kernel; the one-off weight packing of
 # the first call is included, < 1 %), same corrections
-out["bf16/bf16"]["path_hbm_bytes_per_frame"] = (2.0 * total(sys.argv[1], "FETCH_SIZE") + total(sys.argv[2], "WRITE_SIZE")) * 1024.0 / n
+out[KEY]["path_hbm_bytes_per_frame"] = (2.0 * total(sys.argv[1], "FETCH_SIZE") + total(sys.argv[2], "WRITE_SIZE")) * 1024.0 / n
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
