@@ -14,11 +14,15 @@
 
 namespace {
 
-// Tiling of the statistics pass: a 256-thread block reads a (1024/C) x (1024/C) pixel tile with 16-byte loads,
-// thread = (channel quad cq, tile column pl).  Column partials accumulate in registers down the tile's rows; row
-// partials are reduced across the tile's columns with wave shuffles + a small LDS combine.  Every level launches
-// ~900 blocks (C*pixels is constant), so the pass streams at HBM rate instead of one row per block.
-constexpr int GATE_NCOL = 2;     // pixel columns per thread of the statistics pass: tile = (1024/C) rows x (NCOL * 1024/C) columns
+// Tiling of the statistics pass: a 256-thread block owns a TR-row x TC-column pixel tile, thread = (pixel column, channel
+// octet): TC = 256 / (C/8) columns.  Every thread issues all TR loads of its column up front (16 B each for 16-bit x1), keeps
+// the column partials in registers, and parks the loaded vectors in LDS; the row partials are then summed by a TRANSPOSED
+// thread mapping (thread = (row, octet, column segment), sequential over its columns) — no cross-lane reduction per element
+// (round 1's version spent its time in them: 1.3 TB/s), fixed summation order, results bitwise reproducible.
+constexpr int GATE_TR16 = 16;    // tile rows for 16-bit x1
+constexpr int GATE_TR32 = 8;     // tile rows for fp32 x1 (same LDS footprint)
+__host__ __device__ inline int gate_tr(bool lp) { return lp ? GATE_TR16 : GATE_TR32; }
+__host__ __device__ inline int gate_tc(int C) { return 256 / (C / 8); }
 
 struct GateWs {
     float* rowpmax;  // [ntx][H][C]
@@ -28,11 +32,10 @@ struct GateWs {
     float* tilesum;  // [nty*ntx][C]  per-tile channel sums (for the SE mean)
     int ntx, nty;
 };
-__host__ __device__ inline GateWs carve(float* ws, int H, int W, int C) {
+__host__ __device__ inline GateWs carve(float* ws, int H, int W, int C, bool lp) {
     GateWs g;
-    const int T = 1024 / C;
-    g.ntx = (W + GATE_NCOL * T - 1) / (GATE_NCOL * T);
-    g.nty = (H + T - 1) / T;
+    g.ntx = (W + gate_tc(C) - 1) / gate_tc(C);
+    g.nty = (H + gate_tr(lp) - 1) / gate_tr(lp);
     g.rowpmax = ws;
     g.rowpsum = g.rowpmax + (size_t)g.ntx * H * C;
     g.colpmax = g.rowpsum + (size_t)g.ntx * H * C;
@@ -58,88 +61,127 @@ __device__ __forceinline__ f32x4 max4(f32x4 a, f32x4 b) {
 // ---- launch 1: tile statistics -----------------------------------------------------------------------------
 template <int C, typename TX>
 __global__ __launch_bounds__(256) void gate_stats_kernel(const TX* __restrict__ x1, int H, int W, GateWs g) {
-    constexpr int CQ = C / 4;            // channel quads = threads per pixel
-    constexpr int T = 1024 / C;          // tile rows == tile columns
-    constexpr int PLW = 64 / CQ;         // tile columns held by one wave
-    __shared__ f32x4 smax[T][4][CQ], ssum[T][4][CQ];
-    __shared__ f32x4 stot[4][CQ];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cq = tid % CQ, pl = tid / CQ;
+    constexpr bool LP = sizeof(TX) == 2;
+    constexpr int OCT = C / 8;                   // threads per pixel (8 channels each)
+    constexpr int TC = 256 / OCT;                // tile columns
+    constexpr int TR = LP ? GATE_TR16 : GATE_TR32;
+    constexpr int EB = LP ? 16 : 32;             // bytes of one (pixel, octet) entry
+    constexpr int ROWB = TC * OCT * EB + 4 * EB; // LDS row pitch: + 4 entries, so the transposed reads of 16 rows spread over the banks
+    constexpr int ITEMS = TR * OCT;              // (row, octet) sums of the transposed pass
+    constexpr int PARTS = 256 / ITEMS;           // column segments per item: 4, 2, 1 (16-bit) / 8, 4, 2 (fp32)
+    constexpr int SEG = TC / PARTS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile[];      // [TR][ROWB] bytes, then the row sums [TR][C] floats
+    float* rsum = reinterpret_cast<float*>(tile + TR * ROWB);
+    const int tid = threadIdx.x;
+    const int oct = tid % OCT, col = tid / OCT;
     const int tx = blockIdx.x % g.ntx, ty = blockIdx.x / g.ntx;
-    // a thread owns NCOL pixel columns (x0 + j*T): NCOL independent loads per row, and the cross-lane row reduction below
-    // is paid once per NCOL pixels
-    const int x0 = tx * (T * GATE_NCOL) + pl, y0 = ty * T;
-    const f32x4 ninf = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY}, zero = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 cmax[GATE_NCOL], csum[GATE_NCOL];
+    const int x = tx * TC + col, y0 = ty * TR;
+
+    // ---- pass 1: all loads of this thread's column, column partials in registers, raw vectors to LDS ------------------------
+    u32x4 v[TR][LP ? 1 : 2];
 #pragma unroll
-    for (int j = 0; j < GATE_NCOL; ++j) { cmax[j] = ninf; csum[j] = zero; }
-#pragma unroll 4
-    for (int k = 0; k < T; ++k) {
-        const int y = y0 + k;
-        f32x4 vmax = ninf, vsum = zero;
+    for (int r = 0; r < TR; ++r) {
+        const bool ok = x < W && y0 + r < H;
+        const TX* src = x1 + ((size_t)min(y0 + r, H - 1) * W + min(x, W - 1)) * C + oct * 8;
 #pragma unroll
-        for (int j = 0; j < GATE_NCOL; ++j) {
-            const int x = x0 + j * T;
-            if (x < W && y < H) {
-                const f32x4 v = ld4<TX>(x1 + ((size_t)y * W + x) * C + cq * 4);
-                cmax[j] = max4(cmax[j], v);
-                csum[j] += v;
-                vmax = max4(vmax, v);
-                vsum += v;
-            }
-        }
-        // reduce over the PLW columns of this wave (lanes cq + CQ*j), fixed order => reproducible; VALU-only butterflies
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if constexpr (CQ <= 8) { vmax[e] = xor_combine<8, OpMax>(vmax[e]); vsum[e] = xor_combine<8, OpSum>(vsum[e]); }
-            if constexpr (CQ <= 16) { vmax[e] = xor_combine<16, OpMax>(vmax[e]); vsum[e] = xor_combine<16, OpSum>(vsum[e]); }
-            vmax[e] = xor_combine<32, OpMax>(vmax[e]);
-            vsum[e] = xor_combine<32, OpSum>(vsum[e]);
-        }
-        if (lane < CQ) {
-            smax[k][wave][cq] = vmax;
-            ssum[k][wave][cq] = vsum;
+        for (int hlf = 0; hlf < (LP ? 1 : 2); ++hlf) {
+            v[r][hlf] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(src) + 16 * hlf);
+            if (!ok) v[r][hlf] = u32x4{0u, 0u, 0u, 0u};
         }
     }
-    f32x4 tsum = zero;
+    auto unpack = [](const u32x4* q, float* f) __attribute__((always_inline)) {
+        if constexpr (LP) {
+            const typename lpv<TX>::x8 h = *reinterpret_cast<const typename lpv<TX>::x8*>(q);
 #pragma unroll
-    for (int j = 0; j < GATE_NCOL; ++j) {
-        const int x = x0 + j * T;
-        if (x < W) {
-            *reinterpret_cast<f32x4*>(g.colpmax + ((size_t)ty * W + x) * C + cq * 4) = cmax[j];
-            *reinterpret_cast<f32x4*>(g.colpsum + ((size_t)ty * W + x) * C + cq * 4) = csum[j];
-            tsum += csum[j];
+            for (int e = 0; e < 8; ++e) f[e] = (float)h[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = __uint_as_float(q[e >> 2][e & 3]);
         }
+    };
+    float cmax[8], csum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { cmax[e] = -INFINITY; csum[e] = 0.f; }
+#pragma unroll
+    for (int r = 0; r < TR; ++r) {
+        float f[8];
+        unpack(v[r], f);
+        if (y0 + r < H) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { cmax[e] = fmaxf(cmax[e], f[e]); csum[e] += f[e]; }
+        }
+#pragma unroll
+        for (int hlf = 0; hlf < (LP ? 1 : 2); ++hlf)
+            *reinterpret_cast<u32x4*>(tile + r * ROWB + (col * OCT + oct) * EB + 16 * hlf) = v[r][hlf];
     }
-    {   // tile total per channel: the column sums of this wave's columns, then the four waves (fixed order)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if constexpr (CQ <= 8) tsum[e] = xor_combine<8, OpSum>(tsum[e]);
-            if constexpr (CQ <= 16) tsum[e] = xor_combine<16, OpSum>(tsum[e]);
-            tsum[e] = xor_combine<32, OpSum>(tsum[e]);
-        }
-        if (lane < CQ) stot[wave][cq] = tsum;
+    if (x < W) {
+        float* pm = g.colpmax + ((size_t)ty * W + x) * C + oct * 8;
+        float* ps = g.colpsum + ((size_t)ty * W + x) * C + oct * 8;
+        *reinterpret_cast<f32x4*>(pm) = f32x4{cmax[0], cmax[1], cmax[2], cmax[3]};
+        *reinterpret_cast<f32x4*>(pm + 4) = f32x4{cmax[4], cmax[5], cmax[6], cmax[7]};
+        *reinterpret_cast<f32x4*>(ps) = f32x4{csum[0], csum[1], csum[2], csum[3]};
+        *reinterpret_cast<f32x4*>(ps + 4) = f32x4{csum[4], csum[5], csum[6], csum[7]};
     }
     __syncthreads();
-    if (tid < CQ) {
-        const f32x4 t = (stot[0][tid] + stot[1][tid]) + (stot[2][tid] + stot[3][tid]);
-        *reinterpret_cast<f32x4*>(g.tilesum + (size_t)blockIdx.x * C + tid * 4) = t;
-    }
-    for (int i = tid; i < T * CQ; i += 256) {
-        const int k = i / CQ, q = i - k * CQ;
-        const int y = y0 + k;
-        if (y < H) {
-            f32x4 mx = smax[k][0][q], sm = ssum[k][0][q];
+
+    // ---- pass 2: row partials, thread = (row, octet, column phase), sequential over every PARTS-th column -----------------
+    {
+        const int part = tid % PARTS, item = tid / PARTS;
+        const int ro = item % OCT, rr = item / OCT;             // octet, row
+        float rmax[8], rs[8];
 #pragma unroll
-            for (int w = 1; w < 4; ++w) {
-                mx = max4(mx, smax[k][w][q]);
-                sm += ssum[k][w][q];
+        for (int e = 0; e < 8; ++e) { rmax[e] = -INFINITY; rs[e] = 0.f; }
+        const int ncol = min(TC, W - tx * TC);                  // columns of this tile inside the map
+#pragma unroll 4
+        for (int j = 0; j < SEG; ++j) {
+            const int c2 = j * PARTS + part;               // interleaved segments: 16 lanes read 256 contiguous bytes
+            u32x4 q[LP ? 1 : 2];
+#pragma unroll
+            for (int hlf = 0; hlf < (LP ? 1 : 2); ++hlf) q[hlf] = *reinterpret_cast<const u32x4*>(tile + rr * ROWB + (c2 * OCT + ro) * EB + 16 * hlf);
+            float f[8];
+            unpack(q, f);
+            if (c2 < ncol) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { rmax[e] = fmaxf(rmax[e], f[e]); rs[e] += f[e]; }
             }
-            *reinterpret_cast<f32x4*>(g.rowpmax + ((size_t)tx * H + y) * C + q * 4) = mx;
-            *reinterpret_cast<f32x4*>(g.rowpsum + ((size_t)tx * H + y) * C + q * 4) = sm;
+        }
+        // combine the PARTS adjacent lanes of an item in a fixed order (lane part 0 gathers): xor 1, 2, 4 butterflies
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if constexpr (PARTS >= 2) { rmax[e] = fmaxf(rmax[e], dpp_quad<0xB1>(rmax[e])); rs[e] += dpp_quad<0xB1>(rs[e]); }
+            if constexpr (PARTS >= 4) { rmax[e] = fmaxf(rmax[e], dpp_quad<0x4E>(rmax[e])); rs[e] += dpp_quad<0x4E>(rs[e]); }
+            if constexpr (PARTS >= 8) { rmax[e] = fmaxf(rmax[e], dpp_quad<0x141>(rmax[e])); rs[e] += dpp_quad<0x141>(rs[e]); }
+        }
+        const int y = y0 + rr;
+        if (part == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rsum[rr * C + ro * 8 + e] = (y < H) ? rs[e] : 0.f;
+            if (y < H) {
+                float* pm = g.rowpmax + ((size_t)tx * H + y) * C + ro * 8;
+                float* ps = g.rowpsum + ((size_t)tx * H + y) * C + ro * 8;
+                *reinterpret_cast<f32x4*>(pm) = f32x4{rmax[0], rmax[1], rmax[2], rmax[3]};
+                *reinterpret_cast<f32x4*>(pm + 4) = f32x4{rmax[4], rmax[5], rmax[6], rmax[7]};
+                *reinterpret_cast<f32x4*>(ps) = f32x4{rs[0], rs[1], rs[2], rs[3]};
+                *reinterpret_cast<f32x4*>(ps + 4) = f32x4{rs[4], rs[5], rs[6], rs[7]};
+            }
         }
     }
-    (void)PLW;
+    __syncthreads();
+    if (tid < C) {                                   // tile total per channel (SE mean): the row sums, top to bottom
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < TR; ++r) t += rsum[r * C + tid];
+        g.tilesum[(size_t)blockIdx.x * C + tid] = t;
+    }
+}
+
+template <int C, typename TX>
+void launch_gate_stats(const TX* x1, int H, int W, const GateWs& g, hipStream_t st) {
+    constexpr bool LP = sizeof(TX) == 2;
+    constexpr int OCT = C / 8, TC = 256 / OCT, TR = LP ? GATE_TR16 : GATE_TR32, EB = LP ? 16 : 32;
+    const size_t lds = (size_t)TR * (TC * OCT * EB + 4 * EB) + (size_t)TR * C * sizeof(float);
+    ensure_dyn_lds<&gate_stats_kernel<C, TX>>(lds);
+    hipLaunchKernelGGL((gate_stats_kernel<C, TX>), dim3(g.ntx * g.nty), dim3(256), lds, st, x1, H, W, g);
 }
 
 // Reduce the `nt` tile partials of `cnt` rows (or columns) starting at line `l0` (lines outside [0, L) give -inf / 0) into
@@ -159,10 +201,25 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ pmax, 
         mx[j] = -INFINITY;
         sm[j] = 0.f;
     }
-    for (int k = 0; k < nt; ++k) {
+    int k = 0;
+    for (; k + 4 <= nt; k += 4) {                    // 32 independent loads in flight, then the four tiles in order
+        float a[4][4], b[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[u][j] = pmax[(size_t)(k + u) * stride + off[j]];                                        // clamped address when !ok
+                b[u][j] = psum[(size_t)(k + u) * stride + off[j]];
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { mx[j] = fmaxf(mx[j], a[u][j]); sm[j] += b[u][j]; }
+    }
+    for (; k < nt; ++k) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float a = pmax[(size_t)k * stride + off[j]], b = psum[(size_t)k * stride + off[j]];     // clamped address when !ok
+            const float a = pmax[(size_t)k * stride + off[j]], b = psum[(size_t)k * stride + off[j]];
             mx[j] = fmaxf(mx[j], a);
             sm[j] += b;
         }
@@ -322,8 +379,7 @@ __global__ __launch_bounds__(256) void resblock_apply_kernel(const float* __rest
 
 extern "C" int64_t spei_gate_ws_floats(int H, int W, int C) {
     if (C != 32 && C != 64 && C != 128) return 0;
-    const int T = 1024 / C;
-    const int64_t ntx = (W + GATE_NCOL * T - 1) / (GATE_NCOL * T), nty = (H + T - 1) / T;
+    const int64_t ntx = (W + gate_tc(C) - 1) / gate_tc(C), nty = (H + GATE_TR32 - 1) / GATE_TR32;      // the finer of the two tilings
     return 2 * ntx * H * C + 2 * nty * W * C + ntx * nty * C;
 }
 
@@ -337,24 +393,23 @@ extern "C" int spei_resblock_gates(const void* x1, int x1_fmt, int H, int W, int
     SPEI_REQUIRE(H > 0 && W > 0, "spei_resblock_gates: empty map");
     SPEI_REQUIRE(((uintptr_t)x1 | (uintptr_t)ws) % 16 == 0, "spei_resblock_gates: 16-byte alignment required");
     hipStream_t st = (hipStream_t)stream;
-    GateWs g = carve(ws, H, W, C);
-    dim3 grid1(g.ntx * g.nty);
     SPEI_REQUIRE(x1_fmt == SPEI_F32 || x1_fmt == SPEI_BF16 || x1_fmt == SPEI_F16, "spei_resblock_gates: x1_fmt=%d", x1_fmt);
+    GateWs g = carve(ws, H, W, C, x1_fmt != SPEI_F32);
     if (x1_fmt == SPEI_BF16) {
         const __bf16* xp = (const __bf16*)x1;
-        if (C == 32) hipLaunchKernelGGL((gate_stats_kernel<32, __bf16>), grid1, dim3(256), 0, st, xp, H, W, g);
-        else if (C == 64) hipLaunchKernelGGL((gate_stats_kernel<64, __bf16>), grid1, dim3(256), 0, st, xp, H, W, g);
-        else hipLaunchKernelGGL((gate_stats_kernel<128, __bf16>), grid1, dim3(256), 0, st, xp, H, W, g);
+        if (C == 32) launch_gate_stats<32>(xp, H, W, g, st);
+        else if (C == 64) launch_gate_stats<64>(xp, H, W, g, st);
+        else launch_gate_stats<128>(xp, H, W, g, st);
     } else if (x1_fmt == SPEI_F16) {
         const _Float16* xp = (const _Float16*)x1;
-        if (C == 32) hipLaunchKernelGGL((gate_stats_kernel<32, _Float16>), grid1, dim3(256), 0, st, xp, H, W, g);
-        else if (C == 64) hipLaunchKernelGGL((gate_stats_kernel<64, _Float16>), grid1, dim3(256), 0, st, xp, H, W, g);
-        else hipLaunchKernelGGL((gate_stats_kernel<128, _Float16>), grid1, dim3(256), 0, st, xp, H, W, g);
+        if (C == 32) launch_gate_stats<32>(xp, H, W, g, st);
+        else if (C == 64) launch_gate_stats<64>(xp, H, W, g, st);
+        else launch_gate_stats<128>(xp, H, W, g, st);
     } else {
         const float* xp = (const float*)x1;
-        if (C == 32) hipLaunchKernelGGL((gate_stats_kernel<32, float>), grid1, dim3(256), 0, st, xp, H, W, g);
-        else if (C == 64) hipLaunchKernelGGL((gate_stats_kernel<64, float>), grid1, dim3(256), 0, st, xp, H, W, g);
-        else hipLaunchKernelGGL((gate_stats_kernel<128, float>), grid1, dim3(256), 0, st, xp, H, W, g);
+        if (C == 32) launch_gate_stats<32>(xp, H, W, g, st);
+        else if (C == 64) launch_gate_stats<64>(xp, H, W, g, st);
+        else launch_gate_stats<128>(xp, H, W, g, st);
     }
     hipLaunchKernelGGL(gate_maps_kernel, dim3(cdiv((int64_t)H * C, 256) + cdiv((int64_t)W * C, 256) + 1), dim3(256), 0, st, H, W, C, g,
                        cw_w, cw_bn, hc_w, hc_bn, g1, g2, se_w1, se_b1, se_w2, se_b2, s);

