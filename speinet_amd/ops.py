@@ -142,6 +142,9 @@ class Ctx:
                       133-142 us per block at 720p, and as a 1-workgroup-per-CU kernel it shuts out the other stream's
                       kernels: 32.9 vs 30.7 ms per frame) — kept as the base for cross-group prefetching, DESIGN.md §6
       commute_upconv  16-bit: relu(conv1x1(bicubic_up(x))) evaluated as relu(bicubic_up(conv1x1(x)))
+      corr_bf16       "f16" with corr "top2": the candidate pass of the correlation runs on bf16 operands (True, default) instead of
+                      f16.  The fp32 re-score decides the winner and S either way (G14: 16 more of 57600 positions differ, dPSNR
+                      +1e-6 dB); bf16 operands let the chip hold a ~7 % higher MFMA clock on this kernel (tools/bench_corr.py)
     stage        {stage name: {field: value}} overrides applied by `for_stage` (engine: "enc", "swin", "search", "decode", and inside
                  "decode" the last stack "out" and its final conv "tail")
     profile      None, or {op name: [(start_event, end_event), ...]} filled on the launch stream (bench.py)
@@ -151,13 +154,13 @@ class Ctx:
     ACT_NONE, ACT_RELU, ACT_GELU = ACT_NONE, ACT_RELU, ACT_GELU
     CONV, CONV_T = CONV, CONV_T
     _FIELDS = ("precision", "corr_precision", "device", "use_slab", "bf16_storage", "x1_bf16", "fuse_mlp", "fuse_attn",
-               "fuse_block", "commute_upconv", "stage", "profile", "capture")
+               "fuse_block", "commute_upconv", "corr_bf16", "stage", "profile", "capture")
     __slots__ = _FIELDS
 
     def __init__(self, precision: str = "f32", corr_precision: str = "bf16x3", device=None, use_slab: bool = True,
                  bf16_storage: bool = True, x1_bf16: bool = True, fuse_mlp: bool = True, fuse_attn: bool = True,
-                 fuse_block: bool = False, commute_upconv: bool = True, stage: Optional[dict] = None, profile: Optional[dict] = None,
-                 capture: Optional[dict] = None):
+                 fuse_block: bool = False, commute_upconv: bool = True, corr_bf16: bool = True, stage: Optional[dict] = None,
+                 profile: Optional[dict] = None, capture: Optional[dict] = None):
         if precision not in PRECISIONS:
             raise ValueError(f"unknown precision {precision!r}")
         corr_precision = _CORR_ALIASES.get(corr_precision, corr_precision)
@@ -175,7 +178,8 @@ class Ctx:
         object.__setattr__(self, "corr_precision", corr_precision)
         object.__setattr__(self, "device", device)
         for k, v in (("use_slab", use_slab), ("bf16_storage", bf16_storage), ("x1_bf16", x1_bf16), ("fuse_mlp", fuse_mlp),
-                     ("fuse_attn", fuse_attn), ("fuse_block", fuse_block), ("commute_upconv", commute_upconv)):
+                     ("fuse_attn", fuse_attn), ("fuse_block", fuse_block), ("commute_upconv", commute_upconv),
+                     ("corr_bf16", corr_bf16)):
             object.__setattr__(self, k, bool(v))
         object.__setattr__(self, "stage", dict(stage) if stage else {})
         object.__setattr__(self, "profile", profile)
@@ -459,7 +463,7 @@ class Ctx:
                             (lr, ref, inv_lr, inv_ref, ws))
         split = self.corr_precision == "bf16x3"
         rescore = self.corr_precision == "top2" and self.use_slab and lr.C == 128
-        f16 = self.fmt
+        f16 = BF16 if (rescore and self.corr_bf16) else self.fmt
         assert f16 == BF16 or (not split and self.use_slab and lr.C == 128), "f16 correlation: slab kernel, single / top2"
         parts = []
         for f in (lr, ref):
