@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--corr-precision", choices=["bf16x3", "single", "top2"], default="top2",
                     help="correlation arg-max when --precision is not f32: top2 = 16-bit pass keeping two candidates + exact "
                          "re-score; single = 16-bit winner; bf16x3 = f32-grade scores (bf16 / bf16x3 only), 2.4x the kernel time")
-    ap.add_argument("--no-harness", action="store_true", help="skip the end-to-end harness measurement (40 frames on disk, ~15 s)")
+    ap.add_argument("--no-harness", action="store_true", help="skip the end-to-end harness measurement (100 frames on disk, ~25 s)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying hipGraph segments")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams for the independent neighbour-frame / reference branches of a frame")
     ap.add_argument("--branch", choices=["bs", "b"], default="bs", help="bs: with sharp reference (SearchTransfer); b: SelfTransfer")
@@ -233,7 +233,7 @@ def main():
             from speinet_amd.inference import harness_throughput
             del net, frames
             torch.cuda.empty_cache()
-            line["harness"] = harness_throughput(40, args.precision)
+            line["harness"] = harness_throughput(100, args.precision)
         mode = "none" if args.no_cpu_baseline else args.cpu_baseline
         if world == 1 and mode != "none":
             line["cpu_baseline"] = cpu_baseline(1234, mode, args.cpu_budget)

@@ -35,8 +35,10 @@ def _imread(path: str) -> np.ndarray:
 
 
 def _imwrite(path: str, img: np.ndarray) -> None:
+    """Lossless PNG at zlib level 1: the reference writes with cv2.imwrite's default, OpenCV's "best speed" PNG setting
+    (inference_SPEINet.py:415-417); PIL's own default (level 6) costs twice the encode time for 10 % smaller files."""
     from PIL import Image
-    Image.fromarray(img).save(path)
+    Image.fromarray(img).save(path, compress_level=1)
 
 
 def calc_ssim(img1: np.ndarray, img2: np.ndarray) -> float:
@@ -204,15 +206,37 @@ class Inference:
         feats = torch.cat([detector.focus_measures(imgs[i:i + 16].to(self.device), 11) for i in range(0, len(imgs), 16)])
         return detector.predict(feats)
 
-    def _post(self, out_u8: torch.Tensor, psnr: torch.Tensor, ssim: torch.Tensor, save_to: str, finite: torch.Tensor):
-        """Worker thread: fetch the frame and its two metrics from the GPU, encode the PNG."""
+    def _result_slot(self, shape):
+        """One page-locked landing buffer per in-flight result: the frame (uint8 [H,W,3]) and [finite, PSNR, SSIM].  The main
+        thread queues the two device->host copies behind the window's kernels and records an event; the worker waits on THAT
+        event only.  (A `.item()` / `.cpu()` issued from the worker is a synchronous copy on the compute stream: it waits for
+        every window queued after its own as well, four times per frame — the post pool spent its time blocked, 150 ms per
+        frame, and throttled the loop to 36 ms per window on a GPU that needs 29.)  Allocated once per frame shape:
+        allocating page-locked memory synchronises the device."""
+        ring = self.__dict__.setdefault("_ring", {"shape": None, "slots": [], "n": 0})
+        if ring["shape"] != tuple(shape):
+            for sl in ring["slots"]:
+                if sl["fut"] is not None:
+                    sl["fut"].result()
+            ring["shape"] = tuple(shape)
+            ring["slots"] = [{"out": torch.empty(tuple(shape), dtype=torch.uint8, pin_memory=True),
+                              "met": torch.empty(3, dtype=torch.float64, pin_memory=True), "fut": None} for _ in range(4 * self.prefetch)]
+        sl = ring["slots"][ring["n"] % len(ring["slots"])]
+        ring["n"] += 1
+        if sl["fut"] is not None:
+            sl["fut"].result()                      # the worker that last read this slot (long done: the ring is 2x the pending bound)
+        return sl
+
+    def _post(self, slot: dict, ready, save_to: str):
+        """Worker thread: wait for the window's results to land in the slot, check them, encode the PNG."""
         t0 = time.time()
-        if not bool(finite.item()):
+        ready.synchronize()
+        finite, psnr, ssim = (float(v) for v in slot["met"].tolist())
+        if not finite:
             raise FloatingPointError(f"non-finite values in the deblurred frame {save_to or ''}: an activation left the range of the "
                                      "16-bit operand format (half: +-65504); rerun with --precision bf16x3 or f32")
-        psnr, ssim = float(psnr.item()), float(ssim.item())
         if save_to:
-            _imwrite(save_to, out_u8.cpu().numpy())
+            _imwrite(save_to, slot["out"].numpy())
         return (float("inf") if psnr != psnr or psnr == float("inf") else psnr), ssim, time.time() - t0
 
     def infer(self):
@@ -224,6 +248,7 @@ class Inference:
         cache = FrameCache(self.io_pool, device=self.device)
         with torch.no_grad():
             for ci in mine:
+                t_clip = time.time()
                 clip = clips[ci]
                 blur = sorted(glob.glob(os.path.join(a.data_path, "blur", clip, "*")))
                 gts = sorted(glob.glob(os.path.join(a.data_path, "gt", clip, "*")))
@@ -246,6 +271,7 @@ class Inference:
                                               .format(clip, name, psnr, ssim, t_pre, t_fwd, t_post, t_pre + t_fwd + t_post))
 
                 inflight = collections.deque()                  # one event per enqueued window
+                t_loop = time.time()
                 for k, (w, gseq) in enumerate(zip(wins, gt_seqs)):
                     # keep the host at most two windows ahead of the GPU: enough slack to hide its own work, and a worker that
                     # fetches a finished frame waits ~2 windows, not the whole queue (the post pool would otherwise spend its
@@ -276,15 +302,21 @@ class Inference:
                     out_u8 = out.mul(255.0).clamp(0, 255).round()[0].to(torch.uint8).permute(1, 2, 0).contiguous()   # = tensor2numpy, on the GPU
                     gt_u8 = gt[:nh, :nw]
                     psnr, ssim = metrics_gpu(out_u8[4:-4, 4:-4], gt_u8[4:-4, 4:-4])     # border crop: inference_SPEINet.py:405-410
-                    if self.device.type == "cuda":
-                        ev = torch.cuda.Event()
-                        ev.record()
-                        inflight.append(ev)
+                    slot = self._result_slot(out_u8.shape)
+                    slot["out"].copy_(out_u8, non_blocking=True)
+                    slot["met"].copy_(torch.stack([finite.to(torch.float64), psnr, ssim]), non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    inflight.append(ev)
                     t2 = time.time()
                     save_to = os.path.join(a.result_path, clip, w["name"] + ".png") if a.save_image else ""
-                    pending.append((w["name"], self.post_pool.submit(self._post, out_u8, psnr, ssim, save_to, finite), t1 - t0, t2 - t1, t0))
+                    slot["fut"] = self.post_pool.submit(self._post, slot, ev, save_to)
+                    pending.append((w["name"], slot["fut"], t1 - t0, t2 - t1, t0))
                     flush(block=len(pending) > 2 * self.prefetch)
+                t_drain = time.time()
                 flush(block=True)
+                self.logger.write_log("# timing {}: setup {:.3f}s, {} windows enqueued in {:.3f}s, drain {:.3f}s".format(
+                    clip, t_loop - t_clip, len(wins), t_drain - t_loop, time.time() - t_drain))
                 self.logger.write_log("# Video:{} AVG-PSNR={:.5}, AVG-SSIM={:.4}".format(clip, sum(vp) / len(vp), sum(vs) / len(vs)))
                 stats += torch.tensor([sum(vp), sum(vs), float(len(vp))], dtype=torch.float64)
         dist = None
@@ -314,7 +346,7 @@ def synth_clip(root: str, n: int = 40, h: int = 720, w: int = 1280, seed: int = 
     return os.path.join(root, "data")
 
 
-def harness_throughput(frames: int = 40, precision: str = "f16", h: int = 720, w: int = 1280) -> dict:
+def harness_throughput(frames: int = 100, precision: str = "f16", h: int = 720, w: int = 1280) -> dict:
     """End-to-end frames/s of this harness on a synthetic clip ON DISK: PNG decode -> selection -> upload -> forward (with
     cross-window encoder reuse) -> uint8 -> PSNR / SSIM -> PNG encode, everything the reference's loop does per frame
     (inference_SPEINet.py:364-429).  One untimed pass first (graph capture, page cache), then one timed pass."""
@@ -336,7 +368,8 @@ def harness_throughput(frames: int = 40, precision: str = "f16", h: int = 720, w
         n = int(tot[2])
         lines = [ln for f in glob.glob(os.path.join(root, "res", "inference_log*")) for ln in open(f) if ln.startswith(">")][-n:]
         mean = lambda key: sum(float(re.search(key + r":([\d.e-]+)s", ln).group(1)) for ln in lines) / max(1, len(lines))
-        return {"value": n / dt, "unit": "frames/s", "frames": n, "seconds": dt, "precision": precision,
+        timing = [ln.strip()[2:] for f in glob.glob(os.path.join(root, "res", "inference_log*")) for ln in open(f) if ln.startswith("# timing")][-1:]
+        return {"value": n / dt, "unit": "frames/s", "frames": n, "seconds": dt, "precision": precision, "timing": timing,
                 "mean_ms": {k: 1e3 * mean(k) for k in ("pre_time", "forward_time", "post_time")},
                 "what": f"speinet_amd.inference on a synthetic {w}x{h} clip on disk, PNG decode/encode, PSNR and SSIM included, "
                         "cross-window encoder reuse on"}

@@ -8,6 +8,6 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from speinet_amd import inference                     # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 prec = sys.argv[2] if len(sys.argv) > 2 else "f16"
 print(json.dumps(inference.harness_throughput(n, prec), indent=1))
