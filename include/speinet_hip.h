@@ -238,6 +238,28 @@ int spei_resblock_apply_bwd(const float* dout, const float* x1, const float* s, 
                             const float* colmax, const float* d_rowmax, const float* d_rowmean, const float* d_colmax,
                             const float* d_colmean, const float* d_mean, float* dx1, int H, int W, int C, spei_stream_t stream);
 
+/* ---- backward of the cross-window-attention SwinIR blocks (model/swinir.py:238-281 under loss.backward(), the training step of
+ * trainer/trainer_swint.py:34-44).  fp32; fixed-order reductions. ---- */
+
+/* nn.LayerNorm(256) backward: dx [M][256] from x (the layer's input; mean / rstd are recomputed), gamma (NULL = no affine) and dy.
+ * part [spei_ln_bwd_blocks(M)][2][256]: per-block partial sums of dgamma (= dy * xhat) and dbeta (= dy); the caller adds the
+ * blocks in index order. */
+int64_t spei_ln_bwd_blocks(int64_t M);
+int spei_layernorm256_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* part, int64_t M, spei_stream_t stream);
+
+/* nn.GELU (erf form) on a saved pre-activation, and dpre = dy * gelu'(pre).  n floats, n % 4 == 0. */
+int spei_gelu_fwd(const float* pre, float* out, int64_t n, spei_stream_t stream);
+int spei_gelu_bwd(const float* pre, const float* dy, float* dpre, int64_t n, spei_stream_t stream);
+
+/* WindowAttention core backward (model/swinir.py:115-149): q [H*W][256] pre-scaled, kv [H*W][512], relbias [8][25][25], dout
+ * [H*W][256] = gradient of spei_window_attention's output -> dq [H*W][256], dkv [H*W][512] and dbias_part [nwin][8][25][25]
+ * (the gradient of relbias is the sum over the windows).  Same window partition / cyclic shift / mask as the forward. */
+int spei_window_attention_bwd(const float* q, const float* kv, const float* relbias, const float* dout, float* dq, float* dkv,
+                              float* dbias_part, int H, int W, int shift, spei_stream_t stream);
+
+/* out[m][n] = x[m][n] * rowscale[m] (the DropPath factor of model/swinir.py:278-279 applied to a branch gradient).  N % 4 == 0. */
+int spei_scale_rows(const float* x, const float* rowscale, float* out, int64_t M, int N, spei_stream_t stream);
+
 /* Row a11 — LD sharpness detector features (inference_SPEINet.py:54-189).  spei_det_gray: [N][3][H][W] fp32 0..255 ->
  * gray [N][H][W] in 0..1 (ITU-R 601 weights).  spei_det_features: gray -> out [N][6] = LAP1, MIS3, WAV1, GRA7, STA3, DCT3
  * with window size k (odd; the reference uses 11).  ws: spei_det_ws_floats(N,H,W,k) floats. */

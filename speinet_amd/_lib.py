@@ -59,6 +59,12 @@ SIGNATURES = {
     "spei_plane_ws_floats": (L, [I, I, I]),
     "spei_plane_stats": (I, [P, P, I, I, I, I, P, P, P, P, P, P, P]),
     "spei_resblock_apply_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
+    "spei_ln_bwd_blocks": (L, [L]),
+    "spei_layernorm256_bwd": (I, [P, P, P, P, P, L, P]),
+    "spei_gelu_fwd": (I, [P, P, L, P]),
+    "spei_gelu_bwd": (I, [P, P, P, L, P]),
+    "spei_window_attention_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P]),
+    "spei_scale_rows": (I, [P, P, P, L, I, P]),
     "spei_det_gray": (I, [P, P, I, I, I, P]),
     "spei_det_ws_floats": (L, [I, I, I, I]),
     "spei_det_features": (I, [P, P, P, I, I, I, I, P]),

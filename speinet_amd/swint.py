@@ -8,7 +8,9 @@
         out     = outBlock(decoder_first(decoder_second(conv(cat(f_mid, f_i...)))))
 
 It is a strict subset of the SPEINet kernels (no RL prior, no SearchTransfer): same arithmetic modes, same packing, same
-engine pieces.  No CPU path, as for speinet_amd.speinet.
+engine pieces.  In train() mode, or whenever autograd is recording, `forward` builds the differentiable fp32 graph of
+speinet_amd.train (HIP forward AND backward kernels, BatchNorm(1) batch statistics, DropPath), so the reference trainer's
+`loss.backward(); optimizer.step()` works on this module unchanged.  No CPU path, as for speinet_amd.speinet.
 """
 from __future__ import annotations
 
@@ -72,7 +74,7 @@ class SPEINet(nn.Module):
             self._packed[key] = pack.pack_swint(self.state_dict(), self.cfg, device)
         return self._packed[key]
 
-    def forward(self, x: torch.Tensor, profile: Optional[dict] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, profile: Optional[dict] = None, drop_path_scales: Optional[list] = None) -> torch.Tensor:
         if x.dim() != 5 or x.shape[1] < self.n_sequence or x.shape[2] != 3:
             raise ValueError(f"expected [B, >= {self.n_sequence}, 3, H, W], got {tuple(x.shape)}")
         h, w = x.shape[-2:]
@@ -80,9 +82,13 @@ class SPEINet(nn.Module):
             raise ValueError(f"H and W must be multiples of 20 (two stride-2 stages, then 5x5 windows); got {h}x{w}")
         if not x.is_cuda:
             raise RuntimeError("speinet_amd.swint runs on MI355X only (HIP kernels); there is no CPU path")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise RuntimeError("speinet_amd: backward kernels are not built yet; use eval() under torch.no_grad()")
         _lib.lib()
+        if self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            # the differentiable graph (fp32, HIP forward and backward kernels): train() mode runs BatchNorm(1) on batch
+            # statistics and DropPath, as the reference module does under trainer/trainer_swint.py:27,39; eval() with grad enabled
+            # is the same graph with running statistics and no DropPath
+            from . import train
+            return train.forward_swint(self, x, scales=drop_path_scales)
         with torch.cuda.device(x.device):
             ctx = ops.Ctx(self.precision, "top2", device=x.device, profile=profile, **self.knobs)
             x = x.contiguous().float()

@@ -1,0 +1,601 @@
+"""Training step of the swint model on HIP kernels (BASELINE.json config 5: `trainer/trainer_swint.py` around
+`model/swint.py`): the differentiable forward of `speinet_amd.swint.SPEINet` in train() mode, built from
+`torch.autograd.Function`s whose forward AND backward are the C-ABI kernels, on the parameters of the drop-in module itself —
+so the reference trainer's own four lines work unchanged (trainer/trainer_swint.py:39-44):
+
+    out = model(input); optimizer.zero_grad(); loss = loss_fn(out, gt); loss.backward(); optimizer.step()
+
+What is train-mode about the graph (all three differ from the eval() graph the inference path runs):
+  * BatchNorm2d(1) of the ResBlock gates (model/block.py:49-68) normalises with the statistics of the batch and updates its
+    running buffers (momentum 0.01, unbiased variance, num_batches_tracked);
+  * DropPath (model/swinir.py:203,278-279; `timm.models.layers.DropPath`, a dependency the reference does not pin — its
+    published algorithm: one Bernoulli(keep) draw per sample and call, divided by keep) scales each Swin branch per sample.
+    `drop_path_scales` draws the factors from torch's CPU generator in the reference's call order; tests pass the reference's
+    own draws in explicitly;
+  * nothing else: Dropout / attention dropout have p = 0 in the reference's SwinIR constructor call (model/swint.py:31-40).
+
+Activations are NHWC pixel rows, the batch folded into the row index: [B * H * W, C] fp32.  Convolutions and window attention
+loop over the samples (their kernels take one map); linears, LayerNorm, GELU take all rows at once.
+
+What runs where:
+  HIP    every pixel-sized operation: conv / transposed conv / linear forward and data gradient (spei_igemm_f32, spei_conv5_in),
+         weight + bias gradients (spei_conv_wgrad_f32), ReLU / GELU masks, LayerNorm forward and backward, window attention
+         forward and backward, the gates' plane statistics, the gated residual sum and its backward, DropPath row scaling
+  torch  parameter-sized or [H][C]-plane-sized work: the gate maps (SE MLP, two 2->1 convs, BatchNorm(1)) and their autograd,
+         the relative-position bias gather, weight re-layouts, sums over per-block / per-window partial gradients, the
+         ConvTranspose2d bias gradient (a column sum), concatenation of the fused features, the loss on the [B,3,H,W] output,
+         the optimizer (the reference's own torch.optim.Adam)
+No CPU path: everything here raises without the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .ops import ACT_NONE, ACT_RELU, CONV, CONV_T, Ctx
+
+_NULL = C.c_void_p(0)
+
+
+def _ctx(device) -> Ctx:
+    return Ctx("f32", "bf16x3", device=device)
+
+
+def _p(ctx: Ctx, t: Optional[torch.Tensor]):
+    if t is None:
+        return _NULL
+    assert t.dtype == torch.float32
+    return ctx._tp(t)
+
+
+# ---- the GEMM family on raw tensors (no packing objects: the weights change every step) ---------------------------------------
+def _w_conv(weight: torch.Tensor) -> torch.Tensor:
+    """Conv2d [N, K, kh, kw] -> [tap][N][K]."""
+    n, k, kh, kw = weight.shape
+    return weight.detach().permute(2, 3, 0, 1).reshape(kh * kw, n, k).contiguous()
+
+
+def _igemm(ctx: Ctx, a: torch.Tensor, K: int, w_tnk: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, N: int,
+           Hin: int, Win: int, Hout: int, Wout: int, ksize: int, stride: int, mode: int, act: int,
+           residual: Optional[torch.Tensor] = None, rowscale: Optional[torch.Tensor] = None) -> None:
+    assert a.is_contiguous() and out.is_contiguous() and w_tnk.is_contiguous() and tuple(w_tnk.shape) == (ksize * ksize, N, K), \
+        (tuple(w_tnk.shape), ksize, N, K)
+    assert a.shape == (Hin * Win, K) and out.shape == (Hout * Wout, N) and K % 32 == 0 and N % 32 == 0
+    lib = _lib.lib()
+    _lib.check(lib.spei_igemm_f32(_p(ctx, a), K, K, _NULL, 0, 0, _p(ctx, w_tnk), _p(ctx, bias), _p(ctx, out), N,
+                                  _p(ctx, residual), N if residual is not None else 0, _p(ctx, rowscale), Hin, Win, Hout, Wout, N,
+                                  ksize, stride, ksize // 2, mode, act, ctx._stream()), "spei_igemm_f32")
+
+
+def _wgrad(ctx: Ctx, x: torch.Tensor, K: int, dy: torch.Tensor, N: int, Hin: int, Win: int, Hout: int, Wout: int, ksize: int,
+           stride: int, want_bias: bool = True):
+    """dw [tap][N][K], db [N] of a Conv2d(K -> N) from its input rows x and output-gradient rows dy (one map)."""
+    lib = _lib.lib()
+    dev = x.device
+    dw = torch.empty(ksize * ksize, N, K, device=dev)
+    db = torch.empty(N, device=dev) if want_bias else None
+    for n0 in range(0, N, 256):                                       # the kernel takes at most 256 output channels per call
+        nn_ = min(256, N - n0)
+        dwp = dw if N <= 256 else torch.empty(ksize * ksize, nn_, K, device=dev)
+        dbp = (db if N <= 256 else torch.empty(nn_, device=dev)) if want_bias else None
+        ws = torch.empty(lib.spei_wgrad_ws_floats(Hout, Wout, nn_, K, ksize), device=dev)
+        dyp = C.c_void_p(dy.data_ptr() + 4 * n0)
+        assert dy.device == ctx.device and dy.is_contiguous() and dy.dtype == torch.float32
+        _lib.check(lib.spei_conv_wgrad_f32(_p(ctx, x), K, dyp, N, _p(ctx, dwp), _p(ctx, dbp), _p(ctx, ws), Hin, Win, Hout, Wout, nn_, K,
+                                           ksize, stride, ksize // 2, ctx._stream()), "spei_conv_wgrad_f32")
+        if N > 256:
+            dw[:, n0:n0 + nn_] = dwp
+            if want_bias:
+                db[n0:n0 + nn_] = dbp
+    return dw, db
+
+
+def _relu_mask(ctx: Ctx, y: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    dz = torch.empty_like(dy)
+    _lib.check(_lib.lib().spei_relu_bwd(_p(ctx, y), _p(ctx, dy), _p(ctx, dz), dy.numel(), ctx._stream()), "spei_relu_bwd")
+    return dz
+
+
+class _Conv2d(torch.autograd.Function):
+    """y = act(conv(x, weight) + bias) [+ residual] on a batch of maps: x [B*H*W, K] -> [B*Ho*Wo, N]; Conv2d(K -> N, k, stride,
+    padding k // 2) (model/recons_video_ori.py:28-71, model/block.py:26-47, model/swinir.py:467,667,716,742)."""
+
+    @staticmethod
+    def forward(fctx, x, weight, bias, residual, B, H, W, ksize, stride, relu):
+        ctx = _ctx(x.device)
+        n, k = weight.shape[0], weight.shape[1]
+        ho, wo = (H + 2 * (ksize // 2) - ksize) // stride + 1, (W + 2 * (ksize // 2) - ksize) // stride + 1
+        x = x.contiguous()
+        w = _w_conv(weight)
+        b = bias.detach().contiguous()
+        out = torch.empty(B * ho * wo, n, device=x.device)
+        res = residual.contiguous() if residual is not None else None
+        for i in range(B):
+            _igemm(ctx, x[i * H * W:(i + 1) * H * W], k, w, b, out[i * ho * wo:(i + 1) * ho * wo], n, H, W, ho, wo, ksize, stride, CONV,
+                   ACT_RELU if relu else ACT_NONE, res[i * ho * wo:(i + 1) * ho * wo] if res is not None else None)
+        fctx.save_for_backward(x, weight, out if relu else None)
+        fctx.meta = (B, H, W, ho, wo, ksize, stride, relu, residual is not None)
+        return out
+
+    @staticmethod
+    def backward(fctx, dy):
+        x, weight, y = fctx.saved_tensors
+        B, H, W, ho, wo, ksize, stride, relu, has_res = fctx.meta
+        ctx = _ctx(dy.device)
+        n, k = weight.shape[0], weight.shape[1]
+        dy = dy.contiguous()
+        dres = dy if has_res else None
+        assert not (relu and has_res)
+        dz = _relu_mask(ctx, y, dy) if relu else dy
+        dw = db = None
+        for i in range(B):
+            dwi, dbi = _wgrad(ctx, x[i * H * W:(i + 1) * H * W], k, dz[i * ho * wo:(i + 1) * ho * wo], n, H, W, ho, wo, ksize, stride)
+            dw, db = (dwi, dbi) if dw is None else (dw + dwi, db + dbi)
+        dweight = dw.view(ksize, ksize, n, k).permute(2, 3, 0, 1).contiguous()
+        dx = None
+        if fctx.needs_input_grad[0]:
+            # data gradient = transposed convolution of dZ with the weights' channel axes swapped (include/speinet_hip.h)
+            wt = _w_conv(weight).transpose(1, 2).contiguous()                              # [t][k][n]
+            hf, wf = ho * stride, wo * stride
+            dx = torch.empty(B * H * W, k, device=dy.device)
+            full = dx if (hf, wf) == (H, W) else torch.empty(hf * wf, k, device=dy.device)
+            for i in range(B):
+                dst = dx[i * H * W:(i + 1) * H * W] if full is dx else full
+                _igemm(ctx, dz[i * ho * wo:(i + 1) * ho * wo], n, wt, None, dst, k, ho, wo, hf, wf, ksize, stride, CONV_T, ACT_NONE)
+                if full is not dx:        # odd input size under stride 2: the transposed conv made one row / column too many
+                    dx[i * H * W:(i + 1) * H * W] = full.view(hf, wf, k)[:H, :W].reshape(H * W, k)
+        return dx, dweight, db, dres, None, None, None, None, None, None
+
+
+class _ConvT2d(torch.autograd.Function):
+    """y = relu(ConvTranspose2d(K -> N, 3, stride 2, padding 1, output_padding 1)(x) + bias)   (model/recons_video_ori.py:58-71,
+    the decoder tails): x [B*H*W, K] -> [B*2H*2W, N].  Its data gradient is the stride-2 Conv2d of dY with the SAME weight tensor
+    read as [out = K][in = N][3][3]; its weight gradient is that convolution's weight gradient with dY as the input map."""
+
+    @staticmethod
+    def forward(fctx, x, weight, bias, B, H, W):
+        ctx = _ctx(x.device)
+        k, n = weight.shape[0], weight.shape[1]
+        x = x.contiguous()
+        w = weight.detach().permute(2, 3, 1, 0).reshape(9, n, k).contiguous()               # [tap][N][K]
+        out = torch.empty(B * 4 * H * W, n, device=x.device)
+        b = bias.detach().contiguous()
+        for i in range(B):
+            _igemm(ctx, x[i * H * W:(i + 1) * H * W], k, w, b, out[i * 4 * H * W:(i + 1) * 4 * H * W], n, H, W, 2 * H, 2 * W, 3, 2, CONV_T,
+                   ACT_RELU)
+        fctx.save_for_backward(x, weight, out)
+        fctx.meta = (B, H, W)
+        return out
+
+    @staticmethod
+    def backward(fctx, dy):
+        x, weight, y = fctx.saved_tensors
+        B, H, W = fctx.meta
+        ctx = _ctx(dy.device)
+        k, n = weight.shape[0], weight.shape[1]
+        dz = _relu_mask(ctx, y, dy.contiguous())
+        wc = _w_conv(weight)                                                               # Conv2d view: [tap][out = K][in = N]
+        dx = torch.empty(B * H * W, k, device=dy.device)
+        dw = None
+        for i in range(B):
+            dzi = dz[i * 4 * H * W:(i + 1) * 4 * H * W]
+            _igemm(ctx, dzi, n, wc, None, dx[i * H * W:(i + 1) * H * W], k, 2 * H, 2 * W, H, W, 3, 2, CONV, ACT_NONE)
+            dwi, _ = _wgrad(ctx, dzi, n, x[i * H * W:(i + 1) * H * W], k, 2 * H, 2 * W, H, W, 3, 2, want_bias=False)   # [t][K][N]
+            dw = dwi if dw is None else dw + dwi
+        dweight = dw.view(3, 3, k, n).permute(2, 3, 0, 1).contiguous()
+        return dx, dweight, dz.sum(dim=0), None, None, None
+
+
+class _ConvIn(torch.autograd.Function):
+    """The 3-channel head conv + ReLU on NCHW frames (spei_conv5_in): frames [B,3,H,W] -> [B*H*W, 32]."""
+
+    @staticmethod
+    def forward(fctx, frames, weight, bias):
+        ctx = _ctx(frames.device)
+        B, c, H, W = frames.shape
+        n = weight.shape[0]
+        frames = frames.contiguous()
+        w = _w_conv(weight)
+        b = bias.detach().contiguous()
+        out = torch.empty(B * H * W, n, device=frames.device)
+        lib = _lib.lib()
+        for i in range(B):
+            _lib.check(lib.spei_conv5_in(_p(ctx, frames[i]), _p(ctx, w), _p(ctx, b), _p(ctx, out[i * H * W:(i + 1) * H * W]), H, W, n,
+                                         ctx._stream()), "spei_conv5_in")
+        fctx.save_for_backward(frames.permute(0, 2, 3, 1).reshape(B * H * W, c).contiguous(), weight, out)
+        fctx.meta = (B, H, W)
+        return out
+
+    @staticmethod
+    def backward(fctx, dy):
+        x, weight, y = fctx.saved_tensors
+        B, H, W = fctx.meta
+        ctx = _ctx(dy.device)
+        n, k = weight.shape[0], weight.shape[1]
+        dz = _relu_mask(ctx, y, dy.contiguous())
+        dw = db = None
+        for i in range(B):
+            dwi, dbi = _wgrad(ctx, x[i * H * W:(i + 1) * H * W], k, dz[i * H * W:(i + 1) * H * W], n, H, W, H, W, 5, 1)
+            dw, db = (dwi, dbi) if dw is None else (dw + dwi, db + dbi)
+        return None, dw.view(5, 5, n, k).permute(2, 3, 0, 1).contiguous(), db
+
+
+class _Linear(torch.autograd.Function):
+    """out = residual + rowscale * (x W^T + b)   (nn.Linear; residual and the per-row DropPath factor optional, both in the GEMM's
+    epilogue).  x [M, K], weight [N, K]."""
+
+    @staticmethod
+    def forward(fctx, x, weight, bias, residual, rowscale):
+        ctx = _ctx(x.device)
+        n, k = weight.shape
+        x = x.contiguous()
+        M = x.shape[0]
+        out = torch.empty(M, n, device=x.device)
+        _igemm(ctx, x, k, weight.detach().reshape(1, n, k).contiguous(), bias.detach().contiguous(), out, n, M, 1, M, 1, 1, 1, CONV, ACT_NONE,
+               residual.contiguous() if residual is not None else None, rowscale)
+        fctx.save_for_backward(x, weight, rowscale)
+        fctx.has_res = residual is not None
+        return out
+
+    @staticmethod
+    def backward(fctx, dy):
+        x, weight, rowscale = fctx.saved_tensors
+        ctx = _ctx(dy.device)
+        n, k = weight.shape
+        M = x.shape[0]
+        dy = dy.contiguous()
+        g = dy
+        if rowscale is not None:
+            g = torch.empty_like(dy)
+            _lib.check(_lib.lib().spei_scale_rows(_p(ctx, dy), _p(ctx, rowscale), _p(ctx, g), M, n, ctx._stream()), "spei_scale_rows")
+        dw, db = _wgrad(ctx, x, k, g, n, M, 1, M, 1, 1, 1)
+        dx = None
+        if fctx.needs_input_grad[0]:
+            dx = torch.empty(M, k, device=dy.device)
+            _igemm(ctx, g, n, weight.detach().t().reshape(1, k, n).contiguous(), None, dx, k, M, 1, M, 1, 1, 1, CONV, ACT_NONE)
+        return dx, dw.view(n, k), db, (dy if fctx.has_res else None), None
+
+
+class _LayerNorm(torch.autograd.Function):
+    """nn.LayerNorm(256) over the channels of [M, 256] rows."""
+
+    @staticmethod
+    def forward(fctx, x, gamma, beta):
+        ctx = _ctx(x.device)
+        x = x.contiguous()
+        assert x.shape[1] == 256
+        y = torch.empty_like(x)
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        _lib.check(_lib.lib().spei_layernorm256(_p(ctx, x), _p(ctx, y), 0, _p(ctx, g), _p(ctx, b), x.shape[0], ctx._stream()), "spei_layernorm256")
+        fctx.save_for_backward(x, gamma)
+        return y
+
+    @staticmethod
+    def backward(fctx, dy):
+        x, gamma = fctx.saved_tensors
+        ctx = _ctx(dy.device)
+        lib = _lib.lib()
+        M = x.shape[0]
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        part = torch.empty(lib.spei_ln_bwd_blocks(M), 2, 256, device=dy.device)
+        _lib.check(lib.spei_layernorm256_bwd(_p(ctx, x), _p(ctx, gamma.detach().contiguous()), _p(ctx, dy), _p(ctx, dx), _p(ctx, part), M,
+                                             ctx._stream()), "spei_layernorm256_bwd")
+        s = part.sum(dim=0)
+        return dx, s[0], s[1]
+
+
+class _Gelu(torch.autograd.Function):
+    @staticmethod
+    def forward(fctx, pre):
+        ctx = _ctx(pre.device)
+        pre = pre.contiguous()
+        out = torch.empty_like(pre)
+        _lib.check(_lib.lib().spei_gelu_fwd(_p(ctx, pre), _p(ctx, out), pre.numel(), ctx._stream()), "spei_gelu_fwd")
+        fctx.save_for_backward(pre)
+        return out
+
+    @staticmethod
+    def backward(fctx, dy):
+        (pre,) = fctx.saved_tensors
+        ctx = _ctx(dy.device)
+        d = torch.empty_like(pre)
+        _lib.check(_lib.lib().spei_gelu_bwd(_p(ctx, pre), _p(ctx, dy.contiguous()), _p(ctx, d), pre.numel(), ctx._stream()), "spei_gelu_bwd")
+        return d
+
+
+class _WindowAttention(torch.autograd.Function):
+    """softmax(q k^T + bias + mask) v per 5x5 window and head (model/swinir.py:115-149); q [B*H*W, 256] already scaled by
+    head_dim^-0.5, kv [B*H*W, 512], relbias [8, 25, 25]."""
+
+    @staticmethod
+    def forward(fctx, q, kv, relbias, B, H, W, shift):
+        ctx = _ctx(q.device)
+        q, kv, rb = q.contiguous(), kv.contiguous(), relbias.detach().contiguous()
+        out = torch.empty_like(q)
+        lib = _lib.lib()
+        hw = H * W
+        for i in range(B):
+            _lib.check(lib.spei_window_attention(_p(ctx, q[i * hw:(i + 1) * hw]), _p(ctx, kv[i * hw:(i + 1) * hw]), 0, _p(ctx, rb),
+                                                 _p(ctx, out[i * hw:(i + 1) * hw]), H, W, shift, ctx._stream()), "spei_window_attention")
+        fctx.save_for_backward(q, kv, rb)
+        fctx.meta = (B, H, W, shift)
+        return out
+
+    @staticmethod
+    def backward(fctx, dout):
+        q, kv, rb = fctx.saved_tensors
+        B, H, W, shift = fctx.meta
+        ctx = _ctx(dout.device)
+        lib = _lib.lib()
+        dout = dout.contiguous()
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        nwin = (H // 5) * (W // 5)
+        part = torch.empty(B, nwin, 8, 25, 25, device=dout.device)
+        hw = H * W
+        for i in range(B):
+            _lib.check(lib.spei_window_attention_bwd(_p(ctx, q[i * hw:(i + 1) * hw]), _p(ctx, kv[i * hw:(i + 1) * hw]), _p(ctx, rb),
+                                                     _p(ctx, dout[i * hw:(i + 1) * hw]), _p(ctx, dq[i * hw:(i + 1) * hw]),
+                                                     _p(ctx, dkv[i * hw:(i + 1) * hw]), _p(ctx, part[i]), H, W, shift, ctx._stream()),
+                       "spei_window_attention_bwd")
+        return dq, dkv, part.sum(dim=(0, 1)), None, None, None, None
+
+
+# ---- the ResBlock's gated residual sum, batch form, BatchNorm(1) in either mode -------------------------------------------------
+def _gate_maps(rowmax, rowmean, colmax, colmean, mean, prm, bn_train: bool, update_running: bool):
+    """s [B,C], g1 [B,H,C], g2 [B,W,C] from the plane statistics (model/block.py:8-24 SE, :75-96 the two gates without their
+    sigmoid, :49-68 BasicConv1 = 2->1 conv + BatchNorm2d(1); TripletAttention sums the gates, :116-119).  prm: se_w1, se_b1, se_w2,
+    se_b2, cw_w, cw_bn_w, cw_bn_b, cw_rm, cw_rv, hc_w, hc_bn_w, hc_bn_b, hc_rm, hc_rv.  bn_train: normalise with the batch
+    statistics; update_running: also move the running buffers (momentum 0.01), as nn.BatchNorm2d.forward does in train()."""
+    se_w1, se_b1, se_w2, se_b2, cw_w, cw_g, cw_b, cw_rm, cw_rv, hc_w, hc_g, hc_b, hc_rm, hc_rv = prm
+    s = torch.sigmoid(F.linear(F.relu(F.linear(mean, se_w1, se_b1)), se_w2, se_b2))
+
+    def bn(t, g, b, rm, rv):
+        # nn.BatchNorm2d(1, eps 1e-5, momentum 0.01) written out (plain tensor arithmetic: no library batch-norm kernels to
+        # compile per shape): train() normalises with the biased batch variance and moves the buffers with the unbiased one
+        if not bn_train:
+            return (t - rm) / torch.sqrt(rv + 1e-5) * g + b
+        mean = t.mean()
+        var = ((t - mean) ** 2).mean()
+        if update_running:
+            with torch.no_grad():
+                n = t.numel()
+                rm.mul_(1.0 - 0.01).add_(0.01 * mean)
+                rv.mul_(1.0 - 0.01).add_(0.01 * var * (n / max(n - 1, 1)))
+        return (t - mean) / torch.sqrt(var + 1e-5) * g + b
+
+    def conv21(z, w, k):
+        # the 2 -> 1 channel k x k convolution as unfold + one matrix product: the library convolution's weight gradient is not
+        # bitwise reproducible for these shapes (atomics), this form is
+        bsz, _, a, b = z.shape
+        return (w.reshape(1, -1) @ F.unfold(z, k, padding=k // 2)).view(bsz, 1, a, b)
+
+    z1 = torch.stack((rowmax, rowmean), dim=1)                              # [B, 2, H, C]: conv "height" = H, "width" = C
+    g1 = bn(conv21(z1, cw_w, 7), cw_g, cw_b, cw_rm, cw_rv)[:, 0]            # [B, H, C]
+    z2 = torch.stack((colmax.transpose(1, 2), colmean.transpose(1, 2)), dim=1)   # [B, 2, C, W]: conv "height" = C, "width" = W
+    g2 = bn(conv21(z2, hc_w, 5), hc_g, hc_b, hc_rm, hc_rv)[:, 0].transpose(1, 2)  # [B, W, C]
+    return s.contiguous(), g1.contiguous(), g2.contiguous()
+
+
+class _GatedSum(torch.autograd.Function):
+    """out = x + x1 * (s + g1[y] + g2[x]) per sample, the gates built from x1's plane statistics (the tail of model/block.py:136-140).
+    x, x1 [B*H*W, C]."""
+
+    @staticmethod
+    def forward(fctx, x, x1, B, H, W, bn_train, *params):
+        ctx = _ctx(x.device)
+        lib = _lib.lib()
+        c = x.shape[1]
+        dev = x.device
+        x, x1 = x.contiguous(), x1.contiguous()
+        rowmax, rowmean = torch.empty(B, H, c, device=dev), torch.empty(B, H, c, device=dev)
+        colmax, colmean = torch.empty(B, W, c, device=dev), torch.empty(B, W, c, device=dev)
+        mean = torch.empty(B, c, device=dev)
+        ws = torch.empty(lib.spei_plane_ws_floats(H, W, c), device=dev)
+        hw = H * W
+        for i in range(B):
+            _lib.check(lib.spei_plane_stats(_p(ctx, x1[i * hw:(i + 1) * hw]), _NULL, 0, H, W, c, _p(ctx, rowmax[i]), _p(ctx, rowmean[i]),
+                                            _p(ctx, colmax[i]), _p(ctx, colmean[i]), _p(ctx, mean[i]), _p(ctx, ws), ctx._stream()),
+                       "spei_plane_stats")
+        prm = [t.detach() for t in params]
+        with torch.no_grad():
+            s, g1, g2 = _gate_maps(rowmax, rowmean, colmax, colmean, mean, prm, bn_train, update_running=bn_train)
+        out = torch.empty_like(x)
+        for i in range(B):
+            sl = slice(i * hw, (i + 1) * hw)
+            _lib.check(lib.spei_resblock_apply(_p(ctx, x[sl]), _p(ctx, x1[sl]), 0, _p(ctx, s[i]), _p(ctx, g1[i]), _p(ctx, g2[i]), _NULL,
+                                               _p(ctx, out[sl]), c, H, W, c, ctx._stream()), "spei_resblock_apply")
+        # the running buffers move again when the same block runs on the next frame (the encoder is applied to every frame of the
+        # window): the backward of a train-mode call does not read them, so it keeps detached copies
+        keep = [t.detach().clone() if i in (7, 8, 12, 13) else t for i, t in enumerate(params)]
+        fctx.save_for_backward(x1, rowmax, rowmean, colmax, colmean, mean, s, g1, g2, *keep)
+        fctx.meta = (B, H, W, bn_train)
+        return out
+
+    @staticmethod
+    def backward(fctx, dout):
+        x1, rowmax, rowmean, colmax, colmean, mean, s, g1, g2, *params = fctx.saved_tensors
+        B, H, W, bn_train = fctx.meta
+        ctx = _ctx(dout.device)
+        lib = _lib.lib()
+        c = x1.shape[1]
+        dev = dout.device
+        dout = dout.contiguous()
+        hw = H * W
+        # gradients of the gates: sums of dOut * x1 over x, over y, over the map
+        dg1, dg2, ds = torch.empty(B, H, c, device=dev), torch.empty(B, W, c, device=dev), torch.empty(B, c, device=dev)
+        ws = torch.empty(lib.spei_plane_ws_floats(H, W, c), device=dev)
+        for i in range(B):
+            sl = slice(i * hw, (i + 1) * hw)
+            _lib.check(lib.spei_plane_stats(_p(ctx, dout[sl]), _p(ctx, x1[sl]), 1, H, W, c, _NULL, _p(ctx, dg1[i]), _NULL, _p(ctx, dg2[i]),
+                                            _p(ctx, ds[i]), _p(ctx, ws), ctx._stream()), "spei_plane_stats")
+        # through the (tiny) gate maps with torch.autograd: statistics and parameters are the leaves
+        with torch.enable_grad():
+            stats = [t.detach().requires_grad_(True) for t in (rowmax, rowmean, colmax, colmean, mean)]
+            prm = [t.detach().requires_grad_(t.is_floating_point() and i not in (7, 8, 12, 13)) for i, t in enumerate(params)]
+            s2, g1b, g2b = _gate_maps(*stats, prm, bn_train, update_running=False)
+            leaves = stats + [t for t in prm if t.requires_grad]
+            grads = torch.autograd.grad([s2, g1b, g2b], leaves, [ds, dg1, dg2], allow_unused=True)
+        d_stats = [g.contiguous() if g is not None else torch.zeros_like(t) for g, t in zip(grads[:5], stats)]
+        dx1 = torch.empty_like(x1)
+        for i in range(B):
+            sl = slice(i * hw, (i + 1) * hw)
+            _lib.check(lib.spei_resblock_apply_bwd(_p(ctx, dout[sl]), _p(ctx, x1[sl]), _p(ctx, s[i]), _p(ctx, g1[i]), _p(ctx, g2[i]),
+                                                   _p(ctx, rowmax[i]), _p(ctx, colmax[i]), _p(ctx, d_stats[0][i]), _p(ctx, d_stats[1][i]),
+                                                   _p(ctx, d_stats[2][i]), _p(ctx, d_stats[3][i]), _p(ctx, d_stats[4][i]), _p(ctx, dx1[sl]),
+                                                   H, W, c, ctx._stream()), "spei_resblock_apply_bwd")
+        pg = iter(grads[5:])
+        dparams = [next(pg) if t.requires_grad else None for t in prm]
+        return (dout, dx1, None, None, None, None) + tuple(dparams)
+
+
+# ---- the model, train-mode graph ----------------------------------------------------------------------------------------------
+def resblock(x: torch.Tensor, blk, B: int, H: int, W: int, bn_train: bool) -> torch.Tensor:
+    """x + SE(x1) + TE(x1), x1 = conv5(relu(conv5(x)))   (model/block.py:127-140); `blk`: a speinet._ResBlock."""
+    c0, c1 = blk.main[0].main[0], blk.main[1].main[0]
+    t = _Conv2d.apply(x, c0.weight, c0.bias, None, B, H, W, 5, 1, True)
+    x1 = _Conv2d.apply(t, c1.weight, c1.bias, None, B, H, W, 5, 1, False)
+    cw, hc = blk.te.cw.conv, blk.te.hc.conv
+    if bn_train:
+        for bn in (cw.bn, hc.bn):
+            bn.num_batches_tracked += 1
+    return _GatedSum.apply(x, x1, B, H, W, bn_train, blk.se.fc[0].weight, blk.se.fc[0].bias, blk.se.fc[2].weight, blk.se.fc[2].bias,
+                           cw.conv.weight, cw.bn.weight, cw.bn.bias, cw.bn.running_mean, cw.bn.running_var,
+                           hc.conv.weight, hc.bn.weight, hc.bn.bias, hc.bn.running_mean, hc.bn.running_var)
+
+
+def encoder(frames: torch.Tensor, rn, bn_train: bool) -> torch.Tensor:
+    """encoder_second(encoder_first(inBlock(frames)))  (model/swint.py:53,58): [B,3,H,W] -> [B*(H/4)*(W/4), 128]."""
+    B, _, H, W = frames.shape
+    f = _ConvIn.apply(frames, rn.inBlock[0][0].weight, rn.inBlock[0][0].bias)
+    for blk in list(rn.inBlock)[1:]:
+        f = resblock(f, blk, B, H, W, bn_train)
+    h, w = H, W
+    for stage in (rn.encoder_first, rn.encoder_second):
+        f = _Conv2d.apply(f, stage[0][0].weight, stage[0][0].bias, None, B, h, w, 5, 2, True)
+        h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        for blk in list(stage)[1:]:
+            f = resblock(f, blk, B, h, w, bn_train)
+    return f
+
+
+def decoder(f: torch.Tensor, rn, B: int, h: int, w: int, bn_train: bool) -> torch.Tensor:
+    """outBlock(decoder_first(decoder_second(f)))  (model/swint.py:65): [B*h*w, 128] -> [B, 3, 4h, 4w]."""
+    for stage in (rn.decoder_second, rn.decoder_first):
+        for blk in list(stage)[:-1]:
+            f = resblock(f, blk, B, h, w, bn_train)
+        ct = stage[-1][0]
+        f = _ConvT2d.apply(f, ct.weight, ct.bias, B, h, w)
+        h, w = 2 * h, 2 * w
+    for blk in list(rn.outBlock)[:-1]:
+        f = resblock(f, blk, B, h, w, bn_train)
+    last = rn.outBlock[-1]
+    # 32 -> 3 channels: the GEMM family works in 32-channel tiles, so the weights are zero-padded to 32 outputs (autograd
+    # slices the gradient back); the three planes are a view of the first three columns
+    w32 = F.pad(last.weight, (0, 0, 0, 0, 0, 0, 0, 32 - last.weight.shape[0]))
+    b32 = F.pad(last.bias, (0, 32 - last.bias.shape[0]))
+    o = _Conv2d.apply(f, w32, b32, None, B, h, w, 5, 1, False)
+    return o.view(B, h, w, 32)[..., :last.weight.shape[0]].permute(0, 3, 1, 2).contiguous()
+
+
+def drop_path_rates(depths: Sequence[int], drop_path_rate: float = 0.1) -> List[float]:
+    """model/swinir.py:691: stochastic depth decay rule over all blocks."""
+    return [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
+
+
+def drop_path_scales(depths: Sequence[int], B: int, n_calls: int, generator: Optional[torch.Generator] = None) -> list:
+    """The DropPath factors of `n_calls` swin calls in the reference's call order: per call, per block with rate > 0, first the
+    attention branch then the MLP branch, each `new_empty((B,1,1)).bernoulli_(keep) / keep` (timm.models.layers.DropPath,
+    scale_by_keep) drawn on the CPU generator.  Returns [call][block] -> None or (attn [B], mlp [B])."""
+    rates = drop_path_rates(depths)
+    out = []
+    for _ in range(n_calls):
+        call = []
+        for r in rates:
+            if r <= 0.0:
+                call.append(None)
+                continue
+            keep = 1.0 - r
+            pair = tuple(torch.empty(B, 1, 1).bernoulli_(keep, generator=generator).div_(keep).view(B) for _ in range(2))
+            call.append(pair)
+        out.append(call)
+    return out
+
+
+def _rows(scale: Optional[torch.Tensor], hw: int, device) -> Optional[torch.Tensor]:
+    return None if scale is None else scale.to(device=device, dtype=torch.float32).repeat_interleave(hw).contiguous()
+
+
+def swin(sw, x: torch.Tensor, y: torch.Tensor, B: int, h: int, w: int, scales: Optional[list]) -> torch.Tensor:
+    """SwinIR.forward(x, y) of the reference's cross-window-attention variant (model/swinir.py:781-810 with upsampler '',
+    img_range 1, mean 0; :763-779 forward_features; :483-484 RSTB; :238-281 block): queries from y, keys / values from x.
+    x, y [B*h*w, 128] -> [B*h*w, 128].  scales: one call's entry of `drop_path_scales` (None: no DropPath, the eval graph)."""
+    hw = h * w
+    cf = sw.conv_first
+    x_first = _Conv2d.apply(x, cf.weight, cf.bias, None, B, h, w, 3, 1, False)
+    y_first = _Conv2d.apply(y, cf.weight, cf.bias, None, B, h, w, 3, 1, False)
+    pe = sw.patch_embed.norm
+    xt = _LayerNorm.apply(x_first, pe.weight, pe.bias)
+    yt = _LayerNorm.apply(y_first, pe.weight, pe.bias)
+    bi = 0
+    for layer in sw.layers:
+        cur = xt
+        for blk in layer.residual_group.blocks:
+            sc = scales[bi] if scales is not None else None
+            bi += 1
+            shift = 0 if blk.attn_mask is None else 2
+            at = blk.attn
+            xn = _LayerNorm.apply(cur, blk.norm1.weight, blk.norm1.bias)
+            yn = _LayerNorm.apply(yt, blk.norm1.weight, blk.norm1.bias)
+            scale = (256 // 8) ** -0.5
+            q = _Linear.apply(yn, at.qkv_y.weight * scale, at.qkv_y.bias * scale, None, None)
+            kv = _Linear.apply(xn, at.qkv_x.weight, at.qkv_x.bias, None, None)
+            relbias = at.relative_position_bias_table[at.relative_position_index.view(-1)].view(25, 25, -1).permute(2, 0, 1)
+            a = _WindowAttention.apply(q, kv, relbias, B, h, w, shift)
+            cur = _Linear.apply(a, at.proj.weight, at.proj.bias, cur, _rows(sc[0] if sc else None, hw, x.device))
+            hn = _LayerNorm.apply(cur, blk.norm2.weight, blk.norm2.bias)
+            hid = _Gelu.apply(_Linear.apply(hn, blk.mlp.fc1.weight, blk.mlp.fc1.bias, None, None))
+            cur = _Linear.apply(hid, blk.mlp.fc2.weight, blk.mlp.fc2.bias, cur, _rows(sc[1] if sc else None, hw, x.device))
+        xt = _Conv2d.apply(cur, layer.conv.weight, layer.conv.bias, xt, B, h, w, 3, 1, False)        # RSTB: conv(blocks(x)) + x
+    xt = _LayerNorm.apply(xt, sw.norm.weight, sw.norm.bias)
+    res = _Conv2d.apply(xt, sw.conv_after_body.weight, sw.conv_after_body.bias, x_first, B, h, w, 3, 1, False)
+    return _Conv2d.apply(res, sw.conv_last.weight, sw.conv_last.bias, x, B, h, w, 3, 1, False)
+
+
+def forward_swint(model, x: torch.Tensor, scales: Optional[list] = None, bn_train: Optional[bool] = None) -> torch.Tensor:
+    """model/swint.py:51-67 as a differentiable graph on the HIP kernels.  x [B, >= n, 3, H, W]; `scales`: the DropPath factors
+    (`drop_path_scales`; drawn here from torch's CPU generator when the model is in train() mode and none are given)."""
+    if not x.is_cuda:
+        raise RuntimeError("speinet_amd.train runs on MI355X only (HIP kernels); there is no CPU path")
+    _lib.lib()
+    n = model.n_sequence
+    B, _, _, H, W = x.shape
+    if H % 20 or W % 20:
+        raise ValueError(f"H and W must be multiples of 20 (two stride-2 stages, then 5x5 windows); got {H}x{W}")
+    training = model.training if bn_train is None else bn_train
+    n_calls = 1 if n == 1 else n - 1
+    if scales is None and model.training:
+        scales = drop_path_scales(model.cfg.depths, B, n_calls)
+    h3, w3 = H // 4, W // 4
+    x = x.float()
+    with torch.cuda.device(x.device):
+        rn = model.recons_net
+        f_mid = encoder(x[:, n // 2], rn, training)
+        feats = [f_mid]
+        call = 0
+        for i in range(n):
+            if i == n // 2:
+                continue
+            feats.append(swin(model.swin, f_mid, encoder(x[:, i], rn, training), B, h3, w3, scales[call] if scales else None))
+            call += 1
+        if n == 1:
+            fused = f_mid + swin(model.swin, f_mid, f_mid, B, h3, w3, scales[0] if scales else None)
+        else:
+            fused = torch.cat(feats, dim=1)
+        cv = model.conv
+        ff = _Linear.apply(fused, cv.weight.view(cv.weight.shape[0], -1), cv.bias, None, None)
+        return decoder(ff, rn, B, h3, w3, training)

@@ -1,0 +1,290 @@
+"""SURVEY.md §8 f3 / BASELINE.json config 5: the training step of the swint model on the HIP kernels.
+
+Two layers of checks:
+  * every new backward kernel against torch's own autograd of the same operation evaluated in float64 on the CPU (LayerNorm,
+    GELU, linear with residual + DropPath factor, window attention with shift masks, Conv2d / ConvTranspose2d data, weight and
+    bias gradients);
+  * G20 (tests/golden/make_golden_train.py): one full training step of the REFERENCE's model/swint.py — train() mode
+    (BatchNorm(1) batch statistics, DropPath), loss 1*L1 + 2*HEM, backward, Adam — output, loss, every parameter's gradient,
+    the BatchNorm buffers and the updated parameters.
+Tolerances are written where they are used: fp32 kernels against fp32 / fp64 references, summation orders differ.
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _leaf(t, dev):
+    return t.to(dev).float().requires_grad_(True)
+
+
+def test_layernorm_gelu_backward():
+    from speinet_amd import train as T
+    gen = torch.Generator().manual_seed(1)
+    for m in (7, 100, 2500):
+        x = torch.randn(m, 256, generator=gen, dtype=torch.float64) * 1.7 + 0.3
+        g, b = torch.randn(256, generator=gen, dtype=torch.float64), torch.randn(256, generator=gen, dtype=torch.float64)
+        r = torch.randn(m, 256, generator=gen, dtype=torch.float64)
+        xr, gr, br = (t.clone().requires_grad_(True) for t in (x, g, b))
+        (F.layer_norm(xr, (256,), gr, br) * r).sum().backward()
+        xd, gd, bd = _leaf(x, DEV), _leaf(g, DEV), _leaf(b, DEV)
+        y = T._LayerNorm.apply(xd, gd, bd)
+        assert _rel(y, F.layer_norm(x, (256,), g, b)) < 2e-6
+        (y * r.to(DEV).float()).sum().backward()
+        assert _rel(xd.grad, xr.grad) < 5e-6 and _rel(gd.grad, gr.grad) < 5e-6 and _rel(bd.grad, br.grad) < 5e-6, m
+    pre = torch.randn(400, 512, generator=gen, dtype=torch.float64) * 2.5
+    r = torch.randn(400, 512, generator=gen, dtype=torch.float64)
+    pr = pre.clone().requires_grad_(True)
+    (F.gelu(pr) * r).sum().backward()
+    pd = _leaf(pre, DEV)
+    y = T._Gelu.apply(pd)
+    assert _rel(y, F.gelu(pre)) < 2e-6
+    (y * r.to(DEV).float()).sum().backward()
+    assert _rel(pd.grad, pr.grad) < 2e-6
+
+
+def test_linear_backward_with_residual_and_droppath():
+    from speinet_amd import train as T
+    gen = torch.Generator().manual_seed(2)
+    for m, k, n in ((200, 256, 512), (150, 512, 256), (64, 384, 128)):
+        x = torch.randn(m, k, generator=gen, dtype=torch.float64)
+        w = torch.randn(n, k, generator=gen, dtype=torch.float64) * 0.05
+        b = torch.randn(n, generator=gen, dtype=torch.float64)
+        res = torch.randn(m, n, generator=gen, dtype=torch.float64)
+        rs = torch.tensor([0.0, 1.0 / 0.9])[torch.randint(0, 2, (m,), generator=gen)].double()
+        r = torch.randn(m, n, generator=gen, dtype=torch.float64)
+        for use in (False, True):
+            leaves = [t.clone().requires_grad_(True) for t in (x, w, b, res)]
+            y = F.linear(leaves[0], leaves[1], leaves[2])
+            y = leaves[3] + rs[:, None] * y if use else y
+            (y * r).sum().backward()
+            dl = [_leaf(t, DEV) for t in (x, w, b, res)]
+            yd = T._Linear.apply(dl[0], dl[1], dl[2], dl[3] if use else None, rs.to(DEV).float() if use else None)
+            assert _rel(yd, y) < 3e-6
+            (yd * r.to(DEV).float()).sum().backward()
+            for a, e in zip(dl[:3] + (dl[3:] if use else []), leaves):
+                assert _rel(a.grad, e.grad) < 5e-6, (m, k, n, use)
+
+
+def _window_attention_ref(q, kv, relbias, B, H, W, shift):
+    """model/swinir.py:115-149 + :238-275 partition / roll / mask, float64 on the CPU; q pre-scaled."""
+    ws, heads = 5, 8
+    def part(t, c):
+        t = t.view(B, H, W, c)
+        if shift:
+            t = torch.roll(t, shifts=(-shift, -shift), dims=(1, 2))
+        return t.view(B, H // ws, ws, W // ws, ws, c).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, c)
+    qw, kvw = part(q, 256), part(kv, 512)
+    nb = qw.shape[0]
+    qh = qw.view(nb, 25, heads, 32).permute(0, 2, 1, 3)
+    kh = kvw[..., :256].reshape(nb, 25, heads, 32).permute(0, 2, 1, 3)
+    vh = kvw[..., 256:].reshape(nb, 25, heads, 32).permute(0, 2, 1, 3)
+    attn = qh @ kh.transpose(-2, -1) + relbias.unsqueeze(0)
+    if shift:
+        from speinet_amd.speinet import _shift_mask
+        mask = _shift_mask(H, W, ws, shift).double()                                     # [nW, 25, 25]
+        attn = attn.view(B, -1, heads, 25, 25) + mask.unsqueeze(1).unsqueeze(0)
+        attn = attn.view(-1, heads, 25, 25)
+    o = (attn.softmax(-1) @ vh).transpose(1, 2).reshape(nb, 25, 256)
+    o = o.view(B, H // ws, W // ws, ws, ws, 256).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, 256)
+    if shift:
+        o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+    return o.reshape(B * H * W, 256)
+
+
+@pytest.mark.parametrize("shift", [0, 2])
+def test_window_attention_backward(shift):
+    from speinet_amd import train as T
+    gen = torch.Generator().manual_seed(3 + shift)
+    for B, H, W in ((1, 10, 10), (2, 10, 15), (1, 50, 50)):
+        m = B * H * W
+        q = torch.randn(m, 256, generator=gen, dtype=torch.float64) * 0.6
+        kv = torch.randn(m, 512, generator=gen, dtype=torch.float64)
+        rb = torch.randn(8, 25, 25, generator=gen, dtype=torch.float64) * 0.5
+        r = torch.randn(m, 256, generator=gen, dtype=torch.float64)
+        leaves = [t.clone().requires_grad_(True) for t in (q, kv, rb)]
+        ref = _window_attention_ref(*leaves, B, H, W, shift)
+        (ref * r).sum().backward()
+        dl = [_leaf(t, DEV) for t in (q, kv, rb)]
+        out = T._WindowAttention.apply(*dl, B, H, W, shift)
+        assert _rel(out, ref) < 3e-6, (B, H, W)
+        (out * r.to(DEV).float()).sum().backward()
+        for a, e, name in zip(dl, leaves, ("dq", "dkv", "dbias")):
+            assert _rel(a.grad, e.grad) < 1e-5, (name, B, H, W, _rel(a.grad, e.grad))
+
+
+def test_conv_family_backward():
+    from speinet_amd import train as T
+    gen = torch.Generator().manual_seed(5)
+    def nchw(rows, B, H, W):
+        return rows.view(B, H, W, -1).permute(0, 3, 1, 2)
+    def rows(t):
+        return t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
+    for B, H, W, k, n, ks, stride, relu, res in ((2, 12, 10, 32, 32, 5, 1, True, False), (1, 20, 20, 32, 64, 5, 2, True, False),
+                                                 (2, 10, 10, 256, 256, 3, 1, False, True), (1, 11, 13, 64, 128, 5, 2, True, False),
+                                                 (1, 8, 8, 32, 32, 5, 1, False, False)):
+        x = torch.randn(B, k, H, W, generator=gen, dtype=torch.float64)
+        w = torch.randn(n, k, ks, ks, generator=gen, dtype=torch.float64) * (1.0 / math.sqrt(k * ks * ks))
+        b = torch.randn(n, generator=gen, dtype=torch.float64) * 0.1
+        lx, lw, lb = (t.clone().requires_grad_(True) for t in (x, w, b))
+        y = F.conv2d(lx, lw, lb, stride=stride, padding=ks // 2)
+        rr = torch.randn(y.shape, generator=gen, dtype=torch.float64)
+        lr_ = rr.clone().requires_grad_(True) if res else None
+        if relu:
+            y = F.relu(y)
+        if res:
+            y = y + lr_
+        g = torch.randn(y.shape, generator=gen, dtype=torch.float64)
+        (y * g).sum().backward()
+        dx, dw, db = _leaf(rows(x), DEV), _leaf(w, DEV), _leaf(b, DEV)
+        dres = _leaf(rows(rr), DEV) if res else None
+        yd = T._Conv2d.apply(dx, dw, db, dres, B, H, W, ks, stride, relu)
+        assert _rel(yd, rows(y)) < 3e-6
+        (yd * rows(g).to(DEV).float()).sum().backward()
+        assert _rel(dx.grad, rows(lx.grad)) < 5e-6 and _rel(dw.grad, lw.grad) < 5e-6 and _rel(db.grad, lb.grad) < 5e-6, (B, H, W, k, n, ks, stride)
+        if res:
+            assert _rel(dres.grad, rows(lr_.grad)) < 1e-6
+    for B, H, W, k, n in ((2, 5, 5, 128, 64), (1, 10, 15, 64, 32)):
+        x = torch.randn(B, k, H, W, generator=gen, dtype=torch.float64)
+        w = torch.randn(k, n, 3, 3, generator=gen, dtype=torch.float64) * (1.0 / math.sqrt(k * 9 / 4))
+        b = torch.randn(n, generator=gen, dtype=torch.float64) * 0.1
+        lx, lw, lb = (t.clone().requires_grad_(True) for t in (x, w, b))
+        y = F.relu(F.conv_transpose2d(lx, lw, lb, stride=2, padding=1, output_padding=1))
+        g = torch.randn(y.shape, generator=gen, dtype=torch.float64)
+        (y * g).sum().backward()
+        dx, dw, db = _leaf(rows(x), DEV), _leaf(w, DEV), _leaf(b, DEV)
+        yd = T._ConvT2d.apply(dx, dw, db, B, H, W)
+        assert _rel(yd, rows(y)) < 3e-6
+        (yd * rows(g).to(DEV).float()).sum().backward()
+        assert _rel(dx.grad, rows(lx.grad)) < 5e-6 and _rel(dw.grad, lw.grad) < 5e-6 and _rel(db.grad, lb.grad) < 5e-6, (B, H, W, k, n)
+
+
+def _scales_from_draws(draws: np.ndarray, depths, n_calls: int) -> list:
+    """The fixture's flat DropPath draws [n_draws, B] -> train.drop_path_scales' nesting."""
+    from speinet_amd.train import drop_path_rates
+    rates = drop_path_rates(depths)
+    it = iter(torch.from_numpy(draws))
+    out = []
+    for _ in range(n_calls):
+        out.append([None if r <= 0 else (next(it), next(it)) for r in rates])
+    assert next(it, None) is None
+    return out
+
+
+@pytest.mark.parametrize("name", ["g20_train_swint_40x40", "g20_train_swint_n1_40x60"])
+def test_training_step_vs_reference(golden_dir, name):
+    """One full training step against the reference's own (G20): output, loss 1*L1 + 2*HEM, all 828 parameter gradients, the
+    BatchNorm(1) running buffers and the parameters after Adam(lr 1e-4).step().
+
+    Tolerances: output 2e-5 abs (values up to 0.6; measured 6e-7), loss 2e-6.  Gradients: every parameter's L2 norm and its
+    subsample (every 97th element) within 5e-3 of the parameter's gradient norm, against the reference's fp32 run AND against
+    the same step run by the reference in float64 (`sub64/*` in the fixture), median below 1e-3 — see the comment at the
+    assertion for what was measured and why.  Parameters with a gradient norm below 1e-5 of the largest are compared on an
+    absolute scale."""
+    from speinet_amd import train as T
+    from speinet_amd.loss import Loss
+    from speinet_amd.swint import SPEINet
+    from speinet_amd.speinet import default_args
+    from speinet_amd.synth import state_dict_template, synth_frames, synth_state_dict
+    d = np.load(os.path.join(golden_dir, name + ".npz"))
+    seed, n_seq, b, h, w = (int(d[k]) for k in ("seed", "n_sequence", "b", "h", "w"))
+    args = default_args()
+    args.n_sequence = n_seq
+    net = SPEINet(n_sequence=n_seq, args=args)
+    net.load_state_dict(synth_state_dict(net.state_dict(), seed=0), strict=True)
+    net = net.to(DEV).train()
+    x = synth_frames(b, h, w, seed=seed)[:, :n_seq].contiguous().to(DEV)
+    gt = synth_frames(b, h, w, seed=seed + 500)[:, 1].contiguous().to(DEV)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=0.0)
+    scales = _scales_from_draws(d["draws"], net.cfg.depths, 1 if n_seq == 1 else n_seq - 1)
+    # the same factors come out of the restated DropPath generator from the same seed
+    torch.manual_seed(seed)
+    mine = T.drop_path_scales(net.cfg.depths, b, 1 if n_seq == 1 else n_seq - 1)
+    for ca, cb in zip(mine, scales):
+        for pa, pb in zip(ca, cb):
+            assert (pa is None) == (pb is None)
+            if pa is not None:
+                assert torch.equal(pa[0], pb[0]) and torch.equal(pa[1], pb[1])
+    np.random.seed(seed)
+    loss_fn = Loss("1*L1+2*HEM", device=DEV)
+    out = net(x, drop_path_scales=scales)
+    opt.zero_grad()
+    loss = loss_fn(out, gt)
+    loss.backward()
+    err = (out.detach().cpu() - torch.from_numpy(d["out"])).abs().max().item()
+    print(f"{name}: max |out - ref| {err:.2e}; loss {loss.item():.6f} vs {float(d['loss']):.6f}")
+    assert err < 2e-5
+    assert abs(loss.item() - float(d["loss"])) < 2e-6 and abs(loss_fn.log[-1][1] - 2.0 * float(d["hem"])) < 2e-6
+    gmax = max(float(d[k]) for k in d.files if k.startswith("norm/"))
+    rows = []
+    for k, p in net.named_parameters():
+        assert p.grad is not None, k
+        g = p.grad.detach().reshape(-1).cpu()
+        ref_norm = float(d["norm/" + k])
+        scale = max(ref_norm, 1e-5 * gmax)
+        if ".bn." in k:
+            # a one-number gradient (the BatchNorm(1) affine of a gate) is a sum of ~10^3..10^4 signed terms that can cancel to
+            # 1e-3 of their size: measured against the gradient norm of the SAME gate's convolution weight (test_gpu_grad.py)
+            scale = max(scale, float(d["norm/" + k.rsplit(".bn.", 1)[0] + ".conv.weight"]))
+        sub32, sub64 = torch.from_numpy(d["sub/" + k]), torch.from_numpy(d["sub64/" + k])
+        e_norm = abs(g.norm().item() - ref_norm) / scale
+        e32 = (g[::97] - sub32).norm().item() / scale            # HIP fp32 vs the reference's fp32
+        e64 = (g[::97] - sub64).norm().item() / scale            # HIP fp32 vs the reference in float64
+        r64 = (sub32 - sub64).norm().item() / scale              # the reference's fp32 vs its own float64: fp32 summation noise
+        r64 = max(r64, abs(ref_norm - float(d["norm64/" + k])) / scale)
+        rows.append((k, e_norm, e32, e64, r64))
+    top = lambda i: ", ".join(f"{r[0]} {r[i]:.1e}" for r in sorted(rows, key=lambda r: -r[i])[:4])
+    print(f"{name}: {len(rows)} gradients.  HIP vs reference fp32, worst: {top(2)}\n   HIP vs reference float64, worst: {top(3)}\n"
+          f"   reference fp32 vs its own float64, worst: {top(4)}")
+    groups = {}
+    for k, e_norm, e32, e64, r64 in rows:
+        parts = k.split(".")
+        gk = ".".join(parts[:3]) if parts[0] == "swin" and parts[1] == "layers" else ".".join(parts[:2])
+        groups.setdefault(gk, []).append((e64, r64))
+    print("   per stage, median over its parameters of (HIP vs float64, reference fp32 vs float64): "
+          + "; ".join(f"{gk} {np.median([a for a, _ in v]):.1e}/{np.median([b for _, b in v]):.1e}" for gk, v in groups.items()))
+    # Measured (40x40, B = 2): the last stage before the loss (outBlock) agrees with the float64 gradients to 1e-7, the reference's
+    # own fp32 run to 7e-8; from decoder_first upstream BOTH runs sit at a uniform distance from float64 (reference fp32 2e-5
+    # median / 2e-4 worst, HIP 2e-4 median / 2e-3 worst on the cancellation-prone BatchNorm scalars): the signature of ReLU /
+    # max-pool / hard-mask decisions on elements within fp32 round-off of their threshold resolving differently under another
+    # summation order — one element in 10^5 moves every upstream sum by that much (test_gpu_grad.py saw the same at 40x60), while
+    # every kernel on its own matches float64 autograd to 1e-6 (the tests above, tools/diag_resblock_train.py).
+    med = float(np.median([r[3] for r in rows]))
+    assert med < 1e-3, med
+    for k, e_norm, e32, e64, r64 in rows:
+        # (the n_sequence 1, B = 1 case: the reference's float64 run itself sits up to 1.2e-2 from its fp32 run on the gate
+        # parameters — a batch of one map — so there the bound is relative to the reference's own fp32-to-float64 distance)
+        bound = max(5e-3, 2.0 * r64 + 1e-3)
+        assert e32 < bound and e_norm < bound and e64 < bound, (k, e_norm, e32, e64, r64)
+    opt.step()
+    sd = net.state_dict()
+    for k in d.files:
+        if k.startswith("bn/"):
+            ref = torch.from_numpy(np.asarray(d[k]))
+            got = sd[k[3:]].cpu()
+            if "num_batches" in k:
+                assert int(got) == int(ref), k
+            else:
+                assert (got - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item()), k
+        elif k.startswith("adam/"):
+            ref = torch.from_numpy(d[k])
+            got = sd[k[5:]].reshape(-1)[::97].cpu()
+            # Adam's first step moves every element by lr * g / (|g| + eps): +-1e-4 wherever |g| >> eps = 1e-8; an element whose
+            # gradient is within rounding of zero can land on the other side, so compare in units of the step
+            frac_bad = ((got - ref).abs() > 2e-5).float().mean().item()
+            assert frac_bad < 0.02, (k, frac_bad)

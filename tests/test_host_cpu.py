@@ -135,3 +135,39 @@ def test_encoder_cache_lru():
     assert (c.hits, c.misses) == (4, 2)
     c.clear()
     assert c.get("a") is None
+
+
+def test_loss_l1_hem_vs_reference_golden(golden_dir):
+    """speinet_amd.loss against the reference's own loss values (G20: nn.L1Loss + its Loss/hard_example_mining.py on the
+    reference's output, numpy's global generator seeded as in the fixture): same masks, same numbers."""
+    import numpy as np
+    import torch
+    from speinet_amd.loss import Loss
+    from speinet_amd.synth import synth_frames
+    for name in ("g20_train_swint_40x40", "g20_train_swint_n1_40x60"):
+        d = np.load(os.path.join(golden_dir, name + ".npz"))
+        seed, b, h, w = (int(d[k]) for k in ("seed", "b", "h", "w"))
+        out = torch.from_numpy(d["out"]).requires_grad_(True)
+        gt = synth_frames(b, h, w, seed=seed + 500)[:, 1].contiguous()
+        np.random.seed(seed)
+        fn = Loss("1*L1+2*HEM", device="cpu")
+        loss = fn(out, gt)
+        assert abs(loss.item() - float(d["loss"])) < 1e-7
+        assert abs(fn.log[-1][0] - float(d["l1"])) < 1e-7 and abs(fn.log[-1][1] - 2 * float(d["hem"])) < 1e-7
+        loss.backward()
+        assert out.grad.abs().sum().item() > 0
+
+
+def test_drop_path_rates_and_stream():
+    """DropPath: the decay rule of model/swinir.py:691 and the draw order / algorithm recorded by the reference run (G20)."""
+    import numpy as np
+    import torch
+    from speinet_amd.train import drop_path_rates, drop_path_scales
+    r = drop_path_rates([6] * 6)
+    assert len(r) == 36 and r[0] == 0.0 and abs(r[-1] - 0.1) < 1e-7 and all(b > a for a, b in zip(r, r[1:]))
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g20_train_swint_40x40.npz"))
+    torch.manual_seed(int(d["seed"]))
+    sc = drop_path_scales([6] * 6, int(d["b"]), 2)
+    flat = [t for call in sc for pair in call if pair is not None for t in pair]
+    assert len(flat) == d["draws"].shape[0] == 2 * 35 * 2
+    assert all(torch.equal(a, torch.from_numpy(b)) for a, b in zip(flat, d["draws"]))
