@@ -33,6 +33,7 @@ def build_lib(force: bool = False, verbose: bool = True, tuning: bool = False) -
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
     if tuning:
         flags.append("-DSPEI_TUNING")
+        flags += os.environ.get("SPEI_EXTRA_FLAGS", "").split()        # compile-time experiments (e.g. -DSPEI_SLAB_EXP=1)
     flag_text = " ".join(flags)
     if _mtime(STAMP) < 0 or open(STAMP).read() != flag_text:
         force = True

@@ -17,6 +17,7 @@
 // HBM sees every input pixel once per output tile (+halo) instead of once per tap.
 // Call sites replaced: as igemm_f32.hip (convolutions with stride 1/2 and linears; transposed convs stay there).
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -52,14 +53,26 @@ struct SlabParams {
     int ln;                  // 1: LayerNorm(256) without affine is applied to every input row while it is staged
                              //    (fp32 input, K == 256: one wave-instruction loads exactly one token row)
     int stagger, stagger_slots;   // first-round start delay (units of 64 cycles) per co-resident workgroup slot
-    int dbg;                 // ablation switches for tools/ablate_slab.py (0 in production): 1 no staging loads,
+    long long* stamps;       // tuning build: phase stamps (tools/stamp_phases.py conv), else NULL
+    int dbg;                 // ablation switches for tools/ablate_slab.py (0 in production): 1 no staging loads, 8 weight stream from one hot group,
                              // 4 no epilogue stores
 };
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
 constexpr int G = 2;        // k-steps (of 16) per group
-constexpr int RING = 4;     // groups of B fragments in flight
+// groups of B fragments in flight, per tile configuration (registers: RING * G * TN * 4 per lane)
+#ifndef SPEI_RING_N32
+#define SPEI_RING_N32 4
+#endif
+#ifndef SPEI_RING_N64
+#define SPEI_RING_N64 4
+#endif
+#ifndef SPEI_RING_N128
+#define SPEI_RING_N128 4
+#endif
+template <int WM, int WN>
+constexpr int ring_depth() { return WN == 4 ? SPEI_RING_N128 : (WN == 2 ? SPEI_RING_N64 : SPEI_RING_N32); }
 
 // one 16-byte global chunk -> LDS: 4 fp32 -> 4 LP (8 B) [+ residual], or 8 LP unchanged (16 B)
 template <typename TA, bool SPLIT, typename LP>
@@ -91,8 +104,9 @@ struct Stage<float, SPLIT, LP> {
 
 // LP: 16-bit operand type (__bf16 or _Float16); TA / TO: float or LP
 template <int WM, int WN, int TM, int TN, bool SPLIT, typename TA, typename TO, typename LP>
-__global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParams p) {
+__global__ __launch_bounds__(64 * WM * WN, (WM == 4 && WN == 1 && TM <= 2 && !SPLIT) ? 4 : 1) void conv_slab_kernel(const SlabParams p) {
     constexpr int NT = 64 * WM * WN;                   // threads: 4 or 8 waves
+    constexpr int RING = ring_depth<WM, WN>();
     typedef Stage<TA, SPLIT, LP> ST;
     typedef typename lpv<LP>::x8 lp8;
     typedef typename lpv<LP>::x4 lp4;
@@ -133,6 +147,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
     }
 
     // ---- stage the input slab ----------------------------------------------------------------------------------
+    SPEI_STAMP(p.stamps, 0);
     {
         const TA* a0 = static_cast<const TA*>(p.a0);
         const TA* a1 = static_cast<const TA*>(p.a1);
@@ -227,7 +242,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
         for (int s = 0; s < G; ++s)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const size_t o = (size_t)(g * G + s) * 512;
+                const size_t o = (p.dbg & 8) ? (size_t)s * 512 : (size_t)(g * G + s) * 512;     // dbg 8: every group re-reads group 0 (L1-hot)
                 bring[slot][s][j] = *reinterpret_cast<const lp8*>(bptr[j] + o);
                 if (SPLIT) bring_lo[slot][s][j] = *reinterpret_cast<const lp8*>(bptr_lo[j] + o);
             }
@@ -242,7 +257,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
     for (int d = 0; d < RING; ++d) load_b(d, rg(min(d, ngroups - 1)));
     const int nfull = (ngroups / RING) * RING;
 
+    SPEI_STAMP(p.stamps, 1);
     __syncthreads();     // slab + offset table visible; the only barrier of the kernel
+    SPEI_STAMP(p.stamps, 2);
 
     // output row bookkeeping: in both tilings (TH x 32 pixels of a map, TH x 1 tokens) consecutive tile pixels are
     // consecutive output rows, so row(m-tile i, q) = mbase[i] + q with q = (r&3) + 8*(r>>2) + 4*fk in [0,32)
@@ -299,7 +316,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
                         av[i] = an[i];
                         if (SPLIT) avl[i] = anl[i];
                     }
+#if !defined(SPEI_SLAB_EXP) || !(SPEI_SLAB_EXP & 1)          // tuning experiment 1: no A-fragment re-reads (same MFMAs)
                     load_a(s + 1 < G ? go + (s + 1) * 32 : go_next);     // (the very last prefetch is a harmless re-read)
+#endif
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -319,7 +338,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
 #pragma unroll
                 for (int d = 0; d < RING; ++d) {
                     group(d, g0 + d);
+#if !defined(SPEI_SLAB_EXP) || !(SPEI_SLAB_EXP & 2)          // tuning experiment 2: no weight-ring refills (same MFMAs)
                     load_b(d, rg(min(g0 + d + RING, ngroups - 1)));
+#endif
                 }
             }
             // remainder (ngroups % RING groups): their fragments sit in ring slots 0.. from the last refill / the prologue
@@ -327,6 +348,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
             for (int d = 0; d < RING - 1; ++d)
                 if (nfull + d < ngroups) group(d, nfull + d);
         }
+        if (nc == 0) SPEI_STAMP(p.stamps, 3);
         // start the next chunk's weight stream before the epilogue's stores
         const int nbase = (nc * WN + wn) * TN;
         if (nc + 1 < p.n_chunks) {
@@ -348,44 +370,65 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_slab_kernel(const SlabParam
         int fr_e = fr;
         asm volatile("" : "+v"(fr_e));
         const int et = fr_e & 3, ecol = (fr_e >> 2) * 4;
+        // The activation and the optional epilogue inputs are uniform over the launch: one branch here instead of ~100 scalar
+        // branches per wave inside the loops (the plain ReLU / identity epilogues of the ResBlock convs are the hot ones).
+        auto epilogue = [&](auto act_c, auto plain_c) __attribute__((always_inline)) {
+            constexpr int ACT = decltype(act_c)::value;          // -1: decided per value at run time
+            constexpr bool PLAIN = decltype(plain_c)::value;     // no rowscale, no residual, no plane output
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int ncol0 = (nbase + j) * 32;
-                const float bias = biasv[j];
+                for (int j = 0; j < TN; ++j) {
+                    const int ncol0 = (nbase + j) * 32;
+                    const float bias = biasv[j];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float a[4];
+                    for (int k = 0; k < 4; ++k) {
+                        float a[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = acc[i][j][4 * k + e] + bias;
-                        if (p.act == SPEI_ACT_RELU) v = fmaxf(v, 0.f);
-                        else if (p.act == SPEI_ACT_GELU) v = gelu_erf(v);
-                        a[e] = v;
-                    }
-                    quad_transpose4(a[0], a[1], a[2], a[3], et);
-                    const int q = 8 * k + 4 * fk_e + et;         // accumulator row (r&3) + 8*(r>>2) + 4*fk with r = 4k + et
-                    if (q < qlim[i] && !(p.dbg & 4)) {
-                        const unsigned m = (unsigned)(mbase[i] + q * p.o_mul);
-                        f32x4 v = f32x4{a[0], a[1], a[2], a[3]};
-                        if (p.rowscale) { const float rs = p.rowscale[m]; v *= rs; }
-                        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * (unsigned)p.ldr + ncol0 + ecol);
-                        if (p.planes) {                       // 32 -> 3 channel tail: only the lanes holding channels 0..3 store
-                            if (ncol0 + ecol == 0) {
-                                float* po = reinterpret_cast<float*>(outp) + m;
-                                po[0] = v[0]; po[p.planes] = v[1]; po[2 * p.planes] = v[2];
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[i][j][4 * k + e] + bias;
+                            if constexpr (ACT == SPEI_ACT_RELU) v = fmaxf(v, 0.f);
+                            else if constexpr (ACT == SPEI_ACT_GELU) v = gelu_erf(v);
+                            else if constexpr (ACT < 0) {
+                                if (p.act == SPEI_ACT_RELU) v = fmaxf(v, 0.f);
+                                else if (p.act == SPEI_ACT_GELU) v = gelu_erf(v);
                             }
-                        } else if (sizeof(TO) == 4) {
-                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + m * (unsigned)p.ldo + ncol0 + ecol) = v;
-                        } else {
-                            *reinterpret_cast<lp4*>(reinterpret_cast<LP*>(outp) + m * (unsigned)p.ldo + ncol0 + ecol) = to_lp4<LP>(v);
+                            a[e] = v;
+                        }
+                        quad_transpose4(a[0], a[1], a[2], a[3], et);
+                        const int q = 8 * k + 4 * fk_e + et;         // accumulator row (r&3) + 8*(r>>2) + 4*fk with r = 4k + et
+                        if (q < qlim[i] && !(p.dbg & 4)) {
+                            const unsigned m = (unsigned)(mbase[i] + q * p.o_mul);
+                            f32x4 v = f32x4{a[0], a[1], a[2], a[3]};
+                            if constexpr (!PLAIN) {
+                                if (p.rowscale) { const float rs = p.rowscale[m]; v *= rs; }
+                                if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * (unsigned)p.ldr + ncol0 + ecol);
+                                if (p.planes) {                       // 32 -> 3 channel tail: only the lanes holding channels 0..3 store
+                                    if (ncol0 + ecol == 0) {
+                                        float* po = reinterpret_cast<float*>(outp) + m;
+                                        po[0] = v[0]; po[p.planes] = v[1]; po[2 * p.planes] = v[2];
+                                    }
+                                    continue;
+                                }
+                            }
+                            if constexpr (sizeof(TO) == 4) {
+                                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outp) + m * (unsigned)p.ldo + ncol0 + ecol) = v;
+                            } else {
+                                *reinterpret_cast<lp4*>(reinterpret_cast<LP*>(outp) + m * (unsigned)p.ldo + ncol0 + ecol) = to_lp4<LP>(v);
+                            }
                         }
                     }
                 }
             }
-        }
+        };
+        typedef std::integral_constant<int, SPEI_ACT_RELU> act_relu;
+        typedef std::integral_constant<int, SPEI_ACT_NONE> act_none;
+        typedef std::integral_constant<int, -1> act_any;
+        if (!p.rowscale && !p.res && !p.planes && p.act == SPEI_ACT_RELU) epilogue(act_relu{}, std::true_type{});
+        else if (!p.rowscale && !p.res && !p.planes && p.act == SPEI_ACT_NONE) epilogue(act_none{}, std::true_type{});
+        else epilogue(act_any{}, std::false_type{});
     }   // n chunks
+    SPEI_STAMP(p.stamps, 4);
 }
 
 template <int WM, int WN, int TM, int TN, bool SPLIT, typename TA, typename TO, typename LP>
@@ -395,6 +438,7 @@ int launch(const SlabParams& p, size_t lds, hipStream_t s) {
     q.n_chunks = p.N / (WN * TN * 32);
     static const int dbg = spei_knob("SPEI_SLAB_DBG", 0);
     q.dbg = dbg;
+    q.stamps = spei_stamp_buffer();
     static const int stagger = spei_knob("SPEI_SLAB_STAGGER", 0), slots = spei_knob("SPEI_SLAB_SLOTS", 3);
     q.stagger = stagger; q.stagger_slots = slots;
     dim3 grid(p.tiles_x * cdiv(p.Hout, p.TH), 1);

@@ -5,6 +5,8 @@ passed through SPEI_STAMP_PTR.  Prints the median per-phase durations in microse
 of workgroup start / end times across the launch.
 
     python tools/stamp_phases.py attn|mlp|block      (block: the first of the three groups of every workgroup)
+    python tools/stamp_phases.py conv1|conv2|conv3   (conv_slab: the 5x5 ResBlock conv at 720p level 1 / 2 / 3, f16 in and out;
+                                                      stamps: 0 start, 1 slab staged, 2 barrier passed, 3 main loop done, 4 stored)
 """
 import os
 import sys
@@ -16,7 +18,7 @@ which = sys.argv[1] if len(sys.argv) > 1 else "attn"
 H, W = 180, 320
 dev = "cuda:0"
 torch.cuda.set_device(0)
-nwg = 4096
+nwg = 8192
 stamps = torch.zeros(nwg, 16, dtype=torch.int64, device=dev)
 os.environ["SPEI_STAMP_PTR"] = str(stamps.data_ptr())
 
@@ -33,8 +35,19 @@ yhat = torch.randn(H * W, 256, device=dev).half()
 out = torch.empty_like(x)
 
 
+if which.startswith("conv"):
+    from speinet_amd.ops import FMap                                   # noqa: E402
+    ch, hh, ww = {"conv1": (32, 720, 1280), "conv2": (64, 360, 640), "conv3": (128, 180, 320)}[which]
+    cx = FMap(torch.randn(hh * ww, ch, device=dev).half(), hh, ww, ch)
+    cw = pack.PackedW(torch.randn(25, ch, ch) * 0.05, dev)
+    cb = torch.randn(ch, device=dev)
+    cout = FMap(torch.empty(hh * ww, ch, device=dev, dtype=torch.float16), hh, ww, ch)
+
+
 def run():
-    if which == "attn":
+    if which.startswith("conv"):
+        ops.igemm(cx, cw, cb, ch, ksize=5, out=cout)
+    elif which == "attn":
         ops.attn_fused(x, yhat, bk, H, W, 2, out)
     elif which == "block":
         ops.swin_block(x, yhat, bk, H, W, 2, out)
