@@ -71,6 +71,14 @@ int spei_igemm_f32(const float* a0, int lda0, int k0, const float* a1, int lda1,
                    const float* rowscale, int Hin, int Win, int Hout, int Wout, int N, int ksize, int stride,
                    int pad, int mode, int act, spei_stream_t stream);
 
+/* The same on `batch` equally sized maps stored one after the other (a0 / a1 / out / residual rows and rowscale entries of sample b
+ * start at b * map size): one launch, blockIdx.z = sample (the training step's batches of 200x200 crops give single maps of only
+ * 2 500 .. 40 000 pixels — a launch per sample leaves most of the chip idle). */
+int spei_igemm_f32_batched(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const float* w,
+                           const float* bias, float* out, int ldo, const float* residual, int ldr,
+                           const float* rowscale, int Hin, int Win, int Hout, int Wout, int N, int ksize, int stride,
+                           int pad, int mode, int act, int batch, spei_stream_t stream);
+
 /* Same contract on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 activations in HBM rounded to
  * bf16 while staged to LDS).  w_hi/w_lo: [tap][N][K] bf16.  w_lo == NULL: one bf16 product per MAC ("bf16");
  * w_lo != NULL: split product al*wh + ah*wl + ah*wh ("bf16x3", f32-grade at 3/16 of the f32 MFMA cost). */
@@ -219,6 +227,11 @@ int spei_add(const float* a, const float* b, float* out, int64_t n, spei_stream_
 int64_t spei_wgrad_ws_floats(int Hout, int Wout, int N, int K, int ksize);
 int spei_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* ws, int Hin, int Win,
                         int Hout, int Wout, int N, int K, int ksize, int stride, int pad, spei_stream_t stream);
+
+/* The same summed over `batch` equally sized maps stored one after the other (x: batch * Hin*Win rows, dy: batch * Hout*Wout rows):
+ * one launch, one fixed-order reduction over all samples' pixels. */
+int spei_conv_wgrad_f32_batched(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* ws, int Hin, int Win,
+                                int Hout, int Wout, int N, int K, int ksize, int stride, int pad, int batch, spei_stream_t stream);
 
 /* ReLU backward on the output of a fused conv + ReLU: dz = dy where y > 0, else 0 (n floats, n % 4 == 0). */
 int spei_relu_bwd(const float* y, const float* dy, float* dz, int64_t n, spei_stream_t stream);

@@ -29,6 +29,7 @@ SIGNATURES = {
     "spei_conv5_in": (I, [P, P, P, P, I, I, I, P]),
     "spei_conv5_out": (I, [P, I, P, P, P, I, I, I, P]),
     "spei_igemm_f32": (I, [P, I, I, P, I, I, P, P, P, I, P, I, P, I, I, I, I, I, I, I, I, I, I, P]),
+    "spei_igemm_f32_batched": (I, [P, I, I, P, I, I, P, P, P, I, P, I, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "spei_igemm_bf16": (I, [P, I, I, P, I, I, P, P, P, P, I, P, I, P, I, I, I, I, I, I, I, I, I, I, P]),
     "spei_conv_slab16": (I, [I, P, I, I, P, I, I, I, P, P, P, P, I, I, P, I, P, I, I, I, I, I, I, I, I, I, I, P]),
     "spei_attn_fused16": (I, [I, P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
@@ -54,6 +55,7 @@ SIGNATURES = {
     "spei_upsample_bicubic": (I, [P, I, P, I, I, I, I, I, I, P]),
     "spei_add": (I, [P, P, P, L, P]),
     "spei_wgrad_ws_floats": (L, [I, I, I, I, I]),
+    "spei_conv_wgrad_f32_batched": (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
     "spei_conv_wgrad_f32": (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "spei_relu_bwd": (I, [P, P, P, L, P]),
     "spei_plane_ws_floats": (L, [I, I, I]),

@@ -19,6 +19,7 @@ struct WgradParams {
     const float* dy;
     float* part;          // [nchunks][T][N][K]
     int ldx, ldy, K, N, Hin, Win, Hout, Wout, ks, stride, pad, chunk_px, ntn, ntk;
+    int batch;            // equally sized maps stored one after the other: the pixel index runs over all of them
 };
 
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     const int t = tile / p.ntn;
     const int ty = t / p.ks, tx = t - ty * p.ks;
     const int n = nt * 32 + fr, k = kt * 32 + fr;
-    const int M = p.Hout * p.Wout;
+    const int M = p.Hout * p.Wout * p.batch;                // output pixels of all samples; oy runs over the stacked maps
     const int c0 = blockIdx.y * p.chunk_px;
     const int per_wave = p.chunk_px / 4;                    // chunk_px is a multiple of 8
     const int m0 = c0 + wave * per_wave, m1 = min(M, m0 + per_wave);
@@ -40,17 +41,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     int m = m0 + fk;
     int oy = m / p.Wout, ox = m - oy * p.Wout;
+    int smp = oy / p.Hout;                                  // sample of this output row
+    oy -= smp * p.Hout;
     for (int mm = m0; mm < m1; mm += 2) {
         float a = 0.f, b = 0.f;
         if (m < m1) {
             if (n < p.N) a = p.dy[(size_t)m * p.ldy + n];
             const int iy = oy * p.stride - p.pad + ty, ix = ox * p.stride - p.pad + tx;
-            if (k < p.K && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) b = p.x[((size_t)iy * p.Win + ix) * p.ldx + k];
+            if (k < p.K && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win)
+                b = p.x[(((size_t)smp * p.Hin + iy) * p.Win + ix) * p.ldx + k];
         }
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         m += 2;
         ox += 2;
-        while (ox >= p.Wout) { ox -= p.Wout; ++oy; }
+        while (ox >= p.Wout) {
+            ox -= p.Wout;
+            if (++oy == p.Hout) { oy = 0; ++smp; }
+        }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
 // Stage 1: a block owns an R x 64-pixel... tile of TR rows x TC columns, threads = channels x columns; stage 2 combines the tile
 // partials in a fixed order.  C <= 128, C % 4 == 0.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int GT = 32;        // tile rows = tile columns
+constexpr int GT = 16;        // tile rows = tile columns (16: a 200x200 training crop still gives 169 workgroups)
 
 template <bool PROD>
 __global__ __launch_bounds__(256) void plane_stats_kernel(const float* __restrict__ a, const float* __restrict__ b, int H, int W, int C,
@@ -237,9 +244,10 @@ extern "C" int64_t spei_wgrad_ws_floats(int Hout, int Wout, int N, int K, int ks
     return (int64_t)64 * ksize * ksize * N * K + 64 * 256;
 }
 
-extern "C" int spei_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* ws, int Hin, int Win,
-                                   int Hout, int Wout, int N, int K, int ksize, int stride, int pad, spei_stream_t stream) {
+static int conv_wgrad_run(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* ws, int Hin, int Win,
+                          int Hout, int Wout, int N, int K, int ksize, int stride, int pad, int batch, spei_stream_t stream) {
     SPEI_REQUIRE(x && dy && dw && ws, "spei_conv_wgrad_f32: null pointer");
+    SPEI_REQUIRE(batch >= 1 && (int64_t)batch * Hout * Wout < (1ll << 30), "spei_conv_wgrad_f32: batch=%d", batch);
     SPEI_REQUIRE(N > 0 && K > 0 && N <= 256 && ldx >= K && ldy >= N, "spei_conv_wgrad_f32: N=%d K=%d ldx=%d ldy=%d", N, K, ldx, ldy);
     SPEI_REQUIRE(ksize == 1 || ksize == 3 || ksize == 5, "spei_conv_wgrad_f32: ksize=%d", ksize);
     SPEI_REQUIRE(stride == 1 || stride == 2, "spei_conv_wgrad_f32: stride=%d", stride);
@@ -247,8 +255,9 @@ extern "C" int spei_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
     SPEI_REQUIRE(Hout == (Hin + 2 * pad - ksize) / stride + 1 && Wout == (Win + 2 * pad - ksize) / stride + 1,
                  "spei_conv_wgrad_f32: output size %dx%d inconsistent with input %dx%d k%d s%d p%d", Hout, Wout, Hin, Win, ksize, stride, pad);
     hipStream_t st = (hipStream_t)stream;
-    const int M = Hout * Wout, T = ksize * ksize;
+    const int M = Hout * Wout * batch, T = ksize * ksize;
     WgradParams p;
+    p.batch = batch;
     p.x = x; p.dy = dy; p.part = ws; p.ldx = ldx; p.ldy = ldy; p.K = K; p.N = N;
     p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout; p.ks = ksize; p.stride = stride; p.pad = pad;
     int chunk = cdiv(M, 64);
@@ -262,13 +271,26 @@ extern "C" int spei_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
     hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(count, 256)), dim3(256), 0, st, ws, dw, count, nchunks);
     if (dbias) {
         float* bpart = ws + (size_t)64 * T * N * K;
-        const int rows = cdiv(M, 64);
+        int nbmax = (64 * 256) / N;                          // the partials live in the 64 x 256 floats behind the weight partials
+        if (nbmax > 512) nbmax = 512;
+        const int rows = cdiv(M, nbmax);
         const int nb = cdiv(M, rows);
         hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, st, dy, ldy, N, (int64_t)M, rows, bpart);
         hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(256), 0, st, bpart, dbias, (int64_t)N, nb);
     }
     SPEI_CHECK_LAUNCH("spei_conv_wgrad_f32");
     return 0;
+}
+
+extern "C" int spei_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* ws, int Hin, int Win,
+                                   int Hout, int Wout, int N, int K, int ksize, int stride, int pad, spei_stream_t stream) {
+    return conv_wgrad_run(x, ldx, dy, ldy, dw, dbias, ws, Hin, Win, Hout, Wout, N, K, ksize, stride, pad, 1, stream);
+}
+
+extern "C" int spei_conv_wgrad_f32_batched(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* ws, int Hin,
+                                           int Win, int Hout, int Wout, int N, int K, int ksize, int stride, int pad, int batch,
+                                           spei_stream_t stream) {
+    return conv_wgrad_run(x, ldx, dy, ldy, dw, dbias, ws, Hin, Win, Hout, Wout, N, K, ksize, stride, pad, batch, stream);
 }
 
 extern "C" int spei_relu_bwd(const float* y, const float* dy, float* dz, int64_t n, spei_stream_t stream) {

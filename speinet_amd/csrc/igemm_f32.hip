@@ -27,6 +27,7 @@ struct IgemmParams {
     int M, N, K;
     int Hin, Win, Hout, Wout;
     int ks, stride, pad, mode, act;
+    long long sa0, sa1, so, sr, ss;   // per-sample strides in floats (blockIdx.z = sample of a batch of equally sized maps)
 };
 
 constexpr int BK = 32;
@@ -35,7 +36,16 @@ constexpr int LDSK = BK + 1;
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmParams pin) {
+    IgemmParams p = pin;
+    {
+        const long long z = blockIdx.z;           // sample: every map pointer moves by one sample's extent
+        p.a0 += z * pin.sa0;
+        if (p.a1) p.a1 += z * pin.sa1;
+        p.out += z * pin.so;
+        if (p.res) p.res += z * pin.sr;
+        if (p.rowscale) p.rowscale += z * pin.ss;
+    }
     constexpr int TM = BM / WM / 32;   // 32x32 MFMA tiles per wave along M
     constexpr int TN = BN / WN / 32;
     constexpr int AP = BM / 32;        // float4 loads per thread for the A tile
@@ -177,10 +187,10 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmParams p) {
 }
 
 template <int BM, int BN, int WM, int WN>
-int launch(const IgemmParams& p, hipStream_t s) {
+int launch(const IgemmParams& p, int batch, hipStream_t s) {
     const size_t lds = (size_t)2 * (BM + BN) * LDSK * sizeof(float);
     ensure_dyn_lds<&igemm_f32_kernel<BM, BN, WM, WN>>(lds);
-    dim3 grid(cdiv(p.M, BM), p.N / BN);
+    dim3 grid(cdiv(p.M, BM), p.N / BN, batch);
     hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN>), grid, dim3(256), lds, s, p);
     SPEI_CHECK_LAUNCH("spei_igemm_f32");
     return 0;
@@ -188,10 +198,11 @@ int launch(const IgemmParams& p, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int spei_igemm_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const float* w,
-                              const float* bias, float* out, int ldo, const float* residual, int ldr,
-                              const float* rowscale, int Hin, int Win, int Hout, int Wout, int N, int ksize,
-                              int stride, int pad, int mode, int act, spei_stream_t stream) {
+static int igemm_f32_run(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const float* w,
+                         const float* bias, float* out, int ldo, const float* residual, int ldr,
+                         const float* rowscale, int Hin, int Win, int Hout, int Wout, int N, int ksize,
+                         int stride, int pad, int mode, int act, int batch, spei_stream_t stream) {
+    SPEI_REQUIRE(batch >= 1 && batch <= 65535, "spei_igemm_f32: batch=%d", batch);
     SPEI_REQUIRE(a0 && w && out, "spei_igemm_f32: null pointer");
     SPEI_REQUIRE(k0 > 0 && k0 % 32 == 0 && k1 >= 0 && k1 % 32 == 0, "spei_igemm_f32: k0=%d k1=%d must be multiples of 32", k0, k1);
     SPEI_REQUIRE(k1 == 0 || a1, "spei_igemm_f32: a1 missing");
@@ -218,8 +229,26 @@ extern "C" int spei_igemm_f32(const float* a0, int lda0, int k0, const float* a1
     p.M = Hout * Wout; p.N = N; p.K = k0 + k1;
     p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout;
     p.ks = ksize; p.stride = stride; p.pad = pad; p.mode = mode; p.act = act;
+    p.sa0 = (long long)Hin * Win * lda0; p.sa1 = (long long)Hin * Win * lda1;
+    p.so = (long long)Hout * Wout * ldo; p.sr = (long long)Hout * Wout * ldr; p.ss = (long long)Hout * Wout;
     hipStream_t s = (hipStream_t)stream;
-    if (N % 128 == 0) return launch<128, 128, 2, 2>(p, s);
-    if (N % 64 == 0) return launch<128, 64, 4, 1>(p, s);
-    return launch<128, 32, 4, 1>(p, s);
+    if (N % 128 == 0) return launch<128, 128, 2, 2>(p, batch, s);
+    if (N % 64 == 0) return launch<128, 64, 4, 1>(p, batch, s);
+    return launch<128, 32, 4, 1>(p, batch, s);
+}
+
+extern "C" int spei_igemm_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const float* w,
+                              const float* bias, float* out, int ldo, const float* residual, int ldr,
+                              const float* rowscale, int Hin, int Win, int Hout, int Wout, int N, int ksize,
+                              int stride, int pad, int mode, int act, spei_stream_t stream) {
+    return igemm_f32_run(a0, lda0, k0, a1, lda1, k1, w, bias, out, ldo, residual, ldr, rowscale, Hin, Win, Hout, Wout, N, ksize, stride, pad,
+                         mode, act, 1, stream);
+}
+
+extern "C" int spei_igemm_f32_batched(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const float* w,
+                                      const float* bias, float* out, int ldo, const float* residual, int ldr,
+                                      const float* rowscale, int Hin, int Win, int Hout, int Wout, int N, int ksize,
+                                      int stride, int pad, int mode, int act, int batch, spei_stream_t stream) {
+    return igemm_f32_run(a0, lda0, k0, a1, lda1, k1, w, bias, out, ldo, residual, ldr, rowscale, Hin, Win, Hout, Wout, N, ksize, stride, pad,
+                         mode, act, batch, stream);
 }

@@ -61,21 +61,24 @@ def _w_conv(weight: torch.Tensor) -> torch.Tensor:
 
 def _igemm(ctx: Ctx, a: torch.Tensor, K: int, w_tnk: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, N: int,
            Hin: int, Win: int, Hout: int, Wout: int, ksize: int, stride: int, mode: int, act: int,
-           residual: Optional[torch.Tensor] = None, rowscale: Optional[torch.Tensor] = None) -> None:
+           residual: Optional[torch.Tensor] = None, rowscale: Optional[torch.Tensor] = None, batch: int = 1) -> None:
+    """One launch over `batch` equally sized maps stored one after the other (blockIdx.z = sample)."""
     assert a.is_contiguous() and out.is_contiguous() and w_tnk.is_contiguous() and tuple(w_tnk.shape) == (ksize * ksize, N, K), \
         (tuple(w_tnk.shape), ksize, N, K)
-    assert a.shape == (Hin * Win, K) and out.shape == (Hout * Wout, N) and K % 32 == 0 and N % 32 == 0
+    assert a.shape == (batch * Hin * Win, K) and out.shape == (batch * Hout * Wout, N) and K % 32 == 0 and N % 32 == 0
+    assert residual is None or (residual.is_contiguous() and residual.shape == out.shape)
     lib = _lib.lib()
-    _lib.check(lib.spei_igemm_f32(_p(ctx, a), K, K, _NULL, 0, 0, _p(ctx, w_tnk), _p(ctx, bias), _p(ctx, out), N,
-                                  _p(ctx, residual), N if residual is not None else 0, _p(ctx, rowscale), Hin, Win, Hout, Wout, N,
-                                  ksize, stride, ksize // 2, mode, act, ctx._stream()), "spei_igemm_f32")
+    _lib.check(lib.spei_igemm_f32_batched(_p(ctx, a), K, K, _NULL, 0, 0, _p(ctx, w_tnk), _p(ctx, bias), _p(ctx, out), N,
+                                          _p(ctx, residual), N if residual is not None else 0, _p(ctx, rowscale), Hin, Win, Hout, Wout, N,
+                                          ksize, stride, ksize // 2, mode, act, batch, ctx._stream()), "spei_igemm_f32_batched")
 
 
 def _wgrad(ctx: Ctx, x: torch.Tensor, K: int, dy: torch.Tensor, N: int, Hin: int, Win: int, Hout: int, Wout: int, ksize: int,
-           stride: int, want_bias: bool = True):
-    """dw [tap][N][K], db [N] of a Conv2d(K -> N) from its input rows x and output-gradient rows dy (one map)."""
+           stride: int, want_bias: bool = True, batch: int = 1):
+    """dw [tap][N][K], db [N] of a Conv2d(K -> N) from its input rows x and output-gradient rows dy, summed over `batch` maps."""
     lib = _lib.lib()
     dev = x.device
+    assert x.shape == (batch * Hin * Win, K) and dy.shape == (batch * Hout * Wout, N)
     dw = torch.empty(ksize * ksize, N, K, device=dev)
     db = torch.empty(N, device=dev) if want_bias else None
     for n0 in range(0, N, 256):                                       # the kernel takes at most 256 output channels per call
@@ -85,8 +88,8 @@ def _wgrad(ctx: Ctx, x: torch.Tensor, K: int, dy: torch.Tensor, N: int, Hin: int
         ws = torch.empty(lib.spei_wgrad_ws_floats(Hout, Wout, nn_, K, ksize), device=dev)
         dyp = C.c_void_p(dy.data_ptr() + 4 * n0)
         assert dy.device == ctx.device and dy.is_contiguous() and dy.dtype == torch.float32
-        _lib.check(lib.spei_conv_wgrad_f32(_p(ctx, x), K, dyp, N, _p(ctx, dwp), _p(ctx, dbp), _p(ctx, ws), Hin, Win, Hout, Wout, nn_, K,
-                                           ksize, stride, ksize // 2, ctx._stream()), "spei_conv_wgrad_f32")
+        _lib.check(lib.spei_conv_wgrad_f32_batched(_p(ctx, x), K, dyp, N, _p(ctx, dwp), _p(ctx, dbp), _p(ctx, ws), Hin, Win, Hout, Wout, nn_,
+                                                   K, ksize, stride, ksize // 2, batch, ctx._stream()), "spei_conv_wgrad_f32_batched")
         if N > 256:
             dw[:, n0:n0 + nn_] = dwp
             if want_bias:
@@ -114,9 +117,7 @@ class _Conv2d(torch.autograd.Function):
         b = bias.detach().contiguous()
         out = torch.empty(B * ho * wo, n, device=x.device)
         res = residual.contiguous() if residual is not None else None
-        for i in range(B):
-            _igemm(ctx, x[i * H * W:(i + 1) * H * W], k, w, b, out[i * ho * wo:(i + 1) * ho * wo], n, H, W, ho, wo, ksize, stride, CONV,
-                   ACT_RELU if relu else ACT_NONE, res[i * ho * wo:(i + 1) * ho * wo] if res is not None else None)
+        _igemm(ctx, x, k, w, b, out, n, H, W, ho, wo, ksize, stride, CONV, ACT_RELU if relu else ACT_NONE, res, batch=B)
         fctx.save_for_backward(x, weight, out if relu else None)
         fctx.meta = (B, H, W, ho, wo, ksize, stride, relu, residual is not None)
         return out
@@ -131,23 +132,17 @@ class _Conv2d(torch.autograd.Function):
         dres = dy if has_res else None
         assert not (relu and has_res)
         dz = _relu_mask(ctx, y, dy) if relu else dy
-        dw = db = None
-        for i in range(B):
-            dwi, dbi = _wgrad(ctx, x[i * H * W:(i + 1) * H * W], k, dz[i * ho * wo:(i + 1) * ho * wo], n, H, W, ho, wo, ksize, stride)
-            dw, db = (dwi, dbi) if dw is None else (dw + dwi, db + dbi)
+        dw, db = _wgrad(ctx, x, k, dz, n, H, W, ho, wo, ksize, stride, batch=B)
         dweight = dw.view(ksize, ksize, n, k).permute(2, 3, 0, 1).contiguous()
         dx = None
         if fctx.needs_input_grad[0]:
             # data gradient = transposed convolution of dZ with the weights' channel axes swapped (include/speinet_hip.h)
             wt = _w_conv(weight).transpose(1, 2).contiguous()                              # [t][k][n]
             hf, wf = ho * stride, wo * stride
-            dx = torch.empty(B * H * W, k, device=dy.device)
-            full = dx if (hf, wf) == (H, W) else torch.empty(hf * wf, k, device=dy.device)
-            for i in range(B):
-                dst = dx[i * H * W:(i + 1) * H * W] if full is dx else full
-                _igemm(ctx, dz[i * ho * wo:(i + 1) * ho * wo], n, wt, None, dst, k, ho, wo, hf, wf, ksize, stride, CONV_T, ACT_NONE)
-                if full is not dx:        # odd input size under stride 2: the transposed conv made one row / column too many
-                    dx[i * H * W:(i + 1) * H * W] = full.view(hf, wf, k)[:H, :W].reshape(H * W, k)
+            dx = torch.empty(B * hf * wf, k, device=dy.device)
+            _igemm(ctx, dz, n, wt, None, dx, k, ho, wo, hf, wf, ksize, stride, CONV_T, ACT_NONE, batch=B)
+            if (hf, wf) != (H, W):        # odd input size under stride 2: the transposed conv made one row / column too many
+                dx = dx.view(B, hf, wf, k)[:, :H, :W].reshape(B * H * W, k).contiguous()
         return dx, dweight, db, dres, None, None, None, None, None, None
 
 
@@ -164,9 +159,7 @@ class _ConvT2d(torch.autograd.Function):
         w = weight.detach().permute(2, 3, 1, 0).reshape(9, n, k).contiguous()               # [tap][N][K]
         out = torch.empty(B * 4 * H * W, n, device=x.device)
         b = bias.detach().contiguous()
-        for i in range(B):
-            _igemm(ctx, x[i * H * W:(i + 1) * H * W], k, w, b, out[i * 4 * H * W:(i + 1) * 4 * H * W], n, H, W, 2 * H, 2 * W, 3, 2, CONV_T,
-                   ACT_RELU)
+        _igemm(ctx, x, k, w, b, out, n, H, W, 2 * H, 2 * W, 3, 2, CONV_T, ACT_RELU, batch=B)
         fctx.save_for_backward(x, weight, out)
         fctx.meta = (B, H, W)
         return out
@@ -180,12 +173,8 @@ class _ConvT2d(torch.autograd.Function):
         dz = _relu_mask(ctx, y, dy.contiguous())
         wc = _w_conv(weight)                                                               # Conv2d view: [tap][out = K][in = N]
         dx = torch.empty(B * H * W, k, device=dy.device)
-        dw = None
-        for i in range(B):
-            dzi = dz[i * 4 * H * W:(i + 1) * 4 * H * W]
-            _igemm(ctx, dzi, n, wc, None, dx[i * H * W:(i + 1) * H * W], k, 2 * H, 2 * W, H, W, 3, 2, CONV, ACT_NONE)
-            dwi, _ = _wgrad(ctx, dzi, n, x[i * H * W:(i + 1) * H * W], k, 2 * H, 2 * W, H, W, 3, 2, want_bias=False)   # [t][K][N]
-            dw = dwi if dw is None else dw + dwi
+        _igemm(ctx, dz, n, wc, None, dx, k, 2 * H, 2 * W, H, W, 3, 2, CONV, ACT_NONE, batch=B)
+        dw, _ = _wgrad(ctx, dz, n, x, k, 2 * H, 2 * W, H, W, 3, 2, want_bias=False, batch=B)                            # [t][K][N]
         dweight = dw.view(3, 3, k, n).permute(2, 3, 0, 1).contiguous()
         return dx, dweight, dz.sum(dim=0), None, None, None
 
@@ -217,10 +206,7 @@ class _ConvIn(torch.autograd.Function):
         ctx = _ctx(dy.device)
         n, k = weight.shape[0], weight.shape[1]
         dz = _relu_mask(ctx, y, dy.contiguous())
-        dw = db = None
-        for i in range(B):
-            dwi, dbi = _wgrad(ctx, x[i * H * W:(i + 1) * H * W], k, dz[i * H * W:(i + 1) * H * W], n, H, W, H, W, 5, 1)
-            dw, db = (dwi, dbi) if dw is None else (dw + dwi, db + dbi)
+        dw, db = _wgrad(ctx, x, k, dz, n, H, W, H, W, 5, 1, batch=B)
         return None, dw.view(5, 5, n, k).permute(2, 3, 0, 1).contiguous(), db
 
 
