@@ -288,3 +288,29 @@ def test_training_step_vs_reference(golden_dir, name):
             # gradient is within rounding of zero can land on the other side, so compare in units of the step
             frac_bad = ((got - ref).abs() > 2e-5).float().mean().item()
             assert frac_bad < 0.02, (k, frac_bad)
+
+
+def test_trainer_steps_reduce_the_loss():
+    """speinet_amd.trainer.Trainer on the HIP model: five Adam steps on one fixed batch of 40x40 crops lower the loss (train()
+    mode, DropPath drawn from torch's generator, HEM masks from numpy's), and every parameter moved."""
+    from speinet_amd.loss import Loss
+    from speinet_amd.swint import SPEINet
+    from speinet_amd.speinet import default_args
+    from speinet_amd.synth import synth_frames, synth_state_dict
+    from speinet_amd.trainer import Trainer
+    args = default_args()
+    args.n_sequence = 3
+    net = SPEINet(n_sequence=3, args=args)
+    net.load_state_dict(synth_state_dict(net.state_dict(), seed=0), strict=True)
+    net = net.to(DEV)
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
+    x = synth_frames(2, 40, 40, seed=31)[:, :3].contiguous().to(DEV)
+    gt = synth_frames(2, 40, 40, seed=32)[:, 1].contiguous().to(DEV)
+    torch.manual_seed(5)
+    np.random.seed(5)
+    tr = Trainer(net, Loss("1*L1+2*HEM", device=DEV), lr=1e-4)
+    losses = [tr.step(x, gt) for _ in range(5)]
+    print("losses:", ", ".join(f"{v:.5f}" for v in losses))
+    assert losses[-1] < losses[0] and all(np.isfinite(losses))
+    moved = sum(int(not torch.equal(before[k], v.detach())) for k, v in net.named_parameters())
+    assert moved == len(before), (moved, len(before))

@@ -4,8 +4,11 @@ option/template.py:6,22: patch 200, n_sequence 3, batch 20 over the authors' 3 G
 backward, Adam(lr 1e-4).step(), synthetic crops and name-keyed weights.
 
     python tools/train_bench.py [--batch 4] [--patch 200] [--steps 5] [--warmup 2]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/train_bench.py ...   (N ranks:
+        `--batch` crops per rank, gradients averaged over RCCL in 64 MB buckets, speinet_amd.trainer; weak scaling)
 
-Prints one JSON line: crops/s, ms per step and its split (forward / loss + backward / optimizer), measured with HIP events."""
+Rank 0 prints one JSON line: whole-job crops/s, ms per step (max over ranks) and rank 0's split (forward / loss + backward +
+gradient all-reduce / optimizer), measured with HIP events."""
 import argparse
 import json
 import os
@@ -19,6 +22,7 @@ from speinet_amd.loss import Loss                                         # noqa
 from speinet_amd.speinet import default_args                             # noqa: E402
 from speinet_amd.swint import SPEINet                                    # noqa: E402
 from speinet_amd.synth import synth_frames, synth_state_dict             # noqa: E402
+from speinet_amd.trainer import allreduce_gradients, broadcast_buffers   # noqa: E402
 
 
 def main():
@@ -28,7 +32,13 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     a = ap.parse_args()
-    dev = "cuda:0"
+    rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
+    dev = f"cuda:{local}"
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world)
     args = default_args()
     args.n_sequence = 3
     net = SPEINet(n_sequence=3, args=args)
@@ -36,10 +46,10 @@ def main():
     net = net.to(dev).train()
     opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=0.0)
     loss_fn = Loss("1*L1+2*HEM", device=dev)
-    x = synth_frames(a.batch, a.patch, a.patch, seed=7)[:, :3].contiguous().to(dev)
-    gt = synth_frames(a.batch, a.patch, a.patch, seed=8)[:, 1].contiguous().to(dev)
-    torch.manual_seed(0)
-    np.random.seed(0)
+    x = synth_frames(a.batch, a.patch, a.patch, seed=7 + 2 * rank)[:, :3].contiguous().to(dev)
+    gt = synth_frames(a.batch, a.patch, a.patch, seed=8 + 2 * rank)[:, 1].contiguous().to(dev)
+    torch.manual_seed(rank)
+    np.random.seed(rank)
     ev = lambda: torch.cuda.Event(enable_timing=True)
     split = np.zeros(3)
     for it in range(a.warmup + a.steps):
@@ -50,18 +60,27 @@ def main():
         opt.zero_grad()
         loss = loss_fn(out, gt)
         loss.backward()
+        allreduce_gradients(net.parameters())
         e[2].record()
         opt.step()
+        broadcast_buffers(net)
         e[3].record()
         torch.cuda.synchronize()
         if it >= a.warmup:
             split += [e[i].elapsed_time(e[i + 1]) for i in range(3)]
     split /= a.steps
     ms = float(split.sum())
-    print(json.dumps({"metric": "training crops/s, swint model, fwd + loss + bwd + Adam", "value": a.batch * 1e3 / ms, "unit": "crops/s",
-                      "batch": a.batch, "patch": a.patch, "n_sequence": 3, "ms_per_step": ms,
-                      "ms": {"forward": float(split[0]), "loss_backward": float(split[1]), "adam": float(split[2])},
-                      "loss": float(loss.item()), "dtype": "f32", "data": "synthetic"}))
+    if dist is not None:
+        t = torch.tensor([ms], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "training crops/s, swint model, fwd + loss + bwd + Adam", "value": world * a.batch * 1e3 / ms,
+                          "unit": "crops/s", "n_gpus": world, "batch_per_gpu": a.batch, "patch": a.patch, "n_sequence": 3, "ms_per_step": ms,
+                          "ms": {"forward": float(split[0]), "loss_backward": float(split[1]), "adam": float(split[2])},
+                          "loss": float(loss.item()), "dtype": "f32", "data": "synthetic", "scaling": "weak"}))
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
