@@ -292,7 +292,9 @@ class SPEINet(nn.Module):
         """
         self._check_input(x)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise RuntimeError("speinet_amd: backward kernels are not built yet; use eval() under torch.no_grad()")
+            raise RuntimeError("speinet_amd.speinet: the differentiable graph (HIP forward + backward) is built for the swint model "
+                               "(speinet_amd.swint, trainer/trainer_swint.py); SearchTransfer's backward is not — use eval() under "
+                               "torch.no_grad() here")
         _lib.lib()
         h, w = x.shape[-2:]
         with torch.cuda.device(x.device):           # kernels launch on the CURRENT device: make it the tensor's

@@ -19,7 +19,7 @@ import sys
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sys.argv[1:]:
-    for f in glob.glob(f"{d}/*/*_counter_collection.csv"):
+    for f in glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = re.sub(r"\(anonymous namespace\)::|void ", "", r["Kernel_Name"])
             k = re.sub(r"\(.*", "", k)[:60]

@@ -12,7 +12,7 @@ import sys
 
 
 def counter(d, name, kernel_substr):
-    f = glob.glob(f"{d}/*/*_counter_collection.csv")[0]
+    f = (glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True))[0]
     vals, kname = [], None
     for r in csv.DictReader(open(f)):
         if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == name:
@@ -23,7 +23,7 @@ def counter(d, name, kernel_substr):
 
 
 def total(d, name):
-    f = glob.glob(f"{d}/*/*_counter_collection.csv")[0]
+    f = (glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True))[0]
     return sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == name)
 
 
