@@ -273,6 +273,28 @@ int spei_window_attention_bwd(const float* q, const float* kv, const float* relb
 /* out[m][n] = x[m][n] * rowscale[m] (the DropPath factor of model/swinir.py:278-279 applied to a branch gradient).  N % 4 == 0. */
 int spei_scale_rows(const float* x, const float* rowscale, float* out, int64_t M, int N, spei_stream_t stream);
 
+/* ---- backward of SearchTransfer / SelfTransfer and the decoder glue (model/SearchTransfer.py:24-79, model/speinet.py:92-120 under
+ * loss.backward(), trainer/trainer_swint_hsa_nsf.py:34-40).  Gather form, fixed summation order. ---- */
+
+/* Gradient of S (the maximal normalised 3x3-patch correlation, spei_corr_argmax) with respect to the query map lr [H*W][C]:
+ * dlr from dS [H*W], the forward's S / arg and the two inverse patch norms (spei_patch_invnorm).  C % 4 == 0. */
+int spei_corr_s_bwd_lr(const float* lr, const float* ref, const float* inv_lr, const float* inv_ref, const float* S, const int32_t* arg,
+                       const float* dS, float* dlr, int H, int W, int Hr, int Wr, int C, spei_stream_t stream);
+
+/* Gradient with respect to a REFERENCE map at scale s in {1,2,4} ([Hr3*s * Wr3*s][C]): the adjoint of spei_gather_fold (dT
+ * [H3*s * W3*s][C], or NULL) plus, at s == 1, the gradient of S through the reference patches (dS, or NULL; then ref / lr /
+ * inv_lr / inv_ref / S are read).  order [H3*W3]: the queries sorted by arg (stable); start [Hr3*Wr3 + 1]: first entry of each
+ * reference position's list. */
+int spei_search_bwd_ref(const float* ref, const float* dT, const float* lr, const float* inv_lr, const float* inv_ref, const float* S,
+                        const float* dS, const int32_t* order, const int32_t* start, float* dref, int H3, int W3, int Hr3, int Wr3,
+                        int C, int s, spei_stream_t stream);
+
+/* Adjoint of spei_upsample_bicubic (act NONE): dy [H*s * W*s][C] -> dx [H*W][C], s in {2,4}. */
+int spei_upsample_bicubic_bwd(const float* dy, float* dx, int H, int W, int C, int s, spei_stream_t stream);
+
+/* out[m] = sum_n a[m][n] * b[m][n] (the gradient of a per-row scale such as `* weight_S`, model/speinet.py:93). */
+int spei_rowdot(const float* a, const float* b, float* out, int64_t M, int N, spei_stream_t stream);
+
 /* Row a11 — LD sharpness detector features (inference_SPEINet.py:54-189).  spei_det_gray: [N][3][H][W] fp32 0..255 ->
  * gray [N][H][W] in 0..1 (ITU-R 601 weights).  spei_det_features: gray -> out [N][6] = LAP1, MIS3, WAV1, GRA7, STA3, DCT3
  * with window size k (odd; the reference uses 11).  ws: spei_det_ws_floats(N,H,W,k) floats. */

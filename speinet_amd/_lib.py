@@ -67,6 +67,10 @@ SIGNATURES = {
     "spei_gelu_bwd": (I, [P, P, P, L, P]),
     "spei_window_attention_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P]),
     "spei_scale_rows": (I, [P, P, P, L, I, P]),
+    "spei_corr_s_bwd_lr": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "spei_search_bwd_ref": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
+    "spei_upsample_bicubic_bwd": (I, [P, P, I, I, I, I, P]),
+    "spei_rowdot": (I, [P, P, P, L, I, P]),
     "spei_det_gray": (I, [P, P, I, I, I, P]),
     "spei_det_ws_floats": (L, [I, I, I, I]),
     "spei_det_features": (I, [P, P, P, I, I, I, I, P]),

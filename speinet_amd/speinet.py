@@ -282,19 +282,23 @@ class SPEINet(nn.Module):
         return [v == 0 for v in flags.tolist()]
 
     def forward(self, x: torch.Tensor, routing: Optional[Sequence[bool]] = None, profile: Optional[dict] = None,
-                capture: Optional[dict] = None) -> torch.Tensor:
+                capture: Optional[dict] = None, drop_path_scales: Optional[dict] = None) -> torch.Tensor:
         """x [B, n_sequence+2, 3, H, W] fp32 in [0,1] -> [B, 3, H, W] (unclamped).
 
         ``routing`` (optional, beyond the reference signature): per-sample "frame 3 is all zero" decisions when the
         caller already knows them (the harness zeroes the frame itself), which removes the host sync.
         ``profile`` (optional): {op name: []} filled with HIP event pairs around those ops (eager launches only).
         ``capture`` (optional): a dict that receives SearchTransfer's arg-max / weight map (parity tests; eager only).
+        ``drop_path_scales`` (optional, train() mode): the DropPath factors (`train.speinet_drop_path_scales`); drawn from torch's
+        CPU generator in the reference's order when not given.
         """
         self._check_input(x)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise RuntimeError("speinet_amd.speinet: the differentiable graph (HIP forward + backward) is built for the swint model "
-                               "(speinet_amd.swint, trainer/trainer_swint.py); SearchTransfer's backward is not — use eval() under "
-                               "torch.no_grad() here")
+        if self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            # the differentiable fp32 graph (HIP forward AND backward kernels, speinet_amd/train.py): train() mode runs the gates'
+            # BatchNorm(1) on batch statistics and DropPath, as the reference module does under
+            # trainer/trainer_swint_hsa_nsf.py:27-40; eval() with autograd recording is the same graph with running statistics
+            from . import train
+            return train.forward_speinet(self, x, scales=drop_path_scales)
         _lib.lib()
         h, w = x.shape[-2:]
         with torch.cuda.device(x.device):           # kernels launch on the CURRENT device: make it the tensor's

@@ -331,6 +331,142 @@ class _WindowAttention(torch.autograd.Function):
         return dq, dkv, part.sum(dim=(0, 1)), None, None, None, None
 
 
+class _RowScale(torch.autograd.Function):
+    """y[m][n] = x[m][n] * s[m]   (`* weight_S` and its bicubic up-samplings, model/speinet.py:93,95,104); both inputs differentiable."""
+
+    @staticmethod
+    def forward(fctx, x, s):
+        ctx = _ctx(x.device)
+        x, s = x.contiguous(), s.contiguous()
+        M, n = x.shape
+        assert s.numel() == M
+        out = torch.empty_like(x)
+        _lib.check(_lib.lib().spei_scale_rows(_p(ctx, x), _p(ctx, s), _p(ctx, out), M, n, ctx._stream()), "spei_scale_rows")
+        fctx.save_for_backward(x, s)
+        return out
+
+    @staticmethod
+    def backward(fctx, dy):
+        x, s = fctx.saved_tensors
+        ctx = _ctx(dy.device)
+        lib = _lib.lib()
+        M, n = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        _lib.check(lib.spei_scale_rows(_p(ctx, dy), _p(ctx, s), _p(ctx, dx), M, n, ctx._stream()), "spei_scale_rows")
+        ds = torch.empty_like(s)
+        _lib.check(lib.spei_rowdot(_p(ctx, dy), _p(ctx, x), _p(ctx, ds), M, n, ctx._stream()), "spei_rowdot")
+        return dx, ds
+
+
+class _Bicubic(torch.autograd.Function):
+    """F.interpolate(scale_factor=s, mode='bicubic') on pixel rows: [B*H*W, C] -> [B*sH*sW, C]   (model/speinet.py:95-113)."""
+
+    @staticmethod
+    def forward(fctx, x, B, H, W, s):
+        ctx = _ctx(x.device)
+        x = x.contiguous()
+        c = x.shape[1]
+        out = torch.empty(B * s * H * s * W, c, device=x.device)
+        lib = _lib.lib()
+        for i in range(B):
+            _lib.check(lib.spei_upsample_bicubic(_p(ctx, x[i * H * W:(i + 1) * H * W]), c, _p(ctx, out[i * s * s * H * W:(i + 1) * s * s * H * W]), c,
+                                                 H, W, c, s, ACT_NONE, ctx._stream()), "spei_upsample_bicubic")
+        fctx.meta = (B, H, W, s, c)
+        return out
+
+    @staticmethod
+    def backward(fctx, dy):
+        B, H, W, s, c = fctx.meta
+        ctx = _ctx(dy.device)
+        dy = dy.contiguous()
+        dx = torch.empty(B * H * W, c, device=dy.device)
+        lib = _lib.lib()
+        for i in range(B):
+            _lib.check(lib.spei_upsample_bicubic_bwd(_p(ctx, dy[i * s * s * H * W:(i + 1) * s * s * H * W]), _p(ctx, dx[i * H * W:(i + 1) * H * W]),
+                                                     H, W, c, s, ctx._stream()), "spei_upsample_bicubic_bwd")
+        return dx, None, None, None, None
+
+
+class _SearchTransfer(torch.autograd.Function):
+    """S, T_lv3, T_lv2, T_lv1 of model/SearchTransfer.py:24-50 on pixel rows: lr [B*H*W, 128] queries; ref3 [B*Hr*Wr, 128] the map
+    that is searched AND gathered at level 3, ref2 [B*2Hr*2Wr, 64], ref1 [B*4Hr*4Wr, 32] gathered at the other two levels (pass
+    None for all three outputs T when only S is wanted: SelfTransfer, :58-79).  S [B*H*W]."""
+
+    @staticmethod
+    def forward(fctx, lr, ref3, ref2, ref1, B, H, W, Hr, Wr):
+        ctx = _ctx(lr.device)
+        lib = _lib.lib()
+        dev = lr.device
+        lr, ref3 = lr.contiguous(), ref3.contiguous()
+        c = lr.shape[1]
+        hw, hwr = H * W, Hr * Wr
+        want_t = ref2 is not None
+        inv_lr, inv_ref = torch.empty(B * hw, device=dev), torch.empty(B * hwr, device=dev)
+        S = torch.empty(B * hw, device=dev)
+        arg = torch.empty(B * hw, device=dev, dtype=torch.int32)
+        ws = torch.empty(lib.spei_corr_ws_floats(hw), device=dev)
+        T = [torch.empty(B * s * s * hw, cc, device=dev) for s, cc in ((1, c), (2, c // 2), (4, c // 4))] if want_t else [None] * 3
+        refs = [ref3, ref2.contiguous(), ref1.contiguous()] if want_t else None
+        for i in range(B):
+            a, r = lr[i * hw:(i + 1) * hw], ref3[i * hwr:(i + 1) * hwr]
+            il, ir = inv_lr[i * hw:(i + 1) * hw], inv_ref[i * hwr:(i + 1) * hwr]
+            _lib.check(lib.spei_patch_invnorm(_p(ctx, a), c, _p(ctx, il), H, W, c, ctx._stream()), "spei_patch_invnorm")
+            _lib.check(lib.spei_patch_invnorm(_p(ctx, r), c, _p(ctx, ir), Hr, Wr, c, ctx._stream()), "spei_patch_invnorm")
+            _lib.check(lib.spei_corr_argmax(_p(ctx, a), c, _p(ctx, r), c, _p(ctx, il), _p(ctx, ir), H, W, Hr, Wr, c, _p(ctx, S[i * hw:(i + 1) * hw]),
+                                            ctx._tp(arg[i * hw:(i + 1) * hw]), _p(ctx, ws), ctx._stream()), "spei_corr_argmax")
+            if want_t:
+                for (s, t, rf) in zip((1, 2, 4), T, refs):
+                    cc = rf.shape[1]
+                    _lib.check(lib.spei_gather_fold(_p(ctx, rf[i * s * s * hwr:(i + 1) * s * s * hwr]), cc, ctx._tp(arg[i * hw:(i + 1) * hw]),
+                                                    _p(ctx, t[i * s * s * hw:(i + 1) * s * s * hw]), cc, H, W, Hr, Wr, cc, s, ctx._stream()),
+                               "spei_gather_fold")
+        fctx.save_for_backward(lr, ref3, inv_lr, inv_ref, S, arg)
+        fctx.meta = (B, H, W, Hr, Wr, want_t, c)
+        fctx.mark_non_differentiable(arg)
+        return S, T[0], T[1], T[2], arg
+
+    @staticmethod
+    def backward(fctx, dS, dT3, dT2, dT1, _darg):
+        lr, ref3, inv_lr, inv_ref, S, arg = fctx.saved_tensors
+        B, H, W, Hr, Wr, want_t, c = fctx.meta
+        ctx = _ctx(lr.device)
+        lib = _lib.lib()
+        dev = lr.device
+        hw, hwr = H * W, Hr * Wr
+        dS = dS.contiguous() if dS is not None else torch.zeros_like(S)
+        dlr = torch.empty_like(lr)
+        dref = [torch.empty(B * s * s * hwr, cc, device=dev) for s, cc in ((1, c), (2, c // 2), (4, c // 4))] if want_t else \
+            [torch.empty(B * hwr, c, device=dev), None, None]
+        dT = [t.contiguous() if t is not None else None for t in (dT3, dT2, dT1)]
+        for i in range(B):
+            sl, slr = slice(i * hw, (i + 1) * hw), slice(i * hwr, (i + 1) * hwr)
+            a = arg[sl].long()
+            # per reference position, the list of queries that chose it (stable sort: fixed summation order)
+            order = torch.sort(a, stable=True)[1].to(torch.int32).contiguous()
+            start = torch.zeros(hwr + 1, device=dev, dtype=torch.int64)
+            start[1:] = torch.cumsum(torch.bincount(a, minlength=hwr), 0)
+            start = start.to(torch.int32).contiguous()
+            _lib.check(lib.spei_corr_s_bwd_lr(_p(ctx, lr[sl]), _p(ctx, ref3[slr]), _p(ctx, inv_lr[sl]), _p(ctx, inv_ref[slr]), _p(ctx, S[sl]),
+                                              ctx._tp(arg[sl]), _p(ctx, dS[sl]), _p(ctx, dlr[sl]), H, W, Hr, Wr, c, ctx._stream()),
+                       "spei_corr_s_bwd_lr")
+            for j, s in enumerate((1, 2, 4)):
+                if dref[j] is None:
+                    continue
+                cc = dref[j].shape[1]
+                dt = dT[j][i * s * s * hw:(i + 1) * s * s * hw] if dT[j] is not None else None
+                if s > 1 and dt is None:
+                    dref[j][i * s * s * hwr:(i + 1) * s * s * hwr].zero_()
+                    continue
+                first = s == 1
+                _lib.check(lib.spei_search_bwd_ref(_p(ctx, ref3[slr]) if first else _NULL, _p(ctx, dt), _p(ctx, lr[sl]) if first else _NULL,
+                                                   _p(ctx, inv_lr[sl]) if first else _NULL, _p(ctx, inv_ref[slr]) if first else _NULL,
+                                                   _p(ctx, S[sl]) if first else _NULL, _p(ctx, dS[sl]) if first else _NULL, ctx._tp(order),
+                                                   ctx._tp(start), _p(ctx, dref[j][i * s * s * hwr:(i + 1) * s * s * hwr]), H, W, Hr, Wr, cc, s,
+                                                   ctx._stream()), "spei_search_bwd_ref")
+        return dlr, dref[0], dref[1], dref[2], None, None, None, None, None
+
+
 # ---- the ResBlock's gated residual sum, batch form, BatchNorm(1) in either mode -------------------------------------------------
 def _gate_maps(rowmax, rowmean, colmax, colmean, mean, prm, bn_train: bool, update_running: bool):
     """s [B,C], g1 [B,H,C], g2 [B,W,C] from the plane statistics (model/block.py:8-24 SE, :75-96 the two gates without their
@@ -454,29 +590,34 @@ def resblock(x: torch.Tensor, blk, B: int, H: int, W: int, bn_train: bool) -> to
                            hc.conv.weight, hc.bn.weight, hc.bn.bias, hc.bn.running_mean, hc.bn.running_var)
 
 
-def encoder(frames: torch.Tensor, rn, bn_train: bool) -> torch.Tensor:
-    """encoder_second(encoder_first(inBlock(frames)))  (model/swint.py:53,58): [B,3,H,W] -> [B*(H/4)*(W/4), 128]."""
+def encoder(frames: torch.Tensor, rn, bn_train: bool, pyramid: bool = False):
+    """encoder_second(encoder_first(inBlock(frames)))  (model/swint.py:53,58): [B,3,H,W] -> [B*(H/4)*(W/4), 128]; pyramid: all three
+    levels (lv1 [B*H*W, 32], lv2, lv3), the sharp-reference features of model/speinet.py:124-126."""
     B, _, H, W = frames.shape
     f = _ConvIn.apply(frames, rn.inBlock[0][0].weight, rn.inBlock[0][0].bias)
     for blk in list(rn.inBlock)[1:]:
         f = resblock(f, blk, B, H, W, bn_train)
+    levels = [f]
     h, w = H, W
     for stage in (rn.encoder_first, rn.encoder_second):
         f = _Conv2d.apply(f, stage[0][0].weight, stage[0][0].bias, None, B, h, w, 5, 2, True)
         h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         for blk in list(stage)[1:]:
             f = resblock(f, blk, B, h, w, bn_train)
-    return f
+        levels.append(f)
+    return tuple(levels) if pyramid else f
 
 
-def decoder(f: torch.Tensor, rn, B: int, h: int, w: int, bn_train: bool) -> torch.Tensor:
-    """outBlock(decoder_first(decoder_second(f)))  (model/swint.py:65): [B*h*w, 128] -> [B, 3, 4h, 4w]."""
-    for stage in (rn.decoder_second, rn.decoder_first):
-        for blk in list(stage)[:-1]:
-            f = resblock(f, blk, B, h, w, bn_train)
-        ct = stage[-1][0]
-        f = _ConvT2d.apply(f, ct.weight, ct.bias, B, h, w)
-        h, w = 2 * h, 2 * w
+def dec_stage(f: torch.Tensor, stage, B: int, h: int, w: int, bn_train: bool) -> torch.Tensor:
+    """n ResBlocks then ConvTranspose2d + ReLU (decoder_second / decoder_first, model/recons_video_ori.py:58-71): -> 2h x 2w."""
+    for blk in list(stage)[:-1]:
+        f = resblock(f, blk, B, h, w, bn_train)
+    ct = stage[-1][0]
+    return _ConvT2d.apply(f, ct.weight, ct.bias, B, h, w)
+
+
+def out_block(f: torch.Tensor, rn, B: int, h: int, w: int, bn_train: bool) -> torch.Tensor:
+    """outBlock (model/recons_video_ori.py:73-77): [B*h*w, 32] -> [B, 3, h, w]."""
     for blk in list(rn.outBlock)[:-1]:
         f = resblock(f, blk, B, h, w, bn_train)
     last = rn.outBlock[-1]
@@ -486,6 +627,13 @@ def decoder(f: torch.Tensor, rn, B: int, h: int, w: int, bn_train: bool) -> torc
     b32 = F.pad(last.bias, (0, 32 - last.bias.shape[0]))
     o = _Conv2d.apply(f, w32, b32, None, B, h, w, 5, 1, False)
     return o.view(B, h, w, 32)[..., :last.weight.shape[0]].permute(0, 3, 1, 2).contiguous()
+
+
+def decoder(f: torch.Tensor, rn, B: int, h: int, w: int, bn_train: bool) -> torch.Tensor:
+    """outBlock(decoder_first(decoder_second(f)))  (model/swint.py:65): [B*h*w, 128] -> [B, 3, 4h, 4w]."""
+    f = dec_stage(f, rn.decoder_second, B, h, w, bn_train)
+    f = dec_stage(f, rn.decoder_first, B, 2 * h, 2 * w, bn_train)
+    return out_block(f, rn, B, 4 * h, 4 * w, bn_train)
 
 
 def drop_path_rates(depths: Sequence[int], drop_path_rate: float = 0.1) -> List[float]:
@@ -585,3 +733,121 @@ def forward_swint(model, x: torch.Tensor, scales: Optional[list] = None, bn_trai
         cv = model.conv
         ff = _Linear.apply(fused, cv.weight.view(cv.weight.shape[0], -1), cv.bias, None, None)
         return decoder(ff, rn, B, h3, w3, training)
+
+
+# ---- model/speinet.py, train-mode graph (trainer/trainer_swint_hsa_nsf.py) --------------------------------------------------------
+def rl_prior(frames: torch.Tensor, iters: int, lam: float = 0.01) -> torch.Tensor:
+    """r_l_per_channel(frame, 5x5 box, iters, lam) (model/rcl.py:22-51) on a batch of frames; data only, no gradient."""
+    ctx = _ctx(frames.device)
+    lib = _lib.lib()
+    frames = frames.detach().contiguous()
+    B, c, H, W = frames.shape
+    out, scratch = torch.empty_like(frames), torch.empty(c, H, W, device=frames.device)
+    for i in range(B):
+        _lib.check(lib.spei_rl_prior(_p(ctx, frames[i]), _p(ctx, out[i]), _p(ctx, scratch), c, H, W, iters, lam, ctx._stream()), "spei_rl_prior")
+    return out
+
+
+def _conv1x1_relu(x, conv, B, h, w):
+    return _Conv2d.apply(x, conv.weight, conv.bias, None, B, h, w, 1, 1, True)
+
+
+def decode_speinet(m, ff, S, t3, t2, t1, B: int, h3: int, w3: int, bn_train: bool) -> torch.Tensor:
+    """SPEINet._decode (model/speinet.py:92-120) on pixel rows: ff [B*h3*w3, 128], S [B*h3*w3], t3 / t2 / t1 the transferred
+    features at the three levels."""
+    rn = m.recons_net
+    lin = lambda x, conv: _Linear.apply(x, conv.weight.view(conv.weight.shape[0], -1), conv.bias, None, None)
+    f_lv3 = ff + _RowScale.apply(lin(torch.cat((ff, t3), dim=1), m.conv_lv3), S)
+    dec2 = dec_stage(f_lv3, rn.decoder_second, B, h3, w3, bn_train)
+    h2, w2 = 2 * h3, 2 * w3
+    s_col = S.view(-1, 1)
+    s2 = _Bicubic.apply(s_col, B, h3, w3, 2).view(-1)
+    f_lv2 = dec2 + _RowScale.apply(lin(torch.cat((dec2, t2), dim=1), m.conv_lv2), s2)
+    search_1 = _conv1x1_relu(_Bicubic.apply(f_lv3, B, h3, w3, 2), m.search1, B, h2, w2)
+    search_2 = _Conv2d.apply(f_lv2, m.search3.weight, m.search3.bias, None, B, h2, w2, 3, 1, True)
+    search_11 = _conv1x1_relu(torch.cat((dec2, search_1), dim=1), m.search2, B, h2, w2)
+    search_22 = _conv1x1_relu(torch.cat((f_lv2, search_2), dim=1), m.search2, B, h2, w2)
+    f_v3 = dec2 + search_11
+    f_lv2 = f_lv2 + search_22
+    dec1 = dec_stage(f_lv2, rn.decoder_first, B, h2, w2, bn_train)
+    h1, w1 = 2 * h2, 2 * w2
+    s4 = _Bicubic.apply(s_col, B, h3, w3, 4).view(-1)
+    f_lv1 = dec1 + _RowScale.apply(lin(torch.cat((dec1, t1), dim=1), m.conv_lv1), s4)
+    search_13 = _conv1x1_relu(_Bicubic.apply(f_v3, B, h2, w2, 2), m.search13, B, h1, w1)
+    c33 = lambda x: _Conv2d.apply(x, m.search33.weight, m.search33.bias, None, B, h1, w1, 3, 1, True)
+    search_23 = c33(_Bicubic.apply(f_lv2, B, h2, w2, 2))
+    search_33 = _Conv2d.apply(f_lv1, m.search43.weight, m.search43.bias, None, B, h1, w1, 3, 1, True)
+    f_lv1 = f_lv1 + c33(torch.cat((search_13, search_23), dim=1)) + c33(torch.cat((search_13, search_33), dim=1)) \
+        + c33(torch.cat((search_23, search_33), dim=1))
+    return out_block(f_lv1, rn, B, h1, w1, bn_train)
+
+
+def _branch_speinet(m, x: torch.Tensor, has_ref: bool, scales: Optional[list], bn_train: bool) -> torch.Tensor:
+    """SPEINet._forwardbs (has_ref) / _forwardb (model/speinet.py:122-148) for the samples of one routing class."""
+    n = m.n_sequence
+    B, _, _, H, W = x.shape
+    h3, w3 = H // 4, W // 4
+    rn = m.recons_net
+    lv = encoder(x[:, n + 1], rn, bn_train, pyramid=True) if has_ref else None          # sharp_lv1, sharp_lv2, sharp_lv3
+    mid = x[:, n // 2]
+    f_mid = encoder(mid, rn, bn_train) + encoder(rl_prior(mid, 5), rn, bn_train)
+    feats = [f_mid]
+    call = 0
+    for i in range(n):
+        if i == n // 2:
+            continue
+        deb = rl_prior(x[:, i], 1)
+        feat = encoder(x[:, i], rn, bn_train)
+        feat = feat + encoder(deb, rn, bn_train)
+        feats.append(swin(m.swin, f_mid, feat, B, h3, w3, scales[call] if scales else None))
+        call += 1
+    fu = m.fusion
+    ff = _Linear.apply(torch.cat(feats, dim=1), fu.weight.view(fu.weight.shape[0], -1), fu.bias, None, None)
+    if has_ref:
+        S, t3, t2, t1, _ = _SearchTransfer.apply(ff, lv[2], lv[1], lv[0], B, h3, w3, h3, w3)
+    else:
+        # SelfTransfer: the reference map is the query map rotated (x.transpose(2,3).flip(2), model/SearchTransfer.py:60): a pure
+        # re-indexing, done with tensor views; only S comes out of the search, the transfers are up-sampled convs of ff
+        ref = ff.view(B, h3, w3, -1).transpose(1, 2).flip(1).reshape(B * h3 * w3, -1)
+        S, _, _, _, _ = _SearchTransfer.apply(ff, ref, None, None, B, h3, w3, w3, h3)
+        st = m.SelfTransfer
+        t3 = ff
+        t2 = _conv1x1_relu(_Bicubic.apply(ff, B, h3, w3, 2), st.search1, B, 2 * h3, 2 * w3)
+        t1 = _conv1x1_relu(_Bicubic.apply(t2, B, 2 * h3, 2 * w3, 2), st.search2, B, 4 * h3, 4 * w3)
+    return decode_speinet(m, ff, S, t3, t2, t1, B, h3, w3, bn_train)
+
+
+def speinet_drop_path_scales(depths, zero_ref: Sequence[bool], n_sequence: int, generator: Optional[torch.Generator] = None) -> dict:
+    """DropPath factors in the order model/speinet.py:150-168 consumes them: first the no-reference samples' branch (`_forwardb`),
+    then the others' (`_forwardbs`); each runs n_sequence - 1 swin calls on its own sub-batch.  {has_ref: scales}."""
+    out = {}
+    for has_ref in (False, True):
+        nb = sum(1 for z in zero_ref if z != has_ref)
+        if nb:
+            out[has_ref] = drop_path_scales(depths, nb, n_sequence - 1, generator)
+    return out
+
+
+def forward_speinet(model, x: torch.Tensor, scales: Optional[dict] = None, bn_train: Optional[bool] = None) -> torch.Tensor:
+    """model/speinet.py:150-168 as a differentiable graph on the HIP kernels: x [B, n+2, 3, H, W]; samples whose frame 3 is all
+    zero go through `_forwardb` (SelfTransfer), the others through `_forwardbs` (SearchTransfer), each class as one sub-batch
+    (BatchNorm statistics per class, as in the reference)."""
+    if not x.is_cuda:
+        raise RuntimeError("speinet_amd.train runs on MI355X only (HIP kernels); there is no CPU path")
+    _lib.lib()
+    B, _, _, H, W = x.shape
+    if H % 20 or W % 20:
+        raise ValueError(f"H and W must be multiples of 20 (two stride-2 stages, then 5x5 windows); got {H}x{W}")
+    training = model.training if bn_train is None else bn_train
+    x = x.float()
+    zero_ref = [bool(v) for v in (x[:, 3].reshape(B, -1) == 0).all(dim=1).tolist()]
+    if scales is None and model.training:
+        scales = speinet_drop_path_scales(model.cfg.depths, zero_ref, model.n_sequence)
+    out = torch.zeros(B, 3, H, W, device=x.device)
+    with torch.cuda.device(x.device):
+        for has_ref in (False, True):
+            idx = torch.tensor([i for i, z in enumerate(zero_ref) if z != has_ref], device=x.device, dtype=torch.long)
+            if idx.numel():
+                o = _branch_speinet(model, x[idx].contiguous(), has_ref, scales.get(has_ref) if scales else None, training)
+                out = out.index_copy(0, idx, o)
+    return out

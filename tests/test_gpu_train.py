@@ -174,6 +174,82 @@ def test_conv_family_backward():
         assert _rel(dx.grad, rows(lx.grad)) < 5e-6 and _rel(dw.grad, lw.grad) < 5e-6 and _rel(db.grad, lb.grad) < 5e-6, (B, H, W, k, n)
 
 
+def _search_transfer_ref(lr, ref3, ref2, ref1):
+    """model/SearchTransfer.py:24-50 restated on NCHW float64 tensors: cosine correlation of 3x3 patches, arg-max over the reference
+    positions, S and the three gathered + overlap-added maps."""
+    n, c, h, w = lr.shape
+    a = F.normalize(F.unfold(lr, 3, padding=1), dim=1)                        # [n, 9c, hw]
+    bq = F.normalize(F.unfold(ref3, 3, padding=1).transpose(1, 2), dim=2)     # [n, hrwr, 9c]
+    s, arg = torch.bmm(bq, a).max(dim=1)                                      # [n, hw]
+    outs = []
+    for rf, sc in ((ref3, 1), (ref2, 2), (ref1, 4)):
+        if rf is None:
+            outs.append(None)
+            continue
+        u = F.unfold(rf, 3 * sc, padding=sc, stride=sc)                       # [n, c k k, hrwr]
+        t = torch.gather(u, 2, arg.unsqueeze(1).expand(-1, u.shape[1], -1))
+        outs.append(F.fold(t, (h * sc, w * sc), 3 * sc, padding=sc, stride=sc) / 9.0)
+    return s.view(n, h, w), outs[0], outs[1], outs[2], arg
+
+
+def test_search_transfer_bicubic_rowscale_backward():
+    """The SearchTransfer Function (S through the normalised correlation at the arg-max, the three gathers), the bicubic adjoint
+    and the row scale against float64 torch autograd of the same operations; also the SelfTransfer form (rotated reference,
+    S only) on a non-square map."""
+    from speinet_amd import train as T
+    gen = torch.Generator().manual_seed(9)
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
+    for B, H, W in ((1, 10, 10), (2, 10, 15)):
+        lr = torch.randn(B, 128, H, W, generator=gen, dtype=torch.float64)
+        r3 = torch.randn(B, 128, H, W, generator=gen, dtype=torch.float64)
+        r2 = torch.randn(B, 64, 2 * H, 2 * W, generator=gen, dtype=torch.float64)
+        r1 = torch.randn(B, 32, 4 * H, 4 * W, generator=gen, dtype=torch.float64)
+        leaves = [t.clone().requires_grad_(True) for t in (lr, r3, r2, r1)]
+        s, t3, t2, t1, arg = _search_transfer_ref(*leaves)
+        gs = [torch.randn(t.shape, generator=gen, dtype=torch.float64) for t in (s, t3, t2, t1)]
+        (s * gs[0]).sum().backward(retain_graph=True)
+        ((t3 * gs[1]).sum() + (t2 * gs[2]).sum() + (t1 * gs[3]).sum()).backward()
+        dl = [_leaf(rows(t), DEV) for t in (lr, r3, r2, r1)]
+        S, T3, T2, T1, A = T._SearchTransfer.apply(*dl, B, H, W, H, W)
+        assert torch.equal(A.cpu().long().view(B, -1), arg), "arg-max differs from float64 torch"
+        assert _rel(S, s.reshape(-1)) < 3e-6 and _rel(T3, rows(t3)) < 1e-6 and _rel(T2, rows(t2)) < 1e-6 and _rel(T1, rows(t1)) < 1e-6
+        tot = (S * gs[0].reshape(-1).to(DEV).float()).sum() + sum((a * rows(g).to(DEV).float()).sum() for a, g in zip((T3, T2, T1), gs[1:]))
+        tot.backward()
+        for a, e, nm in zip(dl, leaves, ("d lr", "d ref3", "d ref2", "d ref1")):
+            assert _rel(a.grad, rows(e.grad)) < 2e-5, (nm, B, H, W, _rel(a.grad, rows(e.grad)))
+        # SelfTransfer: reference = the query map transposed and flipped; S only
+        l2 = lr.clone().requires_grad_(True)
+        s2 = _search_transfer_ref(l2, l2.transpose(2, 3).flip(2), None, None)[0]
+        (s2 * gs[0]).sum().backward()
+        xd = _leaf(rows(lr), DEV)
+        ref = xd.view(B, H, W, -1).transpose(1, 2).flip(1).reshape(B * H * W, -1)
+        S2 = T._SearchTransfer.apply(xd, ref, None, None, B, H, W, W, H)[0]
+        assert _rel(S2, s2.reshape(-1)) < 3e-6
+        (S2 * gs[0].reshape(-1).to(DEV).float()).sum().backward()
+        assert _rel(xd.grad, rows(l2.grad)) < 2e-5, ("self", B, H, W, _rel(xd.grad, rows(l2.grad)))
+    for B, H, W, c, sc in ((2, 10, 15, 128, 2), (1, 7, 9, 64, 2), (2, 10, 10, 1, 2), (1, 10, 12, 1, 4), (1, 6, 5, 32, 4)):
+        x = torch.randn(B, c, H, W, generator=gen, dtype=torch.float64)
+        xr = x.clone().requires_grad_(True)
+        y = F.interpolate(xr, scale_factor=sc, mode="bicubic")
+        g = torch.randn(y.shape, generator=gen, dtype=torch.float64)
+        (y * g).sum().backward()
+        xd = _leaf(rows(x), DEV)
+        yd = T._Bicubic.apply(xd, B, H, W, sc)
+        assert _rel(yd, rows(y)) < 2e-6
+        (yd * rows(g).to(DEV).float()).sum().backward()
+        assert _rel(xd.grad, rows(xr.grad)) < 3e-6, (B, H, W, c, sc, _rel(xd.grad, rows(xr.grad)))
+    x = torch.randn(300, 128, generator=gen, dtype=torch.float64)
+    sv = torch.randn(300, generator=gen, dtype=torch.float64)
+    g = torch.randn(300, 128, generator=gen, dtype=torch.float64)
+    xr, sr = x.clone().requires_grad_(True), sv.clone().requires_grad_(True)
+    (xr * sr[:, None] * g).sum().backward()
+    xd, sd = _leaf(x, DEV), _leaf(sv, DEV)
+    y = T._RowScale.apply(xd, sd)
+    assert _rel(y, x * sv[:, None]) < 1e-6
+    (y * g.to(DEV).float()).sum().backward()
+    assert _rel(xd.grad, xr.grad) < 1e-6 and _rel(sd.grad, sr.grad) < 3e-6
+
+
 def _scales_from_draws(draws: np.ndarray, depths, n_calls: int) -> list:
     """The fixture's flat DropPath draws [n_draws, B] -> train.drop_path_scales' nesting."""
     from speinet_amd.train import drop_path_rates
@@ -220,6 +296,12 @@ def test_training_step_vs_reference(golden_dir, name):
             assert (pa is None) == (pb is None)
             if pa is not None:
                 assert torch.equal(pa[0], pb[0]) and torch.equal(pa[1], pb[1])
+    _check_step(name, d, net, x, gt, scales, opt, seed)
+
+
+def _check_step(name, d, net, x, gt, scales, opt, seed):
+    """Run one step on the HIP model and compare output, loss, gradients, BatchNorm buffers and the Adam update with fixture d."""
+    from speinet_amd.loss import Loss
     np.random.seed(seed)
     loss_fn = Loss("1*L1+2*HEM", device=DEV)
     out = net(x, drop_path_scales=scales)
@@ -232,7 +314,11 @@ def test_training_step_vs_reference(golden_dir, name):
     assert abs(loss.item() - float(d["loss"])) < 2e-6 and abs(loss_fn.log[-1][1] - 2.0 * float(d["hem"])) < 2e-6
     gmax = max(float(d[k]) for k in d.files if k.startswith("norm/"))
     rows = []
+    unused = set(str(u) for u in d["unused"]) if "unused" in d.files else set()
     for k, p in net.named_parameters():
+        if k in unused:                   # parameters the reference's forward never touches (model/speinet.py: search23, connect, ...)
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
         assert p.grad is not None, k
         g = p.grad.detach().reshape(-1).cpu()
         ref_norm = float(d["norm/" + k])
@@ -288,6 +374,37 @@ def test_training_step_vs_reference(golden_dir, name):
             # gradient is within rounding of zero can land on the other side, so compare in units of the step
             frac_bad = ((got - ref).abs() > 2e-5).float().mean().item()
             assert frac_bad < 0.02, (k, frac_bad)
+
+
+
+
+def test_training_step_speinet_vs_reference(golden_dir):
+    """G21: one full training step of the reference's `model/speinet.py` (trainer/trainer_swint_hsa_nsf.py:27-40) on a batch of
+    three 40x40 windows, the second with an all-zero frame 3: `_forwardb` (SelfTransfer) on a sub-batch of one, `_forwardbs`
+    (SearchTransfer: correlation arg-max, S and the three gathered maps, all differentiated) on the other two.  Same checks
+    and bounds as G20: output, loss, 850 gradients (fp32 and float64 reference runs), BatchNorm buffers, Adam update; the 8
+    parameters the reference's forward never uses get no gradient."""
+    from speinet_amd import train as T
+    from speinet_amd.speinet import SPEINet, default_args
+    from speinet_amd.synth import synth_frames, synth_state_dict
+    name = "g21_train_speinet_40x40"
+    d = np.load(os.path.join(golden_dir, name + ".npz"))
+    seed, b, h, w = (int(d[k]) for k in ("seed", "b", "h", "w"))
+    net = SPEINet(args=default_args())
+    net.load_state_dict(synth_state_dict(net.state_dict(), seed=0), strict=True)
+    net = net.to(DEV).train()
+    x = synth_frames(b, h, w, seed=seed, zero_ref=(1,)).contiguous().to(DEV)
+    gt = synth_frames(b, h, w, seed=seed + 500)[:, 1].contiguous().to(DEV)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=0.0)
+    zero_ref = [False, True, False]
+    torch.manual_seed(seed)
+    scales = T.speinet_drop_path_scales(net.cfg.depths, zero_ref, 3)
+    # the restated DropPath stream equals the reference run's recorded draws: first the no-reference sub-batch, then the other
+    flat = [t for has_ref in (False, True) for call in scales[has_ref] for pair in call if pair is not None for t in pair]
+    assert len(flat) == d["draws"].shape[0]
+    for t, row, n in zip(flat, d["draws"], d["draw_len"]):
+        assert t.numel() == int(n) and torch.equal(t, torch.from_numpy(row[:int(n)]))
+    _check_step(name, d, net, x, gt, scales, opt, seed)
 
 
 def test_trainer_steps_reduce_the_loss():
