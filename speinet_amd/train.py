@@ -1,7 +1,8 @@
-"""Training step of the swint model on HIP kernels (BASELINE.json config 5: `trainer/trainer_swint.py` around
-`model/swint.py`): the differentiable forward of `speinet_amd.swint.SPEINet` in train() mode, built from
-`torch.autograd.Function`s whose forward AND backward are the C-ABI kernels, on the parameters of the drop-in module itself —
-so the reference trainer's own four lines work unchanged (trainer/trainer_swint.py:39-44):
+"""Training step on HIP kernels: BASELINE.json config 5 (`trainer/trainer_swint.py` around `model/swint.py`)
+and the full model (`trainer/trainer_swint_hsa_nsf.py` around `model/speinet.py`): the differentiable forward of
+`speinet_amd.swint.SPEINet` / `speinet_amd.speinet.SPEINet` in train() mode, built from `torch.autograd.Function`s whose forward
+AND backward are the C-ABI kernels, on the parameters of the drop-in module itself — so the reference trainer's own four lines
+work unchanged (trainer/trainer_swint.py:39-44, trainer_swint_hsa_nsf.py:31-40):
 
     out = model(input); optimizer.zero_grad(); loss = loss_fn(out, gt); loss.backward(); optimizer.step()
 
@@ -20,11 +21,14 @@ loop over the samples (their kernels take one map); linears, LayerNorm, GELU tak
 What runs where:
   HIP    every pixel-sized operation: conv / transposed conv / linear forward and data gradient (spei_igemm_f32, spei_conv5_in),
          weight + bias gradients (spei_conv_wgrad_f32), ReLU / GELU masks, LayerNorm forward and backward, window attention
-         forward and backward, the gates' plane statistics, the gated residual sum and its backward, DropPath row scaling
+         forward and backward, the gates' plane statistics, the gated residual sum and its backward, DropPath row scaling,
+         the Richardson-Lucy prior, SearchTransfer forward (exact f32 correlation arg-max, gathers) and backward, bicubic
+         up-sampling and its adjoint, the `* weight_S` row scale and its gradient
   torch  parameter-sized or [H][C]-plane-sized work: the gate maps (SE MLP, two 2->1 convs, BatchNorm(1)) and their autograd,
          the relative-position bias gather, weight re-layouts, sums over per-block / per-window partial gradients, the
-         ConvTranspose2d bias gradient (a column sum), concatenation of the fused features, the loss on the [B,3,H,W] output,
-         the optimizer (the reference's own torch.optim.Adam)
+         ConvTranspose2d bias gradient (a column sum), concatenations (`torch.cat`) and residual additions of feature rows, the
+         rotated view SelfTransfer searches, the per-position query lists of the search backward (a stable sort), the routing
+         scatter of the two sample classes, the loss on the [B,3,H,W] output, the optimizer (the reference's own torch.optim.Adam)
 No CPU path: everything here raises without the HIP library.
 """
 from __future__ import annotations

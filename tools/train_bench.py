@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--patch", type=int, default=200)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", choices=["swint", "speinet"], default="swint",
+                    help="swint: model/swint.py (trainer_swint.py, config 5); speinet: model/speinet.py (trainer_swint_hsa_nsf.py), every "
+                         "4th crop without a sharp reference")
     a = ap.parse_args()
     rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
     dev = f"cuda:{local}"
@@ -41,12 +44,19 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
     args = default_args()
     args.n_sequence = 3
-    net = SPEINet(n_sequence=3, args=args)
+    if a.model == "speinet":
+        from speinet_amd.speinet import SPEINet as FullNet
+        net = FullNet(args=args)
+    else:
+        net = SPEINet(n_sequence=3, args=args)
     net.load_state_dict(synth_state_dict(net.state_dict(), seed=0), strict=True)
     net = net.to(dev).train()
     opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=0.0)
     loss_fn = Loss("1*L1+2*HEM", device=dev)
-    x = synth_frames(a.batch, a.patch, a.patch, seed=7 + 2 * rank)[:, :3].contiguous().to(dev)
+    if a.model == "speinet":
+        x = synth_frames(a.batch, a.patch, a.patch, seed=7 + 2 * rank, zero_ref=tuple(range(3, a.batch, 4))).contiguous().to(dev)
+    else:
+        x = synth_frames(a.batch, a.patch, a.patch, seed=7 + 2 * rank)[:, :3].contiguous().to(dev)
     gt = synth_frames(a.batch, a.patch, a.patch, seed=8 + 2 * rank)[:, 1].contiguous().to(dev)
     torch.manual_seed(rank)
     np.random.seed(rank)
@@ -75,7 +85,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms = float(t.item())
     if rank == 0:
-        print(json.dumps({"metric": "training crops/s, swint model, fwd + loss + bwd + Adam", "value": world * a.batch * 1e3 / ms,
+        print(json.dumps({"metric": f"training crops/s, {a.model} model, fwd + loss + bwd + Adam", "value": world * a.batch * 1e3 / ms,
                           "unit": "crops/s", "n_gpus": world, "batch_per_gpu": a.batch, "patch": a.patch, "n_sequence": 3, "ms_per_step": ms,
                           "ms": {"forward": float(split[0]), "loss_backward": float(split[1]), "adam": float(split[2])},
                           "loss": float(loss.item()), "dtype": "f32", "data": "synthetic", "scaling": "weak"}))
