@@ -58,25 +58,31 @@ __device__ __forceinline__ float dpp_add(float v) { return v + dpp_quad<CTRL>(v)
 // lanes of different quads / octets (the values are already uniform inside them)
 __device__ __forceinline__ float sum16(float v) { return dpp_add<0x140>(dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(v)))); }
 
-template <typename LP>
-__global__ __launch_bounds__(256, 2) void attn_fused_kernel(const AttnParams<LP> p) {
+// HV = 1: a 256-thread workgroup owns two windows, two workgroups share a CU.  HV = 2: a 512-thread workgroup runs two such
+// halves side by side (own LDS slabs, own windows, common barriers): both halves walk the weight stream in lockstep with the SAME
+// rotation, so the second half's fragment loads hit the lines the first half just brought into the CU's L1.
+template <typename LP, int HV>
+__global__ __launch_bounds__(256 * HV, HV == 1 ? 2 : 1) void attn_fused_kernel(const AttnParams<LP> p) {
     typedef typename lpv<LP>::x8 lp8;
     typedef typename lpv<LP>::x4 lp4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const int hv = HV == 1 ? 0 : (int)(threadIdx.x >> 8);
+    unsigned char* smem = smem_all + (size_t)hv * (2 * ROWS * PA + 2 * ROWS * sizeof(int));
+    const int wg = blockIdx.x * HV + hv;           // index of this half among all 256-thread halves
     unsigned char* xs = smem;                      // [64][PA]  LayerNorm(x), bf16
     unsigned char* ys = smem + ROWS * PA;          // [64][PA]  y-hat, bf16; later the attention output
     unsigned char* os = ys;
     int* tok_pix = reinterpret_cast<int*>(smem + 2 * ROWS * PA);   // [64] pixel index or -1
     int* tok_reg = tok_pix + ROWS;                                 // [64] shift-mask region id
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fk = lane >> 5;
     const int nwx = p.W / WS;
 
     SPEI_STAMP(p.stamps, 0);
     if (tid < ROWS) {
         const int w = tid >> 5, t = tid & 31;
-        const int win = blockIdx.x * 2 + w;
+        const int win = wg * 2 + w;
         int pix = -1, reg = 0;
         if (t < NT && win < p.nwin) {
             const int wy = win / nwx, wx = win - wy * nwx;
@@ -371,8 +377,14 @@ static int attn_launch(const float* x, float* out, const void* yhat, const void*
     p.H = H; p.W = W; p.shift = shift; p.nwin = (H / WS) * (W / WS);
     p.stamps = spei_stamp_buffer();
     const size_t lds = (size_t)2 * ROWS * PA + 2 * ROWS * sizeof(int);
-    ensure_dyn_lds<&attn_fused_kernel<LP>>(lds);
-    hipLaunchKernelGGL(attn_fused_kernel<LP>, dim3((p.nwin + 1) / 2), dim3(256), lds, st, p);
+    static const int halves = spei_knob("SPEI_ATTN_HALVES", 1);          // tuning build: 2 = 512-thread workgroups (see the kernel)
+    if (halves == 2) {
+        ensure_dyn_lds<&attn_fused_kernel<LP, 2>>(2 * lds);
+        hipLaunchKernelGGL((attn_fused_kernel<LP, 2>), dim3((p.nwin + 3) / 4), dim3(512), 2 * lds, st, p);
+    } else {
+        ensure_dyn_lds<&attn_fused_kernel<LP, 1>>(lds);
+        hipLaunchKernelGGL((attn_fused_kernel<LP, 1>), dim3((p.nwin + 1) / 2), dim3(256), lds, st, p);
+    }
     SPEI_CHECK_LAUNCH("spei_attn_fused16");
     return 0;
 }

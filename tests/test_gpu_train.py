@@ -431,3 +431,36 @@ def test_trainer_steps_reduce_the_loss():
     assert losses[-1] < losses[0] and all(np.isfinite(losses))
     moved = sum(int(not torch.equal(before[k], v.detach())) for k, v in net.named_parameters())
     assert moved == len(before), (moved, len(before))
+
+
+@pytest.mark.parametrize("which", ["swint", "speinet"])
+def test_training_graph_matches_inference_path_at_crop_size(which):
+    """Size-independent tie between the two paths at the training crop size (200x200, option/template.py:6): in eval() mode the
+    differentiable graph (running BatchNorm statistics, no DropPath) must give the frames the f32 inference path gives —
+    the path the full-size goldens G14-G18 pin — and a backward pass through it must reach every parameter the forward uses."""
+    from speinet_amd.speinet import default_args
+    from speinet_amd.synth import synth_frames, synth_state_dict
+    args = default_args()
+    args.n_sequence = 3
+    if which == "swint":
+        from speinet_amd.swint import SPEINet
+        net = SPEINet(n_sequence=3, args=args)
+        x = synth_frames(2, 200, 200, seed=41)[:, :3].contiguous().to(DEV)
+    else:
+        from speinet_amd.speinet import SPEINet
+        net = SPEINet(args=args)
+        x = synth_frames(2, 200, 200, seed=42, zero_ref=(1,)).contiguous().to(DEV)
+    net.load_state_dict(synth_state_dict(net.state_dict(), seed=0), strict=True)
+    net = net.to(DEV).eval()
+    net.precision = "f32"
+    with torch.no_grad():
+        ref = net(x)
+    out = net(x)                                    # autograd recording -> the differentiable graph, eval-mode semantics
+    assert out.requires_grad
+    err = (out.detach() - ref).abs().max().item()
+    print(f"{which}: max |training-graph output - inference output| at 200x200: {err:.2e} (values up to {ref.abs().max().item():.2f})")
+    assert err < 2e-5 * max(1.0, ref.abs().max().item())
+    out.square().mean().backward()
+    missing = [k for k, p in net.named_parameters() if p.grad is None]
+    allowed = ("search23", "connect", "SearchTransfer.search") if which == "speinet" else ()
+    assert all(any(a in k for a in allowed) for k in missing), missing
