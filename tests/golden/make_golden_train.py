@@ -134,7 +134,7 @@ def main():
     hem_mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(hem_mod)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["swint", "speinet"]
+    which = sys.argv[1:] or ["swint", "speinet", "curve"]
     if "swint" in which:
         for name, seed, n_seq, b, h, w in (("g20_train_swint_40x40", 201, 3, 2, 40, 40), ("g20_train_swint_n1_40x60", 202, 1, 1, 40, 60)):
             args = template_args()
@@ -147,6 +147,34 @@ def main():
             x = synth_frames(b, h, w, seed=seed)[:, :n_seq].contiguous()
             gt = synth_frames(b, h, w, seed=seed + 500)[:, 1].contiguous()
             run_case(name, build, x, gt, hem_mod, seed)
+    if "curve" in which:
+        # G22: SURVEY.md §8(d) config 5 — the loss curve of N optimizer steps with DropPath disabled (identity), BatchNorm in train
+        # mode: swint model, one fixed batch of two 40x40 windows, 1*L1 + 2*HEM, Adam(1e-4), 6 steps
+        args = template_args()
+        args.n_sequence = 3
+        seed, b, h, w, steps = 221, 2, 40, 40, 6
+        torch.manual_seed(0)
+        net = mw.SPEINet(in_channels=3, n_sequence=3, out_channels=3, n_resblock=3, n_feat=32, device="cpu", args=args)
+        net.load_state_dict(synth_state_dict(net.state_dict(), seed=0), strict=True)
+        for m in net.modules():
+            if isinstance(m, DropPath):
+                m.drop_prob = 0.0
+        net.train()
+        x = synth_frames(b, h, w, seed=seed)[:, :3].contiguous()
+        gt = synth_frames(b, h, w, seed=seed + 500)[:, 1].contiguous()
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=0.0)
+        hem = hem_mod.HEM(device="cpu")
+        np.random.seed(seed)
+        losses = []
+        for _ in range(steps):
+            out = net(x)
+            opt.zero_grad()
+            loss = torch.nn.L1Loss()(out, gt) + 2.0 * hem(out, gt)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        np.savez_compressed(os.path.join(HERE, "g22_losscurve_swint_40x40.npz"), seed=seed, b=b, h=h, w=w, losses=np.asarray(losses))
+        print("g22_losscurve_swint_40x40: " + ", ".join(f"{v:.6f}" for v in losses))
     if "speinet" in which:
         # G21: model/speinet.py itself (trainer/trainer_swint_hsa_nsf.py): three samples, the second with an all-zero frame 3 ->
         # `_forwardb` (SelfTransfer) on a sub-batch of one, `_forwardbs` (SearchTransfer) on the other two
