@@ -18,6 +18,8 @@ struct WgradParams {
     const float* x;
     const float* dy;
     float* part;          // [nchunks][T][N][K]
+    float* bpart;         // [nchunks][N] column sums of dy (the bias gradient), or NULL: taken by the (tap 0, k-tile 0) workgroups, which
+                          // stream every dy element of their channel tile through registers anyway
     int ldx, ldy, K, N, Hin, Win, Hout, Wout, ks, stride, pad, chunk_px, ntn, ntk;
     int batch;            // equally sized maps stored one after the other: the pixel index runs over all of them
 };
@@ -39,6 +41,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float asum = 0.f;
     int m = m0 + fk;
     int oy = m / p.Wout, ox = m - oy * p.Wout;
     int smp = oy / p.Hout;                                  // sample of this output row
@@ -52,6 +55,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
                 b = p.x[(((size_t)smp * p.Hin + iy) * p.Win + ix) * p.ldx + k];
         }
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        asum += a;
         m += 2;
         ox += 2;
         while (ox >= p.Wout) {
@@ -59,9 +63,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             if (++oy == p.Hout) { oy = 0; ++smp; }
         }
     }
+    __shared__ float bred[4][64];
+    bred[wave][lane] = asum;
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
     __syncthreads();
+    if (p.bpart && t == 0 && kt == 0 && tid < 32 && nt * 32 + tid < p.N) {
+        float b = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) b += bred[wv][tid] + bred[wv][tid + 32];       // pixel parity 0 then 1 of each wave, waves in order
+        p.bpart[(size_t)blockIdx.y * p.N + nt * 32 + tid] = b;
+    }
     if (wave == 0) {
         const int T = p.ks * p.ks;
         float* dst = p.part + (((size_t)blockIdx.y * T + t) * p.N) * p.K;
@@ -81,27 +93,6 @@ __global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restric
     float s = 0.f;
     for (int c = 0; c < nparts; ++c) s += part[(size_t)c * count + i];
     out[i] = s;
-}
-
-// column sums of a [M][ld] matrix (bias gradient): part[chunk][n]
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ y, int ld, int N, int64_t M, int rows_per_block,
-                                                     float* __restrict__ part) {
-    __shared__ float red[256];
-    const int tid = threadIdx.x;
-    const int tpr = N < 256 ? N : 256;                    // threads per row (N <= 256)
-    const int rsub = tid / tpr, c = tid - rsub * tpr, rpp = 256 / tpr;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
-    float s = 0.f;
-    if (rsub < rpp)
-        for (int64_t r = r0 + rsub; r < r1; r += rpp) s += y[r * ld + c];
-    red[tid] = (rsub < rpp) ? s : 0.f;
-    __syncthreads();
-    if (tid < tpr) {
-        float a = 0.f;
-        for (int j = 0; j < rpp; ++j) a += red[j * tpr + tid];
-        part[(size_t)blockIdx.x * N + tid] = a;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -266,17 +257,13 @@ static int conv_wgrad_run(const float* x, int ldx, const float* dy, int ldy, flo
     p.chunk_px = chunk;
     const int nchunks = cdiv(M, chunk);
     p.ntn = cdiv(N, 32); p.ntk = cdiv(K, 32);
+    float* bpart = ws + (size_t)64 * T * N * K;
+    p.bpart = dbias ? bpart : nullptr;
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(T * p.ntn * p.ntk, nchunks), dim3(256), 0, st, p);
     const int64_t count = (int64_t)T * N * K;
     hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(count, 256)), dim3(256), 0, st, ws, dw, count, nchunks);
     if (dbias) {
-        float* bpart = ws + (size_t)64 * T * N * K;
-        int nbmax = (64 * 256) / N;                          // the partials live in the 64 x 256 floats behind the weight partials
-        if (nbmax > 512) nbmax = 512;
-        const int rows = cdiv(M, nbmax);
-        const int nb = cdiv(M, rows);
-        hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, st, dy, ldy, N, (int64_t)M, rows, bpart);
-        hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(256), 0, st, bpart, dbias, (int64_t)N, nb);
+        hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(256), 0, st, bpart, dbias, (int64_t)N, nchunks);
     }
     SPEI_CHECK_LAUNCH("spei_conv_wgrad_f32");
     return 0;
