@@ -161,6 +161,8 @@ int spei_layernorm256(const float* x, void* y, int out_fmt, const float* gamma, 
  * are fp32 or 16-bit in HBM (the arithmetic stays fp32 on the f32 MFMA). */
 int spei_window_attention(const void* q, const void* kv, int io_fmt, const float* relbias, void* out, int H, int W,
                           int shift, spei_stream_t stream);
+int spei_window_attention_batched(const void* q, const void* kv, int io_fmt, const float* relbias, void* out, int H, int W,
+                                  int shift, int batch, spei_stream_t stream);   /* batch maps stored one after the other */
 
 /* K10 — 1 / max(||unfold3x3(f)[p]||_2, 1e-12) per position (F.normalize, model/SearchTransfer.py:30-31). */
 int spei_patch_invnorm(const float* f, int ldf, float* inv, int H, int W, int C, spei_stream_t stream);
@@ -245,6 +247,11 @@ int64_t spei_plane_ws_floats(int H, int W, int C);
 int spei_plane_stats(const float* a, const float* b, int prod, int H, int W, int C, float* rowmax, float* rowmean, float* colmax,
                      float* colmean, float* mean, float* ws, spei_stream_t stream);
 
+/* The same for `batch` equally sized maps stored one after the other (a, b: batch * H*W rows; outputs [batch][H][C], [batch][W][C],
+ * [batch][C]); ws: batch * spei_plane_ws_floats(H, W, C) floats. */
+int spei_plane_stats_batched(const float* a, const float* b, int prod, int H, int W, int C, float* rowmax, float* rowmean, float* colmax,
+                             float* colmean, float* mean, float* ws, int batch, spei_stream_t stream);
+
 /* Backward of the gated residual sum through x1 (model/block.py:136-140): dx1 = dOut * (s + g1 + g2) + the pooled statistics'
  * gradients routed back (means spread evenly, maxima to the arg-max element).  dx = dOut needs no kernel. */
 int spei_resblock_apply_bwd(const float* dout, const float* x1, const float* s, const float* g1, const float* g2, const float* rowmax,
@@ -266,9 +273,10 @@ int spei_gelu_bwd(const float* pre, const float* dy, float* dpre, int64_t n, spe
 
 /* WindowAttention core backward (model/swinir.py:115-149): q [H*W][256] pre-scaled, kv [H*W][512], relbias [8][25][25], dout
  * [H*W][256] = gradient of spei_window_attention's output -> dq [H*W][256], dkv [H*W][512] and dbias_part [nwin][8][25][25]
- * (the gradient of relbias is the sum over the windows).  Same window partition / cyclic shift / mask as the forward. */
+ * (the gradient of relbias is the sum over the windows).  Same window partition / cyclic shift / mask as the forward.  `batch`
+ * equally sized maps stored one after the other are processed in one launch (dbias_part [batch][nwin][8][25][25]). */
 int spei_window_attention_bwd(const float* q, const float* kv, const float* relbias, const float* dout, float* dq, float* dkv,
-                              float* dbias_part, int H, int W, int shift, spei_stream_t stream);
+                              float* dbias_part, int H, int W, int shift, int batch, spei_stream_t stream);
 
 /* out[m][n] = x[m][n] * rowscale[m] (the DropPath factor of model/swinir.py:278-279 applied to a branch gradient).  N % 4 == 0. */
 int spei_scale_rows(const float* x, const float* rowscale, float* out, int64_t M, int N, spei_stream_t stream);

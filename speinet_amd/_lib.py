@@ -47,6 +47,7 @@ SIGNATURES = {
     "spei_resblock_apply": (I, [P, P, I, P, P, P, P, P, I, I, I, I, P]),
     "spei_layernorm256": (I, [P, P, I, P, P, L, P]),
     "spei_window_attention": (I, [P, P, I, P, P, I, I, I, P]),
+    "spei_window_attention_batched": (I, [P, P, I, P, P, I, I, I, I, P]),
     "spei_patch_invnorm": (I, [P, I, P, I, I, I, P]),
     "spei_corr_ws_floats": (L, [L]),
     "spei_corr_argmax": (I, [P, I, P, I, P, P, I, I, I, I, I, P, P, P, P]),
@@ -60,12 +61,13 @@ SIGNATURES = {
     "spei_relu_bwd": (I, [P, P, P, L, P]),
     "spei_plane_ws_floats": (L, [I, I, I]),
     "spei_plane_stats": (I, [P, P, I, I, I, I, P, P, P, P, P, P, P]),
+    "spei_plane_stats_batched": (I, [P, P, I, I, I, I, P, P, P, P, P, P, I, P]),
     "spei_resblock_apply_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
     "spei_ln_bwd_blocks": (L, [L]),
     "spei_layernorm256_bwd": (I, [P, P, P, P, P, L, P]),
     "spei_gelu_fwd": (I, [P, P, L, P]),
     "spei_gelu_bwd": (I, [P, P, P, L, P]),
-    "spei_window_attention_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P]),
+    "spei_window_attention_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
     "spei_scale_rows": (I, [P, P, P, L, I, P]),
     "spei_corr_s_bwd_lr": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "spei_search_bwd_ref": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),

@@ -118,6 +118,16 @@ template <bool PROD>
 __global__ __launch_bounds__(256) void plane_stats_kernel(const float* __restrict__ a, const float* __restrict__ b, int H, int W, int C,
                                                           float* __restrict__ rowp_max, float* __restrict__ rowp_sum,
                                                           float* __restrict__ colp_max, float* __restrict__ colp_sum, int ntx, int nty) {
+    {   // blockIdx.y = sample of a batch of equally sized maps: inputs and partial buffers move by one sample's extent
+        const size_t z = blockIdx.y;
+        a += z * H * W * C;
+        if (PROD) b += z * H * W * C;
+        const size_t pstride = 2 * ((size_t)ntx * H * C + (size_t)nty * W * C);
+        if (rowp_max) rowp_max += z * pstride;
+        rowp_sum += z * pstride;
+        if (colp_max) colp_max += z * pstride;
+        colp_sum += z * pstride;
+    }
     // thread -> (channel c, column group): with C channels, 256 / C columns are processed side by side
     const int tid = threadIdx.x;
     const int c = tid % C, cg = tid / C, ncg = 256 / C;
@@ -165,7 +175,14 @@ __global__ __launch_bounds__(256) void plane_stats_kernel(const float* __restric
 
 // stage 2: lines [L][C] from `nt` partials [nt][L][C]; scale applied to the sum (1/W for a mean, 1 for a plain sum)
 __global__ __launch_bounds__(256) void plane_combine_kernel(const float* __restrict__ pmax, const float* __restrict__ psum, int nt, int64_t LC,
-                                                            float scale, float* __restrict__ omax, float* __restrict__ osum) {
+                                                            float scale, float* __restrict__ omax, float* __restrict__ osum, int64_t pstride) {
+    {   // blockIdx.y = sample: partials move by pstride floats, outputs by LC
+        const int64_t z = blockIdx.y;
+        if (pmax) pmax += z * pstride;
+        psum += z * pstride;
+        if (omax) omax += z * LC;
+        osum += z * LC;
+    }
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= LC) return;
     float m = -INFINITY, s = 0.f;
@@ -179,6 +196,8 @@ __global__ __launch_bounds__(256) void plane_combine_kernel(const float* __restr
 
 // total[c] = scale * sum over lines of line_sum[l][c]   (one block, fixed order)
 __global__ __launch_bounds__(256) void lines_total_kernel(const float* __restrict__ lines, int L, int C, float scale, float* __restrict__ total) {
+    lines += (size_t)blockIdx.x * L * C;          // blockIdx.x = sample
+    total += (size_t)blockIdx.x * C;
     __shared__ float red[256];
     const int tid = threadIdx.x, c = tid % C, g = tid / C, ng = 256 / C;
     float s = 0.f;
@@ -294,27 +313,42 @@ extern "C" int64_t spei_plane_ws_floats(int H, int W, int C) {
 
 // prod == 0: rowmax, rowmean [H][C], colmax, colmean [W][C], mean [C] of a.   prod == 1: rowmax = colmax = NULL; rowmean / colmean /
 // mean receive the plain SUMS of a * b over x, over y and over the map.
-extern "C" int spei_plane_stats(const float* a, const float* b, int prod, int H, int W, int C, float* rowmax, float* rowmean, float* colmax,
-                                float* colmean, float* mean, float* ws, spei_stream_t stream) {
+static int plane_stats_run(const float* a, const float* b, int prod, int H, int W, int C, float* rowmax, float* rowmean, float* colmax,
+                           float* colmean, float* mean, float* ws, int batch, spei_stream_t stream) {
     SPEI_REQUIRE(a && rowmean && colmean && mean && ws && (!prod || b) && (prod || (rowmax && colmax)), "spei_plane_stats: null pointer");
     SPEI_REQUIRE((C == 32 || C == 64 || C == 128) && H > 0 && W > 0, "spei_plane_stats: C=%d (32/64/128 built)", C);
+    SPEI_REQUIRE(batch >= 1 && batch <= 65535, "spei_plane_stats: batch=%d", batch);
     hipStream_t st = (hipStream_t)stream;
     const int ntx = (W + GT - 1) / GT, nty = (H + GT - 1) / GT;
+    const int64_t pstride = 2 * ((int64_t)ntx * H * C + (int64_t)nty * W * C);          // partial floats per sample
     float* rpm = ws;
     float* rps = rpm + (size_t)ntx * H * C;
     float* cpm = rps + (size_t)ntx * H * C;
     float* cps = cpm + (size_t)nty * W * C;
-    if (prod) hipLaunchKernelGGL(plane_stats_kernel<true>, dim3(ntx * nty), dim3(256), 0, st, a, b, H, W, C, rpm, rps, cpm, cps, ntx, nty);
-    else hipLaunchKernelGGL(plane_stats_kernel<false>, dim3(ntx * nty), dim3(256), 0, st, a, b, H, W, C, rpm, rps, cpm, cps, ntx, nty);
+    const dim3 g1(ntx * nty, batch);
+    if (prod) hipLaunchKernelGGL(plane_stats_kernel<true>, g1, dim3(256), 0, st, a, b, H, W, C, rpm, rps, cpm, cps, ntx, nty);
+    else hipLaunchKernelGGL(plane_stats_kernel<false>, g1, dim3(256), 0, st, a, b, H, W, C, rpm, rps, cpm, cps, ntx, nty);
     const int64_t hc = (int64_t)H * C, wc = (int64_t)W * C;
     // rows: plain sums first (the channel total is the sum of the row sums), then scaled to means when asked for
-    hipLaunchKernelGGL(plane_combine_kernel, dim3(cdiv(hc, 256)), dim3(256), 0, st, prod ? nullptr : rpm, rps, ntx, hc, 1.0f, prod ? nullptr : rowmax, rowmean);
-    hipLaunchKernelGGL(lines_total_kernel, dim3(1), dim3(256), 0, st, rowmean, H, C, prod ? 1.0f : 1.0f / ((float)H * (float)W), mean);
-    if (!prod) hipLaunchKernelGGL(plane_combine_kernel, dim3(cdiv(hc, 256)), dim3(256), 0, st, nullptr, rps, ntx, hc, 1.0f / (float)W, nullptr, rowmean);
-    hipLaunchKernelGGL(plane_combine_kernel, dim3(cdiv(wc, 256)), dim3(256), 0, st, prod ? nullptr : cpm, cps, nty, wc, prod ? 1.0f : 1.0f / (float)H,
-                       prod ? nullptr : colmax, colmean);
+    hipLaunchKernelGGL(plane_combine_kernel, dim3(cdiv(hc, 256), batch), dim3(256), 0, st, prod ? nullptr : rpm, rps, ntx, hc, 1.0f,
+                       prod ? nullptr : rowmax, rowmean, pstride);
+    hipLaunchKernelGGL(lines_total_kernel, dim3(batch), dim3(256), 0, st, rowmean, H, C, prod ? 1.0f : 1.0f / ((float)H * (float)W), mean);
+    if (!prod) hipLaunchKernelGGL(plane_combine_kernel, dim3(cdiv(hc, 256), batch), dim3(256), 0, st, nullptr, rps, ntx, hc, 1.0f / (float)W, nullptr,
+                                  rowmean, pstride);
+    hipLaunchKernelGGL(plane_combine_kernel, dim3(cdiv(wc, 256), batch), dim3(256), 0, st, prod ? nullptr : cpm, cps, nty, wc,
+                       prod ? 1.0f : 1.0f / (float)H, prod ? nullptr : colmax, colmean, pstride);
     SPEI_CHECK_LAUNCH("spei_plane_stats");
     return 0;
+}
+
+extern "C" int spei_plane_stats(const float* a, const float* b, int prod, int H, int W, int C, float* rowmax, float* rowmean, float* colmax,
+                                float* colmean, float* mean, float* ws, spei_stream_t stream) {
+    return plane_stats_run(a, b, prod, H, W, C, rowmax, rowmean, colmax, colmean, mean, ws, 1, stream);
+}
+
+extern "C" int spei_plane_stats_batched(const float* a, const float* b, int prod, int H, int W, int C, float* rowmax, float* rowmean,
+                                        float* colmax, float* colmean, float* mean, float* ws, int batch, spei_stream_t stream) {
+    return plane_stats_run(a, b, prod, H, W, C, rowmax, rowmean, colmax, colmean, mean, ws, batch, stream);
 }
 
 extern "C" int spei_resblock_apply_bwd(const float* dout, const float* x1, const float* s, const float* g1, const float* g2, const float* rowmax,

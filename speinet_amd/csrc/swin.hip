@@ -69,6 +69,10 @@ __global__ __launch_bounds__(256) void window_attention_kernel(const T* __restri
                                                                int H, int W, int shift) {
     __shared__ float sQ[4][32][LDT], sK[4][32][LDT], sV[4][32][LDT];
     __shared__ int tok_pix[32], tok_reg[32];
+    {   // blockIdx.y = sample of a batch of equally sized maps stored one after the other
+        const size_t z = (size_t)blockIdx.y * H * W;
+        q += z * 256; kv += z * 512; out += z * 256;
+    }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nwx = W / WS;
     const int win = blockIdx.x >> 1;
@@ -167,16 +171,27 @@ extern "C" int spei_layernorm256(const float* x, void* y, int out_fmt, const flo
     return 0;
 }
 
-extern "C" int spei_window_attention(const void* q, const void* kv, int io_fmt, const float* relbias, void* out, int H, int W,
-                                     int shift, spei_stream_t stream) {
+static int window_attention_run(const void* q, const void* kv, int io_fmt, const float* relbias, void* out, int H, int W, int shift, int batch,
+                                spei_stream_t stream) {
     SPEI_REQUIRE(q && kv && relbias && out, "spei_window_attention: null pointer");
+    SPEI_REQUIRE(batch >= 1 && batch <= 65535, "spei_window_attention: batch=%d", batch);
     SPEI_REQUIRE(H > 0 && W > 0 && H % WS == 0 && W % WS == 0, "spei_window_attention: %dx%d is not a multiple of the 5x5 window", H, W);
     SPEI_REQUIRE(shift >= 0 && shift < WS, "spei_window_attention: shift=%d", shift);
     SPEI_REQUIRE(io_fmt == SPEI_F32 || io_fmt == SPEI_BF16 || io_fmt == SPEI_F16, "spei_window_attention: io_fmt=%d", io_fmt);
-    const dim3 grid(2 * (H / WS) * (W / WS));
+    const dim3 grid(2 * (H / WS) * (W / WS), batch);
     if (io_fmt == SPEI_BF16) hipLaunchKernelGGL(window_attention_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)q, (const __bf16*)kv, relbias, (__bf16*)out, H, W, shift);
     else if (io_fmt == SPEI_F16) hipLaunchKernelGGL(window_attention_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)q, (const _Float16*)kv, relbias, (_Float16*)out, H, W, shift);
     else hipLaunchKernelGGL(window_attention_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)q, (const float*)kv, relbias, (float*)out, H, W, shift);
     SPEI_CHECK_LAUNCH("spei_window_attention");
     return 0;
+}
+
+extern "C" int spei_window_attention(const void* q, const void* kv, int io_fmt, const float* relbias, void* out, int H, int W,
+                                     int shift, spei_stream_t stream) {
+    return window_attention_run(q, kv, io_fmt, relbias, out, H, W, shift, 1, stream);
+}
+
+extern "C" int spei_window_attention_batched(const void* q, const void* kv, int io_fmt, const float* relbias, void* out, int H, int W,
+                                             int shift, int batch, spei_stream_t stream) {
+    return window_attention_run(q, kv, io_fmt, relbias, out, H, W, shift, batch, stream);
 }

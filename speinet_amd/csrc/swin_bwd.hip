@@ -102,6 +102,11 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const float* 
                                                                    float* __restrict__ dq, float* __restrict__ dkv,
                                                                    float* __restrict__ dbias_part, int H, int W, int shift) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    {   // blockIdx.y = sample of a batch of equally sized maps stored one after the other
+        const size_t z = (size_t)blockIdx.y * H * W;
+        q += z * 256; kv += z * 512; dout += z * 256; dq += z * 256; dkv += z * 512;
+        dbias_part += (size_t)blockIdx.y * (H / WS) * (W / WS) * 8 * NT * NT;
+    }
     typedef float (*Tile)[32][LDT];
     Tile sQ = reinterpret_cast<Tile>(smem);
     Tile sK = reinterpret_cast<Tile>(smem + 4 * 32 * LDT);
@@ -282,13 +287,14 @@ extern "C" int spei_gelu_bwd(const float* pre, const float* dy, float* dpre, int
 }
 
 extern "C" int spei_window_attention_bwd(const float* q, const float* kv, const float* relbias, const float* dout, float* dq, float* dkv,
-                                         float* dbias_part, int H, int W, int shift, spei_stream_t stream) {
+                                         float* dbias_part, int H, int W, int shift, int batch, spei_stream_t stream) {
+    SPEI_REQUIRE(batch >= 1 && batch <= 65535, "spei_window_attention_bwd: batch=%d", batch);
     SPEI_REQUIRE(q && kv && relbias && dout && dq && dkv && dbias_part, "spei_window_attention_bwd: null pointer");
     SPEI_REQUIRE(H > 0 && W > 0 && H % WS == 0 && W % WS == 0, "spei_window_attention_bwd: %dx%d is not a multiple of the 5x5 window", H, W);
     SPEI_REQUIRE(shift >= 0 && shift < WS, "spei_window_attention_bwd: shift=%d", shift);
     const size_t lds = (size_t)(16 * 32 * LDT + 4 * 3 * 32 + 64) * sizeof(float);
     ensure_dyn_lds<&window_attention_bwd_kernel>(lds);
-    hipLaunchKernelGGL(window_attention_bwd_kernel, dim3(2 * (H / WS) * (W / WS)), dim3(256), lds, (hipStream_t)stream, q, kv, relbias, dout,
+    hipLaunchKernelGGL(window_attention_bwd_kernel, dim3(2 * (H / WS) * (W / WS), batch), dim3(256), lds, (hipStream_t)stream, q, kv, relbias, dout,
                        dq, dkv, dbias_part, H, W, shift);
     SPEI_CHECK_LAUNCH("spei_window_attention_bwd");
     return 0;

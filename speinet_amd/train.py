@@ -309,9 +309,8 @@ class _WindowAttention(torch.autograd.Function):
         out = torch.empty_like(q)
         lib = _lib.lib()
         hw = H * W
-        for i in range(B):
-            _lib.check(lib.spei_window_attention(_p(ctx, q[i * hw:(i + 1) * hw]), _p(ctx, kv[i * hw:(i + 1) * hw]), 0, _p(ctx, rb),
-                                                 _p(ctx, out[i * hw:(i + 1) * hw]), H, W, shift, ctx._stream()), "spei_window_attention")
+        _lib.check(lib.spei_window_attention_batched(_p(ctx, q), _p(ctx, kv), 0, _p(ctx, rb), _p(ctx, out), H, W, shift, B, ctx._stream()),
+                   "spei_window_attention_batched")
         fctx.save_for_backward(q, kv, rb)
         fctx.meta = (B, H, W, shift)
         return out
@@ -327,11 +326,8 @@ class _WindowAttention(torch.autograd.Function):
         nwin = (H // 5) * (W // 5)
         part = torch.empty(B, nwin, 8, 25, 25, device=dout.device)
         hw = H * W
-        for i in range(B):
-            _lib.check(lib.spei_window_attention_bwd(_p(ctx, q[i * hw:(i + 1) * hw]), _p(ctx, kv[i * hw:(i + 1) * hw]), _p(ctx, rb),
-                                                     _p(ctx, dout[i * hw:(i + 1) * hw]), _p(ctx, dq[i * hw:(i + 1) * hw]),
-                                                     _p(ctx, dkv[i * hw:(i + 1) * hw]), _p(ctx, part[i]), H, W, shift, ctx._stream()),
-                       "spei_window_attention_bwd")
+        _lib.check(lib.spei_window_attention_bwd(_p(ctx, q), _p(ctx, kv), _p(ctx, rb), _p(ctx, dout), _p(ctx, dq), _p(ctx, dkv), _p(ctx, part),
+                                                 H, W, shift, B, ctx._stream()), "spei_window_attention_bwd")
         return dq, dkv, part.sum(dim=(0, 1)), None, None, None, None
 
 
@@ -521,12 +517,10 @@ class _GatedSum(torch.autograd.Function):
         rowmax, rowmean = torch.empty(B, H, c, device=dev), torch.empty(B, H, c, device=dev)
         colmax, colmean = torch.empty(B, W, c, device=dev), torch.empty(B, W, c, device=dev)
         mean = torch.empty(B, c, device=dev)
-        ws = torch.empty(lib.spei_plane_ws_floats(H, W, c), device=dev)
+        ws = torch.empty(B * lib.spei_plane_ws_floats(H, W, c), device=dev)
         hw = H * W
-        for i in range(B):
-            _lib.check(lib.spei_plane_stats(_p(ctx, x1[i * hw:(i + 1) * hw]), _NULL, 0, H, W, c, _p(ctx, rowmax[i]), _p(ctx, rowmean[i]),
-                                            _p(ctx, colmax[i]), _p(ctx, colmean[i]), _p(ctx, mean[i]), _p(ctx, ws), ctx._stream()),
-                       "spei_plane_stats")
+        _lib.check(lib.spei_plane_stats_batched(_p(ctx, x1), _NULL, 0, H, W, c, _p(ctx, rowmax), _p(ctx, rowmean), _p(ctx, colmax),
+                                                _p(ctx, colmean), _p(ctx, mean), _p(ctx, ws), B, ctx._stream()), "spei_plane_stats_batched")
         prm = [t.detach() for t in params]
         with torch.no_grad():
             s, g1, g2 = _gate_maps(rowmax, rowmean, colmax, colmean, mean, prm, bn_train, update_running=bn_train)
@@ -554,11 +548,9 @@ class _GatedSum(torch.autograd.Function):
         hw = H * W
         # gradients of the gates: sums of dOut * x1 over x, over y, over the map
         dg1, dg2, ds = torch.empty(B, H, c, device=dev), torch.empty(B, W, c, device=dev), torch.empty(B, c, device=dev)
-        ws = torch.empty(lib.spei_plane_ws_floats(H, W, c), device=dev)
-        for i in range(B):
-            sl = slice(i * hw, (i + 1) * hw)
-            _lib.check(lib.spei_plane_stats(_p(ctx, dout[sl]), _p(ctx, x1[sl]), 1, H, W, c, _NULL, _p(ctx, dg1[i]), _NULL, _p(ctx, dg2[i]),
-                                            _p(ctx, ds[i]), _p(ctx, ws), ctx._stream()), "spei_plane_stats")
+        ws = torch.empty(B * lib.spei_plane_ws_floats(H, W, c), device=dev)
+        _lib.check(lib.spei_plane_stats_batched(_p(ctx, dout), _p(ctx, x1), 1, H, W, c, _NULL, _p(ctx, dg1), _NULL, _p(ctx, dg2), _p(ctx, ds),
+                                                _p(ctx, ws), B, ctx._stream()), "spei_plane_stats_batched")
         # through the (tiny) gate maps with torch.autograd: statistics and parameters are the leaves
         with torch.enable_grad():
             stats = [t.detach().requires_grad_(True) for t in (rowmax, rowmean, colmax, colmean, mean)]
