@@ -298,6 +298,8 @@ class SPEINet(nn.Module):
             # BatchNorm(1) on batch statistics and DropPath, as the reference module does under
             # trainer/trainer_swint_hsa_nsf.py:27-40; eval() with autograd recording is the same graph with running statistics
             from . import train
+            if self.training:
+                self.invalidate_packed()      # an optimizer step follows: the packed inference weights are stale from here on
             return train.forward_speinet(self, x, scales=drop_path_scales)
         _lib.lib()
         h, w = x.shape[-2:]

@@ -88,6 +88,8 @@ class SPEINet(nn.Module):
             # statistics and DropPath, as the reference module does under trainer/trainer_swint.py:27,39; eval() with grad enabled
             # is the same graph with running statistics and no DropPath
             from . import train
+            if self.training:
+                self.invalidate_packed()      # an optimizer step follows: the packed inference weights are stale from here on
             return train.forward_swint(self, x, scales=drop_path_scales)
         with torch.cuda.device(x.device):
             ctx = ops.Ctx(self.precision, "top2", device=x.device, profile=profile, **self.knobs)

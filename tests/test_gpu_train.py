@@ -431,6 +431,14 @@ def test_trainer_steps_reduce_the_loss():
     assert losses[-1] < losses[0] and all(np.isfinite(losses))
     moved = sum(int(not torch.equal(before[k], v.detach())) for k, v in net.named_parameters())
     assert moved == len(before), (moved, len(before))
+    # evaluation after training (Trainer.test in the reference: model.eval() under no_grad): the inference path must see the UPDATED
+    # parameters — its packed weights were dropped by the training forward
+    net.eval()
+    net.precision = "f32"
+    with torch.no_grad():
+        ev = net(x)
+    ev2 = net(x)                                   # the differentiable graph reads the live parameters
+    assert (ev - ev2.detach()).abs().max().item() < 2e-5
 
 
 @pytest.mark.parametrize("which", ["swint", "speinet"])
