@@ -48,8 +48,8 @@ def rl_prior(img: torch.Tensor, iters: int, lam: float = 0.01) -> torch.Tensor:
     """
     b_, c_, h, w = img.shape
     x = img.reshape(b_ * c_, 1, h, w)
-    box = torch.ones(1, 1, 5, 5, dtype=torch.float32) / 25.0
-    lap = torch.tensor([[0, -1, 0], [-1, 4, -1], [0, -1, 0]], dtype=torch.float32).view(1, 1, 3, 3)
+    box = torch.ones(1, 1, 5, 5, dtype=img.dtype) / 25.0                 # (the reference builds both in fp32, its only dtype)
+    lap = torch.tensor([[0, -1, 0], [-1, 4, -1], [0, -1, 0]], dtype=img.dtype).view(1, 1, 3, 3)
     d = x.clone()
     for _ in range(iters):
         blurred = F.conv2d(d, box, padding=2)
@@ -63,8 +63,43 @@ def rl_prior(img: torch.Tensor, iters: int, lam: float = 0.01) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------
 # K2/K3  ResBlock = conv5-relu-conv5, SE + TripletAttention gates, skip  (model/block.py:8-140)
 # --------------------------------------------------------------------------------------------
+class _TrainState:
+    """Train-mode switches of the restatement (used by the training-step checks only; default = the eval graph):
+    bn_batch — BatchNorm2d(1) normalises with the statistics of the batch (nn.BatchNorm2d in train(), model/block.py:56);
+    drop     — iterator over the DropPath factors in call order, one (attention [B], mlp [B]) pair or None per Swin block
+               (timm.models.layers.DropPath as used at model/swinir.py:203,278-279)."""
+    bn_batch = False
+    drop = None
+
+
+_TRAIN = _TrainState()
+
+
+class train_mode:
+    """``with train_mode(drop_scales):`` — evaluate the restatement as the reference module computes in train(): batch
+    statistics in the gates' BatchNorm (the running buffers are not touched: the restatement is functional) and the given
+    DropPath factors ([call][block] -> None | (attn [B], mlp [B]); None = no DropPath).  With tensors of ``sd`` that require
+    grad, ``loss.backward()`` then gives the training gradients."""
+
+    def __init__(self, drop_scales=None):
+        self.flat = None if drop_scales is None else [pair for call in drop_scales for pair in call]
+
+    def __enter__(self):
+        _TRAIN.bn_batch, _TRAIN.drop = True, (iter(self.flat) if self.flat is not None else None)
+        return self
+
+    def __exit__(self, *exc):
+        left = list(_TRAIN.drop) if _TRAIN.drop is not None else []
+        _TRAIN.bn_batch, _TRAIN.drop = False, None
+        assert exc[0] is not None or not left, f"{len(left)} DropPath factors were not consumed"
+        return False
+
+
 def _bn1_eval(x: torch.Tensor, sd: SD, p: str) -> torch.Tensor:
-    """BatchNorm2d(1) in eval mode, eps 1e-5 (model/block.py:56)."""
+    """BatchNorm2d(1), eps 1e-5 (model/block.py:56): running statistics (eval), or the batch's (inside ``train_mode``)."""
+    if _TRAIN.bn_batch:
+        m, v = x.mean(), x.var(unbiased=False)
+        return (x - m) / torch.sqrt(v + 1e-5) * sd[p + "weight"].view(1, -1, 1, 1) + sd[p + "bias"].view(1, -1, 1, 1)
     return (x - sd[p + "running_mean"].view(1, -1, 1, 1)) / torch.sqrt(sd[p + "running_var"].view(1, -1, 1, 1) + 1e-5) \
         * sd[p + "weight"].view(1, -1, 1, 1) + sd[p + "bias"].view(1, -1, 1, 1)
 
@@ -159,7 +194,7 @@ def rel_pos_index(ws: int) -> torch.Tensor:
 
 def shift_mask(h: int, w: int, ws: int, shift: int) -> torch.Tensor:
     """``calculate_mask`` (model/swinir.py:215-236): [nW, ws*ws, ws*ws] of 0 / -100."""
-    img = torch.zeros(1, h, w, 1)
+    img = torch.zeros(1, h, w, 1)          # region ids: small integers, exact in any float type
     cnt = 0
     for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
         for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
@@ -221,10 +256,13 @@ def swin_block(x, y, x_size, sd: SD, p: str, nh: int, ws: int, shift: int):
     xr = window_reverse(aw, ws, h, w)
     if shift > 0:
         xr = torch.roll(xr, shifts=(shift, shift), dims=(1, 2))
-    x = shortcut + xr.view(b, h * w, c)
+    pair = next(_TRAIN.drop) if _TRAIN.drop is not None else None          # DropPath factors of this block, or None
+    branch = xr.view(b, h * w, c)
+    x = shortcut + (branch if pair is None else branch * pair[0].to(branch.dtype).view(b, 1, 1))
     hmid = F.gelu(F.linear(F.layer_norm(x, (c,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-5),
                            sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))
-    return x + F.linear(hmid, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+    branch = F.linear(hmid, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+    return x + (branch if pair is None else branch * pair[1].to(branch.dtype).view(b, 1, 1))
 
 
 def rstb(x, y, x_size, sd: SD, p: str, depth: int, nh: int, ws: int):
@@ -270,14 +308,13 @@ def correlation_max(lrsr: torch.Tensor, refsr: torch.Tensor, chunk: int = 4096):
     lu = F.normalize(F.unfold(lrsr, kernel_size=(3, 3), padding=1), dim=1)                      # [B,1152,N]
     ru = F.normalize(F.unfold(refsr, kernel_size=(3, 3), padding=1).permute(0, 2, 1), dim=2)    # [B,Nr,1152]
     n = lu.shape[2]
-    smax = torch.empty(lu.shape[0], n)
-    sarg = torch.empty(lu.shape[0], n, dtype=torch.long)
+    ms, args = [], []
     for i0 in range(0, n, chunk):
         r = torch.bmm(ru, lu[:, :, i0:i0 + chunk])
         m, a = torch.max(r, dim=1)
-        smax[:, i0:i0 + chunk] = m
-        sarg[:, i0:i0 + chunk] = a
-    return smax, sarg
+        ms.append(m)
+        args.append(a)
+    return torch.cat(ms, dim=1), torch.cat(args, dim=1)      # (concatenation keeps dtype and the autograd graph of the maxima)
 
 
 def _bis(inp: torch.Tensor, dim: int, index: torch.Tensor) -> torch.Tensor:
@@ -383,7 +420,7 @@ def route(x: torch.Tensor) -> torch.Tensor:
 def forward(x: torch.Tensor, sd: SD, cfg: Cfg = Cfg()) -> torch.Tensor:
     """``SPEINet.forward`` (model/speinet.py:150-168).  x [B, n_sequence+2, 3, H, W] -> [B,3,H,W], unclamped."""
     z = route(x)
-    out = torch.empty(x.shape[0], x.shape[2], x.shape[3], x.shape[4])
+    out = torch.empty(x.shape[0], x.shape[2], x.shape[3], x.shape[4], dtype=x.dtype)
     if z.any():
         out[z] = forward_b(x[z], sd, cfg)
     if (~z).any():

@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--patch", type=int, default=200)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--cpu-baseline", action="store_true",
+                    help="also time one training step of the oracle (CPU restatement, fp32, torch autograd) on the host cores: 2 crops")
     ap.add_argument("--model", choices=["swint", "speinet"], default="swint",
                     help="swint: model/swint.py (trainer_swint.py, config 5); speinet: model/speinet.py (trainer_swint_hsa_nsf.py), every "
                          "4th crop without a sharp reference")
@@ -84,11 +86,35 @@ def main():
         t = torch.tensor([ms], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms = float(t.item())
+    cpu = None
+    if rank == 0 and a.cpu_baseline:
+        # the checker as a baseline: the oracle's train-mode graph + torch autograd on the host, fp32, a bounded sample
+        import time
+        from oracle import speinet_oracle as O
+        from speinet_amd.train import drop_path_scales, speinet_drop_path_scales
+        threads = min(os.cpu_count() or 1, 16)
+        torch.set_num_threads(threads)
+        nb = 2
+        xs, gs = x[:nb].cpu(), gt[:nb].cpu()
+        sd = {k: (v.detach().cpu().clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.detach().cpu())
+              for k, v in net.state_dict().items()}
+        if a.model == "speinet":
+            sc = speinet_drop_path_scales(net.cfg.depths, [bool(v) for v in (xs[:, 3].reshape(nb, -1) == 0).all(dim=1).tolist()], 3)
+            calls = sc.get(False, []) + sc.get(True, [])
+        else:
+            calls = drop_path_scales(net.cfg.depths, nb, 2)
+        t0 = time.time()
+        with O.train_mode(calls):
+            o = (O.forward if a.model == "speinet" else O.forward_swint)(xs, sd, O.Cfg(n_sequence=3))
+        Loss("1*L1+2*HEM", device="cpu")(o, gs).backward()
+        dt = time.time() - t0
+        cpu = {"value": nb / dt, "unit": "crops/s", "cores": threads, "kind": "port",
+               "sample": f"oracle train-mode graph + torch autograd (fp32), forward + loss + backward of {nb} crops of {a.patch}x{a.patch} in {dt:.1f} s, no optimizer step"}
     if rank == 0:
         print(json.dumps({"metric": f"training crops/s, {a.model} model, fwd + loss + bwd + Adam", "value": world * a.batch * 1e3 / ms,
                           "unit": "crops/s", "n_gpus": world, "batch_per_gpu": a.batch, "patch": a.patch, "n_sequence": 3, "ms_per_step": ms,
                           "ms": {"forward": float(split[0]), "loss_backward": float(split[1]), "adam": float(split[2])},
-                          "loss": float(loss.item()), "dtype": "f32", "data": "synthetic", "scaling": "weak"}))
+                          "loss": float(loss.item()), "dtype": "f32", "data": "synthetic", "scaling": "weak", "cpu_baseline": cpu}))
     if dist is not None:
         dist.destroy_process_group()
 
