@@ -26,6 +26,11 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                  (F = 20.64 TFLOP) against the same peak.  `traffic` / `path_hbm_bytes_per_frame`: HBM bytes from
                  rocprofv3 PMC passes made OFFLINE with tools/pmc_traffic.py (FETCH_SIZE doubled as the guide prescribes for
                  wide coalesced reads on gfx950) and read from profiles/ — `traffic_source` names the file, null if absent.
+  --train        a second measurement, BASELINE.json configs[4] (trainer/trainer_swint.py on 200x200 crops, option/template.py:6-22):
+                 `python bench.py --train [--model swint|speinet] [--batch 20] [--steps 5] [--warmup 2] [--cpu-baseline]` prints ONE
+                 JSON line of its own — training crops/s (forward in train() mode, 1*L1+2*HEM, backward, Adam; N ranks under
+                 torch.distributed.run average gradients over RCCL, weak scaling), the per-phase split by HIP events, and with
+                 --cpu-baseline the oracle's train-mode graph under torch autograd on the host cores (2 crops)
   harness        (N = 1, unless --no-harness) end-to-end frames/s of the inference harness (speinet_amd.inference, the counterpart of
                  inference_SPEINet.py) on a synthetic 720p clip ON DISK: PNG decode, selection, upload, forward with cross-window
                  encoder reuse, uint8, PSNR / SSIM, PNG encode — what a user of the reference's script gets per frame.
@@ -102,6 +107,107 @@ def cpu_baseline(seed: int, mode: str, budget_s: float) -> dict:
     return {"value": 1.0 / (dt * scale), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"EXTRAPOLATED: oracle on one {sw}x{sh} _forwardbs frame in {dt:.1f} s, scaled x{scale:.2f} to 720p by F(HW) of "
                       "BASELINE.md (optimistic: the 57600^2 correlation does not scale like FLOPs)"}
+
+
+def train_main(argv=None):
+    """`bench.py --train ...`: training-step throughput (config 5), see the module docstring."""
+    ap = argparse.ArgumentParser(prog="bench.py --train")
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--patch", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--cpu-baseline", action="store_true",
+                    help="also time one training step of the oracle (CPU restatement, fp32, torch autograd) on the host cores: 2 crops")
+    ap.add_argument("--model", choices=["swint", "speinet"], default="swint",
+                    help="swint: model/swint.py (trainer_swint.py, config 5); speinet: model/speinet.py (trainer_swint_hsa_nsf.py), every "
+                         "4th crop without a sharp reference")
+    a = ap.parse_args(argv)
+    import numpy as np
+    from speinet_amd.loss import Loss
+    from speinet_amd.speinet import default_args
+    from speinet_amd.swint import SPEINet
+    from speinet_amd.synth import synth_frames, synth_state_dict
+    from speinet_amd.trainer import allreduce_gradients, broadcast_buffers
+    rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
+    dev = f"cuda:{local}"
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    args = default_args()
+    args.n_sequence = 3
+    if a.model == "speinet":
+        from speinet_amd.speinet import SPEINet as FullNet
+        net = FullNet(args=args)
+    else:
+        net = SPEINet(n_sequence=3, args=args)
+    net.load_state_dict(synth_state_dict(net.state_dict(), seed=0), strict=True)
+    net = net.to(dev).train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=0.0)
+    loss_fn = Loss("1*L1+2*HEM", device=dev)
+    if a.model == "speinet":
+        x = synth_frames(a.batch, a.patch, a.patch, seed=7 + 2 * rank, zero_ref=tuple(range(3, a.batch, 4))).contiguous().to(dev)
+    else:
+        x = synth_frames(a.batch, a.patch, a.patch, seed=7 + 2 * rank)[:, :3].contiguous().to(dev)
+    gt = synth_frames(a.batch, a.patch, a.patch, seed=8 + 2 * rank)[:, 1].contiguous().to(dev)
+    torch.manual_seed(rank)
+    np.random.seed(rank)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    split = np.zeros(3)
+    for it in range(a.warmup + a.steps):
+        e = [ev() for _ in range(4)]
+        e[0].record()
+        out = net(x)
+        e[1].record()
+        opt.zero_grad()
+        loss = loss_fn(out, gt)
+        loss.backward()
+        allreduce_gradients(net.parameters())
+        e[2].record()
+        opt.step()
+        broadcast_buffers(net)
+        e[3].record()
+        torch.cuda.synchronize()
+        if it >= a.warmup:
+            split += [e[i].elapsed_time(e[i + 1]) for i in range(3)]
+    split /= a.steps
+    ms = float(split.sum())
+    if dist is not None:
+        t = torch.tensor([ms], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item())
+    cpu = None
+    if rank == 0 and a.cpu_baseline:
+        # the checker as a baseline (SURVEY.md §8d): the oracle's train-mode graph + torch autograd on the host, fp32, a bounded sample
+        import time
+        from oracle import speinet_oracle as O
+        from speinet_amd.train import drop_path_scales, speinet_drop_path_scales
+        threads = min(os.cpu_count() or 1, 16)
+        torch.set_num_threads(threads)
+        nb = 2
+        xs, gs = x[:nb].cpu(), gt[:nb].cpu()
+        sd = {k: (v.detach().cpu().clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.detach().cpu())
+              for k, v in net.state_dict().items()}
+        if a.model == "speinet":
+            sc = speinet_drop_path_scales(net.cfg.depths, [bool(v) for v in (xs[:, 3].reshape(nb, -1) == 0).all(dim=1).tolist()], 3)
+            calls = sc.get(False, []) + sc.get(True, [])
+        else:
+            calls = drop_path_scales(net.cfg.depths, nb, 2)
+        t0 = time.time()
+        with O.train_mode(calls):
+            o = (O.forward if a.model == "speinet" else O.forward_swint)(xs, sd, O.Cfg(n_sequence=3))
+        Loss("1*L1+2*HEM", device="cpu")(o, gs).backward()
+        dt = time.time() - t0
+        cpu = {"value": nb / dt, "unit": "crops/s", "cores": threads, "kind": "port",
+               "sample": f"oracle train-mode graph + torch autograd (fp32), forward + loss + backward of {nb} crops of {a.patch}x{a.patch} in {dt:.1f} s, no optimizer step"}
+    if rank == 0:
+        print(json.dumps({"metric": f"training crops/s, {a.model} model, fwd + loss + bwd + Adam", "value": world * a.batch * 1e3 / ms,
+                          "unit": "crops/s", "n_gpus": world, "batch_per_gpu": a.batch, "patch": a.patch, "n_sequence": 3, "ms_per_step": ms,
+                          "ms": {"forward": float(split[0]), "loss_backward": float(split[1]), "adam": float(split[2])},
+                          "loss": float(loss.item()), "dtype": "f32", "data": "synthetic", "scaling": "weak", "cpu_baseline": cpu}))
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def main():
@@ -243,4 +349,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--train" in sys.argv[1:]:
+        train_main([v for v in sys.argv[1:] if v != "--train"])
+    else:
+        main()
