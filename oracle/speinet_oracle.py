@@ -1,6 +1,7 @@
 """ORACLE — test infrastructure only.  CPU restatement (PyTorch fp32, functional) of the reference
-SPEINet per-sequence forward pass.  Nothing under ``speinet_amd/`` may import this file; only
-``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg use it, as the checker.
+SPEINet per-sequence forward pass (and, inside ``train_mode``, of the training graph: torch autograd over the same functions).
+Nothing under ``speinet_amd/`` or ``tools/`` may import this file; only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` legs (inference and ``--train``) use it, as the checker / the CPU baseline.
 
 Pinning: checked in ``tests/test_oracle_golden.py`` against golden vectors produced by importing
 the reference itself in the build container (``tests/golden/make_golden.py``; recipe in SURVEY.md §8c).

@@ -19,9 +19,21 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import speinet_oracle as O                                                     # noqa: E402  (checker only)
 from speinet_amd.speinet import SPEINet, default_args                                      # noqa: E402
 from speinet_amd.synth import state_dict_template, synth_frames, synth_frames_edges, synth_state_dict   # noqa: E402
+
+
+def _to_uint8(t):
+    """tensor2numpy of the harness (inference_SPEINet.py:477-482): [0,1] floats -> uint8, rounded."""
+    return t.detach().float().mul(255.0).clamp(0, 255).round().to(torch.uint8)
+
+
+def _psnr_uint8(a, b, shave: int = 4) -> float:
+    """PSNR of two uint8 frames with a 4-pixel border removed (inference_SPEINet.py:484-500)."""
+    a, b = a[..., shave:-shave, shave:-shave].double(), b[..., shave:-shave, shave:-shave].double()
+    mse = ((a - b) ** 2).mean().item()
+    return float("inf") if mse == 0 else 20.0 * __import__("math").log10(255.0 / mse ** 0.5)
+
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 BF = {"precision": "bf16"}
@@ -66,7 +78,7 @@ def load_case(name):
         zr = tuple(int(i) for i in d["zero_ref"]) if "zero_ref" in d else ()
         x = synth_frames(b, h, w, seed=int(d["seed"]), zero_ref=zr)
         d["sub"] = d["out"][:, :, ::8, ::8]
-        d["psnr"] = np.array([O.psnr_uint8(O.to_uint8(out[i:i + 1]), O.to_uint8(x[i:i + 1, 1])) for i in range(b)])
+        d["psnr"] = np.array([_psnr_uint8(_to_uint8(out[i:i + 1]), _to_uint8(x[i:i + 1, 1])) for i in range(b)])
         return d, x, x[:, 1], zr
     b = d["sub"].shape[0]
     h, w = d["sub"].shape[2] * 8, d["sub"].shape[3] * 8
@@ -119,7 +131,7 @@ def main():
                         si += 1
             out = torch.cat(outs)
             err = (out[:, :, ::8, ::8] - sub).abs().max().item()
-            dp = max(abs(O.psnr_uint8(O.to_uint8(out[i:i + 1]), O.to_uint8(gt[i:i + 1])) - float(d["psnr"][i])) for i in range(x.shape[0]))
+            dp = max(abs(_psnr_uint8(_to_uint8(out[i:i + 1]), _to_uint8(gt[i:i + 1])) - float(d["psnr"][i])) for i in range(x.shape[0]))
             rows.append({"case": case, "config": label, "max_err_grid": err, "dpsnr_db": dp, "argmax_flips": flips,
                          "flips_margin_ge_1e-5": tight, "max_s_err": serr})
             print(f"{case:26s} {label:40s} max|err| {err:.2e}  |dPSNR| {dp:.2e} dB  flips {flips:5d} (non-near-tie {tight})  "

@@ -12,12 +12,24 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import speinet_oracle as O                                                     # noqa: E402  (checker only)
 from speinet_amd.speinet import SPEINet, default_args                                      # noqa: E402
 from speinet_amd.synth import state_dict_template, synth_frames, synth_frames_edges, synth_state_dict   # noqa: E402
 
 dev = torch.device("cuda:0")
 sd = synth_state_dict(state_dict_template(), seed=0)
+
+
+
+def _to_uint8(t):
+    """tensor2numpy of the harness (inference_SPEINet.py:477-482): [0,1] floats -> uint8, rounded."""
+    return t.detach().float().mul(255.0).clamp(0, 255).round().to(torch.uint8)
+
+
+def _psnr_uint8(a, b, shave: int = 4) -> float:
+    """PSNR of two uint8 frames with a 4-pixel border removed (inference_SPEINet.py:484-500)."""
+    a, b = a[..., shave:-shave, shave:-shave].double(), b[..., shave:-shave, shave:-shave].double()
+    mse = ((a - b) ** 2).mean().item()
+    return float("inf") if mse == 0 else 20.0 * __import__("math").log10(255.0 / mse ** 0.5)
 
 
 def rounded(sd, dt):
@@ -36,7 +48,7 @@ def stats(tag, out, base, gt):
     e = (out - base).double() * 255.0
     r = (base - gt).double() * 255.0
     c = (e * r).mean() / (e.pow(2).mean().sqrt() * r.pow(2).mean().sqrt())
-    dp = O.psnr_uint8(O.to_uint8(out), O.to_uint8(gt)) - O.psnr_uint8(O.to_uint8(base), O.to_uint8(gt))
+    dp = _psnr_uint8(_to_uint8(out), _to_uint8(gt)) - _psnr_uint8(_to_uint8(base), _to_uint8(gt))
     pred = 4.3429 * (2 * (e * r).mean() + e.pow(2).mean()) / r.pow(2).mean()
     print(f"  {tag:44s} mean e {e.mean():+.4f}  rms e {e.pow(2).mean().sqrt():.4f} levels  corr(e,r) {c:+.4f}  dPSNR {dp:+.2e} dB "
           f"(-{pred:.2e} predicted from e, r)", flush=True)
