@@ -100,6 +100,16 @@ int spei_conv_slab16(int fmt, const void* a0, int lda0, int k0, const void* a1, 
                      const float* residual, int ldr, const float* rowscale, int Hin, int Win, int Hout, int Wout,
                      int N, int ksize, int stride, int pad, int act, int ln_input, spei_stream_t stream);
 
+/* The same convolution (stride 1, pad k/2, one dense fp32 input map, single-product arithmetic) with the PREVIOUS ResBlock's gated
+ * residual sum folded into its staging (model/block.py:136-140 feeding the next block's first conv, :127-131):
+ *     x'[p][c] = x[p][c] + x1[p][c] * (s[c] + g1[y][c] + g2[x][c]),    out = act(conv(x', w) + bias)
+ * x' is what spei_resblock_apply would have written; every pixel of it is also stored to x_out (fp32 [H*W][K], must not alias x)
+ * by the workgroup that owns it: the residual stream of the next block.  x1: 16-bit (fmt) [H*W][K]; s [K], g1 [H][K], g2 [W][K]
+ * from spei_resblock_gates.  K in {32, 64, 128, 256}. */
+int spei_conv_slab16_fa(int fmt, const float* x, int K, const void* x1, const float* s, const float* g1, const float* g2,
+                        float* x_out, const void* wfrag, const float* bias, void* out, int ldo, int out_fmt, int H, int W, int N,
+                        int ksize, int act, spei_stream_t stream);
+
 /* Fused Swin MLP branch (model/swinir.py:12-29 Mlp.forward + the `x + mlp(norm2(x))` tail of :279), 16-bit matrix pipe:
  * out = x + fc2(GELU(fc1(LayerNorm256(x)))), LayerNorm affine folded into w1/b1 (pack.py); w*_frag in MFMA fragment
  * order; the normalised tokens and the 512-wide hidden activations live only in LDS.  x, out: [M][256] fp32, may alias. */

@@ -53,6 +53,13 @@ struct SlabParams {
     int ln;                  // 1: LayerNorm(256) without affine is applied to every input row while it is staged
                              //    (fp32 input, K == 256: one wave-instruction loads exactly one token row)
     int stagger, stagger_slots;   // first-round start delay (units of 64 cycles) per co-resident workgroup slot
+    // Fused "apply" staging (template flag FA; 2-D stride-1 convs on fp32 maps): the input map is NOT a0 itself but
+    //     x'[p][c] = a0[p][c] + x1[p][c] * (s[c] + g1[y][c] + g2[x][c])          (the tail of the previous ResBlock, model/block.py:136-140)
+    // computed while the slab is staged; the pixels of the workgroup's own output tile are also written to fa_out (fp32, row stride K):
+    // the residual stream of the next block.  x1: LP, row stride K; s [K], g1 [Hin][K], g2 [Win][K].
+    const void* fa_x1;
+    const float *fa_s, *fa_g1, *fa_g2;
+    float* fa_out;
     long long* stamps;       // tuning build: phase stamps (tools/stamp_phases.py conv), else NULL
     int dbg;                 // ablation switches for tools/ablate_slab.py (0 in production): 1 no staging loads, 8 weight stream from one hot group,
                              // 4 no epilogue stores
@@ -103,8 +110,9 @@ struct Stage<float, SPLIT, LP> {
 };
 
 // LP: 16-bit operand type (__bf16 or _Float16); TA / TO: float or LP
-template <int WM, int WN, int TM, int TN, bool SPLIT, typename TA, typename TO, typename LP>
-__global__ __launch_bounds__(64 * WM * WN, (WM == 4 && WN == 1 && TM <= 2 && !SPLIT) ? 4 : 1) void conv_slab_kernel(const SlabParams p) {
+template <int WM, int WN, int TM, int TN, bool SPLIT, typename TA, typename TO, typename LP, bool FA = false>
+__global__ __launch_bounds__(64 * WM * WN, (WM == 4 && WN == 1 && TM <= 2 && !SPLIT) ? (FA ? 3 : 4) : 1) void conv_slab_kernel(const SlabParams p) {
+    static_assert(!FA || (sizeof(TA) == 4 && !SPLIT), "the fused apply staging reads an fp32 map");
     constexpr int NT = 64 * WM * WN;                   // threads: 4 or 8 waves
     constexpr int RING = ring_depth<WM, WN>();
     typedef Stage<TA, SPLIT, LP> ST;
@@ -165,11 +173,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 4 && WN == 1 && TM <= 2 && !SP
             const TA* src = (c < p.k0) ? a0 + c : a1 + (c - p.k0);
             const int ld = (c < p.k0) ? p.lda0 : p.lda1;
             const int lofs = c * 2;
+            typedef typename lpv<LP>::x4 lp4s;
+            f32x4 fa_sv = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (FA) fa_sv = *reinterpret_cast<const f32x4*>(p.fa_s + c);
             while (pix < npix) {
                 // branch-free loads: clamp the coordinates to a valid pixel, select zero afterwards
                 sreg_t v[U];
                 int off[U];
                 bool ok[U];
+                // fused apply: x1 rides with the map loads; the gate rows / columns (L2-resident, just written by the gate kernel) go
+                // through a 4-deep register pipeline — all eight in flight at once cost 64 registers and an occupancy step
+                constexpr int GP = 4;
+                lp4s fx1[FA ? U : 1];
+                f32x4 fg1[FA ? GP : 1], fg2[FA ? GP : 1];
+                unsigned fpix[FA ? U : 1], fyx[FA ? U : 1];
+                bool fin[FA ? U : 1];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int gy = gy0 + iy, gx = gx0 + ix;
@@ -177,6 +195,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 4 && WN == 1 && TM <= 2 && !SP
                     ok[u] = (gy >= 0) & (gy < p.Hin) & (gx >= 0) & (gx < p.Win) & !(p.dbg & 1);
                     const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
                     v[u] = *reinterpret_cast<const sreg_t*>(src + ((size_t)cy * p.Win + cx) * ld);
+                    if constexpr (FA) {        // everything the fused apply needs, issued with the map loads (one round trip)
+                        fpix[u] = (unsigned)(cy * p.Win + cx);
+                        fyx[u] = ((unsigned)cy << 16) | (unsigned)cx;
+                        fx1[u] = *reinterpret_cast<const lp4s*>(static_cast<const LP*>(p.fa_x1) + (size_t)fpix[u] * p.K + c);
+                        if (u < GP) {
+                            fg1[u] = *reinterpret_cast<const f32x4*>(p.fa_g1 + (size_t)cy * p.K + c);
+                            fg2[u] = *reinterpret_cast<const f32x4*>(p.fa_g2 + (size_t)cx * p.K + c);
+                        }
+                        fin[u] = ok[u] & (pix < npix) & (iy >= p.pad) & (iy < p.pad + p.TH) & (ix >= p.pad) & (ix < p.pad + p.TW);
+                    }
                     pix += step;
                     ix += step_x;
                     iy += step_y;
@@ -186,6 +214,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 4 && WN == 1 && TM <= 2 && !SP
                 for (int u = 0; u < U; ++u)
                 {
                     sreg_t val = ok[u] ? v[u] : ST::zero();
+                    if constexpr (FA) {
+                        if (ok[u]) {
+                            // x3 = se(x1) + (cw(x1) + hc(x1));  return x3 + x   (block.py:136-140): resblock_apply_kernel's expression
+                            f32x4 b;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) b[e] = (float)fx1[u][e];
+                            val = (b * fa_sv + (b * fg1[u % GP] + b * fg2[u % GP])) + val;
+                            if (fin[u]) *reinterpret_cast<f32x4*>(p.fa_out + (size_t)fpix[u] * p.K + c) = val;
+                        }
+                        if (u + GP < U) {          // refill the slot just consumed
+                            fg1[u % GP] = *reinterpret_cast<const f32x4*>(p.fa_g1 + (size_t)(fyx[u + GP] >> 16) * p.K + c);
+                            fg2[u % GP] = *reinterpret_cast<const f32x4*>(p.fa_g2 + (size_t)(fyx[u + GP] & 0xffffu) * p.K + c);
+                        }
+                    }
                     if constexpr (sizeof(TA) == 4) {
                         if (p.ln) {      // the 64 lanes of this wave hold the 256 channels of one row
                             const float mean = wave_sum((val[0] + val[1]) + (val[2] + val[3])) * (1.0f / 256.0f);
@@ -431,9 +473,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 4 && WN == 1 && TM <= 2 && !SP
     SPEI_STAMP(p.stamps, 4);
 }
 
-template <int WM, int WN, int TM, int TN, bool SPLIT, typename TA, typename TO, typename LP>
+template <int WM, int WN, int TM, int TN, bool SPLIT, typename TA, typename TO, typename LP, bool FA = false>
 int launch(const SlabParams& p, size_t lds, hipStream_t s) {
-    ensure_dyn_lds<&conv_slab_kernel<WM, WN, TM, TN, SPLIT, TA, TO, LP>>(lds);
+    ensure_dyn_lds<&conv_slab_kernel<WM, WN, TM, TN, SPLIT, TA, TO, LP, FA>>(lds);
     SlabParams q = p;
     q.n_chunks = p.N / (WN * TN * 32);
     static const int dbg = spei_knob("SPEI_SLAB_DBG", 0);
@@ -442,12 +484,12 @@ int launch(const SlabParams& p, size_t lds, hipStream_t s) {
     static const int stagger = spei_knob("SPEI_SLAB_STAGGER", 0), slots = spei_knob("SPEI_SLAB_SLOTS", 3);
     q.stagger = stagger; q.stagger_slots = slots;
     dim3 grid(p.tiles_x * cdiv(p.Hout, p.TH), 1);
-    hipLaunchKernelGGL((conv_slab_kernel<WM, WN, TM, TN, SPLIT, TA, TO, LP>), grid, dim3(64 * WM * WN), lds, s, q);
+    hipLaunchKernelGGL((conv_slab_kernel<WM, WN, TM, TN, SPLIT, TA, TO, LP, FA>), grid, dim3(64 * WM * WN), lds, s, q);
     SPEI_CHECK_LAUNCH("spei_conv_slab16");
     return 0;
 }
 
-template <bool SPLIT, typename TA, typename TO, typename LP>
+template <bool SPLIT, typename TA, typename TO, typename LP, bool FA = false>
 int dispatch(SlabParams& p, hipStream_t s) {
     const int pitch = 2 * p.K + 16;
     const int nparts = SPLIT ? 2 : 1;
@@ -491,37 +533,37 @@ int dispatch(SlabParams& p, hipStream_t s) {
         static const int c32 = spei_knob("SPEI_SLAB_CFG_N32", 0), c64 = spei_knob("SPEI_SLAB_CFG_N64", 0), c128 = spei_knob("SPEI_SLAB_CFG_N128", 0);
         const bool ok2d = !linear;
         if (p.N == 32 && c32 && ok2d) {
-            if (c32 == 1) { lds = setup(256); if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 1, 4, 1, SPLIT, TA, TO, LP>(p, lds, s); }
-            if (c32 == 2) { lds = setup(512); if (lds <= hard && p.IH * p.IW < 2048) return launch<4, 1, 4, 1, SPLIT, TA, TO, LP>(p, lds, s); }
-            if (c32 == 3) { lds = setup(128); if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 1, 4, 1, SPLIT, TA, TO, LP>(p, lds, s); }
+            if (c32 == 1) { lds = setup(256); if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 1, 4, 1, SPLIT, TA, TO, LP, FA>(p, lds, s); }
+            if (c32 == 2) { lds = setup(512); if (lds <= hard && p.IH * p.IW < 2048) return launch<4, 1, 4, 1, SPLIT, TA, TO, LP, FA>(p, lds, s); }
+            if (c32 == 3) { lds = setup(128); if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 1, 4, 1, SPLIT, TA, TO, LP, FA>(p, lds, s); }
         }
         if (p.N % 64 == 0 && p.N % 128 != 0 && c64 && ok2d) {
-            if (c64 == 1) { lds = setup(128); if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 2, 4, 1, SPLIT, TA, TO, LP>(p, lds, s); }
-            if (c64 == 2) { lds = setup(256); if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 1, 4, 2, SPLIT, TA, TO, LP>(p, lds, s); }
-            if (c64 == 3) { lds = setup(256); if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 2, 4, 1, SPLIT, TA, TO, LP>(p, lds, s); }
-            if (c64 == 4) { lds = setup(128); if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 1, 4, 2, SPLIT, TA, TO, LP>(p, lds, s); }
+            if (c64 == 1) { lds = setup(128); if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 2, 4, 1, SPLIT, TA, TO, LP, FA>(p, lds, s); }
+            if (c64 == 2) { lds = setup(256); if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 1, 4, 2, SPLIT, TA, TO, LP, FA>(p, lds, s); }
+            if (c64 == 3) { lds = setup(256); if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 2, 4, 1, SPLIT, TA, TO, LP, FA>(p, lds, s); }
+            if (c64 == 4) { lds = setup(128); if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 1, 4, 2, SPLIT, TA, TO, LP, FA>(p, lds, s); }
         }
         if (p.N % 128 == 0 && c128 && ok2d) {
-            if (c128 == 1) { lds = setup(128); if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 2, 4, 2, SPLIT, TA, TO, LP>(p, lds, s); }
-            if (c128 == 2) { lds = setup(256); if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 2, 4, 2, SPLIT, TA, TO, LP>(p, lds, s); }
-            if (c128 == 3) { lds = setup(128); if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 4, 4, 1, SPLIT, TA, TO, LP>(p, lds, s); }
-            if (c128 == 4) { lds = setup(256); if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 4, 4, 1, SPLIT, TA, TO, LP>(p, lds, s); }
+            if (c128 == 1) { lds = setup(128); if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 2, 4, 2, SPLIT, TA, TO, LP, FA>(p, lds, s); }
+            if (c128 == 2) { lds = setup(256); if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 2, 4, 2, SPLIT, TA, TO, LP, FA>(p, lds, s); }
+            if (c128 == 3) { lds = setup(128); if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 4, 4, 1, SPLIT, TA, TO, LP, FA>(p, lds, s); }
+            if (c128 == 4) { lds = setup(256); if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 4, 4, 1, SPLIT, TA, TO, LP, FA>(p, lds, s); }
         }
     }
 #endif
     if (p.N % 128 == 0) {
         lds = setup(128);
-        if (lds <= budget && p.IH * p.IW < 2048) return launch<1, 4, 4, 1, SPLIT, TA, TO, LP>(p, lds, s);
+        if (lds <= budget && p.IH * p.IW < 2048) return launch<1, 4, 4, 1, SPLIT, TA, TO, LP, FA>(p, lds, s);
         lds = setup(64);
-        if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 4, 2, 1, SPLIT, TA, TO, LP>(p, lds, s);
+        if (lds <= hard && p.IH * p.IW < 2048) return launch<1, 4, 2, 1, SPLIT, TA, TO, LP, FA>(p, lds, s);
     } else if (p.N % 64 == 0) {
         lds = setup(128);
-        if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 2, 2, 1, SPLIT, TA, TO, LP>(p, lds, s);
+        if (lds <= hard && p.IH * p.IW < 2048) return launch<2, 2, 2, 1, SPLIT, TA, TO, LP, FA>(p, lds, s);
     } else {
         lds = setup(256);
-        if (lds <= budget && p.IH * p.IW < 2048) return launch<4, 1, 2, 1, SPLIT, TA, TO, LP>(p, lds, s);
+        if (lds <= budget && p.IH * p.IW < 2048) return launch<4, 1, 2, 1, SPLIT, TA, TO, LP, FA>(p, lds, s);
         lds = setup(128);
-        if (lds <= hard && p.IH * p.IW < 2048) return launch<4, 1, 1, 1, SPLIT, TA, TO, LP>(p, lds, s);
+        if (lds <= hard && p.IH * p.IW < 2048) return launch<4, 1, 1, 1, SPLIT, TA, TO, LP, FA>(p, lds, s);
     }
     spei_set_error("spei_conv_slab16: slab of %zu bytes (K=%d, k=%d, stride %d) does not fit LDS", lds, p.K, p.ks, p.stride);
     return -1;
@@ -533,6 +575,7 @@ int dispatch(SlabParams& p, hipStream_t s) {
 template <typename LP>
 static int dispatch_io(SlabParams& p, bool split, bool a16, bool o16, hipStream_t st) {
     if (split) return dispatch<true, float, float, LP>(p, st);
+    if (p.fa_x1) return o16 ? dispatch<false, float, LP, LP, true>(p, st) : dispatch<false, float, float, LP, true>(p, st);
     if (a16) return o16 ? dispatch<false, LP, LP, LP>(p, st) : dispatch<false, LP, float, LP>(p, st);
     return o16 ? dispatch<false, float, LP, LP>(p, st) : dispatch<false, float, float, LP>(p, st);
 }
@@ -547,12 +590,21 @@ static int dispatch_fmt(SlabParams& p, int fmt, bool split, bool a16, bool o16, 
     SPEI_REQUIRE(((fmt) == SPEI_BF16 || (fmt) == SPEI_F16) && ((a_fmt) == SPEI_F32 || (a_fmt) == (fmt)) &&              \
                  ((out_fmt) == SPEI_F32 || (out_fmt) == (fmt)), who ": fmt=%d a_fmt=%d out_fmt=%d", fmt, a_fmt, out_fmt)
 
-extern "C" int spei_conv_slab16(int fmt, const void* a0, int lda0, int k0, const void* a1, int lda1, int k1, int a_fmt,
-                                const void* wfrag_hi, const void* wfrag_lo, const float* bias, void* out, int ldo,
-                                int out_fmt, const float* residual, int ldr, const float* rowscale, int Hin, int Win,
-                                int Hout, int Wout, int N, int ksize, int stride, int pad, int act, int ln_input,
-                                spei_stream_t stream) {
+static int conv_slab16_run(int fmt, const void* a0, int lda0, int k0, const void* a1, int lda1, int k1, int a_fmt,
+                           const void* wfrag_hi, const void* wfrag_lo, const float* bias, void* out, int ldo,
+                           int out_fmt, const float* residual, int ldr, const float* rowscale, int Hin, int Win,
+                           int Hout, int Wout, int N, int ksize, int stride, int pad, int act, int ln_input,
+                           const void* fa_x1, const float* fa_s, const float* fa_g1, const float* fa_g2, float* fa_out,
+                           spei_stream_t stream) {
     SPEI_REQUIRE(a0 && wfrag_hi && out, "spei_conv_slab16: null pointer");
+    if (fa_x1) {
+        SPEI_REQUIRE(fa_s && fa_g1 && fa_g2 && fa_out, "spei_conv_slab16_fa: null pointer");
+        SPEI_REQUIRE(a_fmt == SPEI_F32 && !wfrag_lo && !a1 && k1 == 0 && lda0 == k0 && stride == 1 && ksize > 1 && !ln_input && Wout > 1,
+                     "spei_conv_slab16_fa: needs a dense fp32 map, one input, stride 1, a 2-D kernel, single-product arithmetic");
+        SPEI_REQUIRE(k0 == 32 || k0 == 64 || k0 == 128 || k0 == 256, "spei_conv_slab16_fa: K=%d (32 / 64 / 128 / 256)", k0);
+        SPEI_REQUIRE(((uintptr_t)fa_x1 | (uintptr_t)fa_s | (uintptr_t)fa_g1 | (uintptr_t)fa_g2 | (uintptr_t)fa_out) % 16 == 0 && fa_out != a0,
+                     "spei_conv_slab16_fa: 16-byte alignment, and fa_out must not be the input map (neighbouring tiles read its halo)");
+    }
     SPEI_REQUIRE_FMT("spei_conv_slab16", fmt, a_fmt, out_fmt);
     const bool a16 = a_fmt != SPEI_F32, o16 = out_fmt != SPEI_F32;
     SPEI_REQUIRE(k0 > 0 && k0 % 32 == 0 && k1 >= 0 && k1 % 32 == 0, "spei_conv_slab16: k0=%d k1=%d must be multiples of 32", k0, k1);
@@ -573,7 +625,7 @@ extern "C" int spei_conv_slab16(int fmt, const void* a0, int lda0, int k0, const
     SPEI_REQUIRE(!(wfrag_lo && (a16 || o16 || fmt != SPEI_BF16)), "spei_conv_slab16: the split (bf16x3) mode is bf16 with fp32 activations");
     SPEI_REQUIRE(ldo % 4 == 0 && (!residual || ldr % 4 == 0) && ((uintptr_t)out % 16 == 0) && (!residual || (uintptr_t)residual % 16 == 0),
                  "spei_conv_slab16: out / residual must be 16-byte aligned with row strides that are multiples of 4");
-    SlabParams p;
+    SlabParams p = {};
     p.a0 = a0; p.a1 = a1; p.wh = wfrag_hi; p.wl = wfrag_lo; p.bias = bias; p.out = out;
     p.res = residual; p.rowscale = rowscale;
     p.lda0 = lda0; p.lda1 = lda1; p.k0 = k0; p.k1 = k1; p.ldo = ldo; p.ldr = ldr;
@@ -583,7 +635,24 @@ extern "C" int spei_conv_slab16(int fmt, const void* a0, int lda0, int k0, const
     SPEI_REQUIRE(!ln_input || (!a16 && k0 == 256 && k1 == 0 && ksize == 1), "spei_conv_slab16: ln_input needs a 256-wide fp32 linear");
     p.ln = ln_input;
     p.ntap = 0; p.o_mul = 1; p.o_row_add = 0; p.o_col_add = 0; p.Wfull = Wout; p.planes = 0;
+    p.fa_x1 = fa_x1; p.fa_s = fa_s; p.fa_g1 = fa_g1; p.fa_g2 = fa_g2; p.fa_out = fa_out;
     return dispatch_fmt(p, fmt, wfrag_lo != nullptr, a16, o16, (hipStream_t)stream);
+}
+
+extern "C" int spei_conv_slab16(int fmt, const void* a0, int lda0, int k0, const void* a1, int lda1, int k1, int a_fmt,
+                                const void* wfrag_hi, const void* wfrag_lo, const float* bias, void* out, int ldo,
+                                int out_fmt, const float* residual, int ldr, const float* rowscale, int Hin, int Win,
+                                int Hout, int Wout, int N, int ksize, int stride, int pad, int act, int ln_input,
+                                spei_stream_t stream) {
+    return conv_slab16_run(fmt, a0, lda0, k0, a1, lda1, k1, a_fmt, wfrag_hi, wfrag_lo, bias, out, ldo, out_fmt, residual, ldr, rowscale, Hin,
+                           Win, Hout, Wout, N, ksize, stride, pad, act, ln_input, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int spei_conv_slab16_fa(int fmt, const float* x, int K, const void* x1, const float* s, const float* g1, const float* g2,
+                                   float* x_out, const void* wfrag, const float* bias, void* out, int ldo, int out_fmt, int H, int W, int N,
+                                   int ksize, int act, spei_stream_t stream) {
+    return conv_slab16_run(fmt, x, K, K, nullptr, 0, 0, SPEI_F32, wfrag, nullptr, bias, out, ldo, out_fmt, nullptr, 0, nullptr, H, W, H, W, N,
+                           ksize, 1, ksize / 2, act, 0, x1, s, g1, g2, x_out, stream);
 }
 
 extern "C" int spei_convt2_slab16(int fmt, const void* a0, int lda0, int k0, int a_fmt, const void* wfrag00, const void* wfrag01,
@@ -600,7 +669,7 @@ extern "C" int spei_convt2_slab16(int fmt, const void* a0, int lda0, int k0, int
     const void* wf[2][2] = {{wfrag00, wfrag01}, {wfrag10, wfrag11}};
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
-            SlabParams p;
+            SlabParams p = {};
             p.a0 = a0; p.a1 = nullptr; p.wh = wf[py][px]; p.wl = nullptr; p.bias = bias; p.out = out;
             p.res = nullptr; p.rowscale = nullptr;
             p.lda0 = lda0; p.lda1 = 0; p.k0 = k0; p.k1 = 0; p.ldo = ldo; p.ldr = 0;
@@ -630,7 +699,7 @@ extern "C" int spei_conv5_out_slab16(int fmt, const void* in, int ldi, int in_fm
     SPEI_REQUIRE(ldi >= 32 && ldi % (a16 ? 8 : 4) == 0 && ((uintptr_t)in | (uintptr_t)wfrag | (uintptr_t)out_chw) % 16 == 0,
                  "spei_conv5_out_slab16: alignment / stride");
     SPEI_REQUIRE((int64_t)H * W < (1ll << 30), "spei_conv5_out_slab16: map too large");
-    SlabParams p;
+    SlabParams p = {};
     p.a0 = in; p.a1 = nullptr; p.wh = wfrag; p.wl = nullptr; p.bias = bias32; p.out = out_chw;
     p.res = nullptr; p.rowscale = nullptr;
     p.lda0 = ldi; p.lda1 = 0; p.k0 = 32; p.k1 = 0; p.ldo = 1; p.ldr = 0;

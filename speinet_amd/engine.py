@@ -14,9 +14,10 @@ from .ops import ACT_GELU, ACT_RELU, CONV_T, Ctx, FMap
 # ---- encoder / decoder stacks (reference model/recons_video_ori.py:26-77) -----------------------------
 def _resblocks(ctx: Ctx, f: FMap, blocks, extra=None, out=None) -> FMap:
     n = len(blocks)
+    fuse = ctx.apply_fused_available(f.C)            # every block but the last hands its gated sum to the next block's first conv
     for i, pk in enumerate(blocks):
         last = i == n - 1
-        f = ctx.resblock(f, pk, extra=extra if last else None, out=out if last else None)
+        f = ctx.resblock(f, pk, extra=extra if last else None, out=out if last else None, defer=fuse and not last)
     return f
 
 

@@ -142,6 +142,9 @@ class Ctx:
                       133-142 us per block at 720p, and as a 1-workgroup-per-CU kernel it shuts out the other stream's
                       kernels: 32.9 vs 30.7 ms per frame) — kept as the base for cross-group prefetching, DESIGN.md §6
       commute_upconv  16-bit: relu(conv1x1(bicubic_up(x))) evaluated as relu(bicubic_up(conv1x1(x)))
+      fuse_apply      (default OFF) 16-bit: the gated residual sum of a ResBlock (all but the last of a stack) is computed inside the next
+                      block's first conv while that stages its input (spei_conv_slab16_fa) instead of by spei_resblock_apply.
+                      Bit-identical frames; measured no faster: 30.3 vs 30.15 ms per 720p frame
       corr_bf16       "f16" with corr "top2": the candidate pass of the correlation runs on bf16 operands (True, default) instead of
                       f16.  The fp32 re-score decides the winner and S either way (G14: 16 more of 57600 positions differ, dPSNR
                       +1e-6 dB); bf16 operands let the chip hold a ~7 % higher MFMA clock on this kernel (tools/bench_corr.py)
@@ -154,12 +157,13 @@ class Ctx:
     ACT_NONE, ACT_RELU, ACT_GELU = ACT_NONE, ACT_RELU, ACT_GELU
     CONV, CONV_T = CONV, CONV_T
     _FIELDS = ("precision", "corr_precision", "device", "use_slab", "bf16_storage", "x1_bf16", "fuse_mlp", "fuse_attn",
-               "fuse_block", "commute_upconv", "corr_bf16", "stage", "profile", "capture")
+               "fuse_block", "commute_upconv", "corr_bf16", "fuse_apply", "stage", "profile", "capture")
     __slots__ = _FIELDS
 
     def __init__(self, precision: str = "f32", corr_precision: str = "bf16x3", device=None, use_slab: bool = True,
                  bf16_storage: bool = True, x1_bf16: bool = True, fuse_mlp: bool = True, fuse_attn: bool = True,
-                 fuse_block: bool = False, commute_upconv: bool = True, corr_bf16: bool = True, stage: Optional[dict] = None,
+                 fuse_block: bool = False, commute_upconv: bool = True, corr_bf16: bool = True, fuse_apply: bool = False,
+                 stage: Optional[dict] = None,
                  profile: Optional[dict] = None, capture: Optional[dict] = None):
         if precision not in PRECISIONS:
             raise ValueError(f"unknown precision {precision!r}")
@@ -179,7 +183,7 @@ class Ctx:
         object.__setattr__(self, "device", device)
         for k, v in (("use_slab", use_slab), ("bf16_storage", bf16_storage), ("x1_bf16", x1_bf16), ("fuse_mlp", fuse_mlp),
                      ("fuse_attn", fuse_attn), ("fuse_block", fuse_block), ("commute_upconv", commute_upconv),
-                     ("corr_bf16", corr_bf16)):
+                     ("corr_bf16", corr_bf16), ("fuse_apply", fuse_apply)):
             object.__setattr__(self, k, bool(v))
         object.__setattr__(self, "stage", dict(stage) if stage else {})
         object.__setattr__(self, "profile", profile)
@@ -354,14 +358,36 @@ class Ctx:
                                            tp(s), tp(g1), tp(g2), tp(ws), self._stream()), "spei_resblock_gates")
         return s, g1, g2
 
-    def resblock(self, x: FMap, pk: dict, extra: Optional[FMap] = None, out: Optional[FMap] = None) -> FMap:
-        """x + SE(x1) + TE(x1), x1 = conv5(relu(conv5(x)))  (reference model/block.py:127-140)."""
-        c = x.C
-        assert x.off == 0 and x.ld == c
+    def apply_fused_available(self, c: int) -> bool:
+        """The gated residual sum of a ResBlock can ride in the NEXT block's first conv (spei_conv_slab16_fa): 16-bit modes on the
+        slab kernel with a 16-bit x1."""
+        return self.lp16 and self.use_slab and self.x1_bf16 and self.fuse_apply and c in (32, 64, 128, 256)
+
+    def resblock(self, x, pk: dict, extra: Optional[FMap] = None, out: Optional[FMap] = None, defer: bool = False):
+        """x + SE(x1) + TE(x1), x1 = conv5(relu(conv5(x)))  (reference model/block.py:127-140).
+
+        `x` is a map, or the deferred tail of the previous block — a tuple (x, x1, s, g1, g2): then this block's first conv computes
+        that block's output while it stages its input (one kernel fewer, one fp32 map round trip fewer) and writes it back as the
+        residual stream.  `defer=True` returns this block's own tail instead of applying it (the caller passes it to the next)."""
         idt = self.inter_dtype()
-        t = self.igemm(x, pk["w1"], pk["b1"], c, ksize=5, act=ACT_RELU, out_dtype=idt)   # only conv2 reads it
+        if isinstance(x, tuple):
+            px, px1, ps, pg1, pg2 = x
+            c = px.C
+            xn = FMap.empty(px.H, px.W, c, px.t.device)
+            t = FMap.empty(px.H, px.W, c, px.t.device, idt)
+            w1 = pk["w1"] if not torch.is_tensor(pk["w1"]) else PackedW(pk["w1"], px.t.device)
+            _lib.check(_lib.lib().spei_conv_slab16_fa(self.fmt, self._fp(px), c, self._fp(px1), self._tp(ps), self._tp(pg1), self._tp(pg2),
+                                                      self._fp(xn), self._tp(w1.frag(self.fmt)), self._tp(pk["b1"]), self._fp(t), t.ld, t.fmt,
+                                                      px.H, px.W, c, 5, ACT_RELU, self._stream()), "spei_conv_slab16_fa")
+            x = xn
+        else:
+            c = x.C
+            assert x.off == 0 and x.ld == c
+            t = self.igemm(x, pk["w1"], pk["b1"], c, ksize=5, act=ACT_RELU, out_dtype=idt)   # only conv2 reads it
         x1 = self.igemm(t, pk["w2"], pk["b2"], c, ksize=5, out_dtype=idt if self.x1_bf16 else torch.float32)
         s, g1, g2 = self.resblock_gates(x1, pk)
+        if defer:
+            return (x, x1, s, g1, g2)
         if out is None:
             out = FMap.empty(x.H, x.W, c, x.t.device)
         if extra is not None:

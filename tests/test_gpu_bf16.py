@@ -564,3 +564,18 @@ def test_two_models_two_threads_bit_identical(synth_sd):
         for o in results[i]:
             assert torch.equal(o, serial[i]), f"model {i} differs when run concurrently"
     assert not torch.equal(serial[0], serial[1])          # the two modes really are different arithmetic
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_fused_apply_matches_separate_apply(synth_sd, mode):
+    """The opt-in `fuse_apply` path (a ResBlock's gated residual sum computed inside the next block's first conv,
+    spei_conv_slab16_fa) gives bit-identical maps to the default path (spei_resblock_apply + spei_conv_slab16): stacks of three
+    ResBlocks at ragged sizes for the three channel counts, incl. tiles cut by the map border."""
+    from speinet_amd import engine
+    gen = torch.Generator().manual_seed(17)
+    for prefix, h, w, c in (("recons_net.inBlock.", 44, 70, 32), ("recons_net.encoder_first.", 37, 33, 64), ("recons_net.encoder_second.", 20, 45, 128)):
+        blocks = [pack._to_device(pack.resblock(synth_sd, f"{prefix}{i}."), DEV) for i in (1, 2, 3)]
+        x = FMap(torch.randn(h * w, c, generator=gen).to(DEV), h, w, c)
+        a = engine._resblocks(Ctx(mode, device=DEV, fuse_apply=True), x, blocks)
+        b = engine._resblocks(Ctx(mode, device=DEV, fuse_apply=False), x, blocks)
+        assert torch.equal(a.t, b.t), (prefix, h, w, (a.t - b.t).abs().max().item())
