@@ -272,13 +272,10 @@ class Inference:
 
                 inflight = collections.deque()                  # one event per enqueued window
                 t_loop = time.time()
-                for k, (w, gseq) in enumerate(zip(wins, gt_seqs)):
-                    # keep the host at most two windows ahead of the GPU: enough slack to hide its own work, and a worker that
-                    # fetches a finished frame waits ~2 windows, not the whole queue (the post pool would otherwise spend its
-                    # time blocked on results instead of encoding PNGs)
-                    if len(inflight) >= 2:
-                        inflight.popleft().synchronize()
+                def prepare(k):
+                    """Inputs of window k on the device: (x, keys, gt, nh, nw, window, seconds spent)."""
                     t0 = time.time()
+                    w = wins[k]
                     for ahead in needs[k:k + 1 + self.prefetch]:
                         cache.request(ahead)
                     imgs = [cache.get_dev(p) for p in needs[k]]            # uint8 [H,W,3] on the device, uploaded once per file
@@ -291,10 +288,26 @@ class Inference:
                     if w["zero_sub"]:
                         imgs[-1] = torch.zeros_like(imgs[-1])
                     x = selection.uint8_frames_to_input(imgs)
+                    keys = list(needs[k][:self.n_seq]) + [("zero", nh, nw) if w["zero_pre"] else w["pre"],
+                                                          ("zero", nh, nw) if w["zero_sub"] else w["sub"]]
+                    return x, keys, gt, nh, nw, w, time.time() - t0
+
+                nxt = prepare(0) if wins else None
+                for k in range(len(wins)):
+                    # keep the host at most two windows ahead of the GPU: enough slack to hide its own work, and a worker that
+                    # fetches a finished frame waits ~2 windows, not the whole queue (the post pool would otherwise spend its
+                    # time blocked on results instead of encoding PNGs)
+                    if len(inflight) >= 2:
+                        inflight.popleft().synchronize()
+                    x, keys, gt, nh, nw, w, t_prep = nxt
+                    t0 = time.time()
+                    # one window of lookahead: the NEXT window's inputs go to the device and its missing encoder passes start on the
+                    # model's prefetch stream before this window's fuse-and-decode graph is queued, so they run underneath it
+                    nxt = prepare(k + 1) if k + 1 < len(wins) else None
                     t1 = time.time()
+                    if a.reuse and nxt is not None:
+                        self.net.prefetch_window(nxt[0], nxt[1], enc_cache, zero_ref=bool(nxt[5]["zero_pre"]))
                     if a.reuse:
-                        keys = list(needs[k][:self.n_seq]) + [("zero", nh, nw) if w["zero_pre"] else w["pre"],
-                                                              ("zero", nh, nw) if w["zero_sub"] else w["sub"]]
                         out = self.net.forward_window(x, keys, enc_cache, zero_ref=bool(w["zero_pre"]))
                     else:
                         out = self.net(x, routing=[bool(w["zero_pre"])])
@@ -311,7 +324,7 @@ class Inference:
                     t2 = time.time()
                     save_to = os.path.join(a.result_path, clip, w["name"] + ".png") if a.save_image else ""
                     slot["fut"] = self.post_pool.submit(self._post, slot, ev, save_to)
-                    pending.append((w["name"], slot["fut"], t1 - t0, t2 - t1, t0))
+                    pending.append((w["name"], slot["fut"], t_prep, t2 - t1, t0))        # pre_time = this window's own input preparation
                     flush(block=len(pending) > 2 * self.prefetch)
                 t_drain = time.time()
                 flush(block=True)

@@ -329,7 +329,22 @@ class SPEINet(nn.Module):
         with torch.cuda.device(x.device):
             return self._forward_window(x, keys, cache, zero_ref)
 
-    def _forward_window(self, x, keys, cache, zero_ref):
+    def _prefetch_stream(self, device) -> "torch.cuda.Stream":
+        key = ("prefetch", torch.device(device).index)
+        if key not in self._side_streams:
+            self._side_streams[key] = torch.cuda.Stream(device=device)
+        return self._side_streams[key]
+
+    def prefetch_window(self, x: torch.Tensor, keys: Sequence, cache: "EncoderCache", zero_ref: bool) -> None:
+        """Start the encoder passes a later `forward_window(x, keys, cache, zero_ref)` will need, on the prefetch stream: called for
+        window k+1 BEFORE `forward_window` of window k, they run under window k's fuse-and-decode graph (same kernels, same operands:
+        the frames do not change)."""
+        self._check_input(x, batch1=True)
+        _lib.lib()
+        with torch.cuda.device(x.device):
+            self._forward_window(x, keys, cache, zero_ref, pieces_only=True)
+
+    def _forward_window(self, x, keys, cache, zero_ref, pieces_only: bool = False):
         h, w = x.shape[-2:]
         ctx = self._ctx(x.device)
         x = x.contiguous().float()
@@ -351,12 +366,27 @@ class SPEINet(nn.Module):
             return cache.get(k) or cache.put(
                 k, G(("sum", iters, h, w), [x[0, i], raw(i)], lambda fr, e: [engine.encode_sum(ctx, fr, iters, e, P)])[0])
 
-        f_mid = summed(mid, 5)
-        feats = [summed(i, 1) for i in range(n) if i != mid]
-        lv = None
-        if not zero_ref:
-            k = (tag, keys[n + 1], "ref")
-            lv = cache.get(k) or cache.put(k, tuple(G(("pyr", h, w), [x[0, n + 1]], lambda fr: list(engine.reference_pyramid(ctx, fr, P)))))
+        # The pieces run on a stream of their own (always the same one: their captured graphs share static buffers).  A caller that
+        # knows the next window (`prefetch_window`) gets that window's encoder passes under the CURRENT window's fuse-and-decode
+        # graph; without a prefetch the main stream simply waits for them here.
+        main = torch.cuda.current_stream(x.device)
+        pf = self._prefetch_stream(x.device)
+        pf.wait_stream(main)                         # x is ready
+        x.record_stream(pf)
+        with torch.cuda.stream(pf):
+            f_mid = summed(mid, 5)
+            feats = [summed(i, 1) for i in range(n) if i != mid]
+            lv = None
+            if not zero_ref:
+                k = (tag, keys[n + 1], "ref")
+                lv = cache.get(k) or cache.put(k, tuple(G(("pyr", h, w), [x[0, n + 1]], lambda fr: list(engine.reference_pyramid(ctx, fr, P)))))
+            ready = torch.cuda.Event()
+            ready.record(pf)
+        for f in [f_mid] + feats + list(lv or ()):   # produced on `pf`, consumed (and possibly freed by the cache) under `main`
+            f.t.record_stream(main)
+        if pieces_only:
+            return None
+        main.wait_event(ready)
         out = torch.empty(1, 3, h, w, device=x.device, dtype=torch.float32)
         if not self.use_graph:
             engine.fuse_and_decode(ctx, f_mid, feats, lv, P, n, out[0], sides)
