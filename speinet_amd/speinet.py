@@ -429,6 +429,7 @@ class SPEINet(nn.Module):
 
     def _trim_graphs(self, limit: int = 12) -> None:
         if len(self._graphs) >= limit:
+            torch.cuda.synchronize()           # a replay of one of them may still be running (other stream, earlier window)
             self._graphs.clear()
 
     def _graphed(self, name: tuple, inputs: list, fn) -> list:
