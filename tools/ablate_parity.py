@@ -60,7 +60,7 @@ CONFIGS = [
     ("f16 top2, unfused attention", "f16", "top2", {"fuse_attn": False}),
     ("f16 top2, conv after upsample", "f16", "top2", {"commute_upconv": False}),
     ("f16 top2, f16 correlation candidates", "f16", "top2", {"corr_bf16": False}),
-    ("f16 top2, separate ResBlock apply kernels", "f16", "top2", {"fuse_apply": False}),
+    ("f16 top2, ResBlock apply fused into the next conv1 (opt-in)", "f16", "top2", {"fuse_apply": True}),
     ("f16, search stage bf16x3", "f16", "top2", {"stage": {"search": {"precision": "bf16x3", "corr_precision": "bf16x3"}}}),
     ("f16, decode stage bf16x3", "f16", "top2", {"stage": {"decode": {"precision": "bf16x3"}}}),
     ("f16, swin stage bf16x3", "f16", "top2", {"stage": {"swin": {"precision": "bf16x3"}}}),
