@@ -419,7 +419,8 @@ static int corr_slab_run(const void* lr_hi, const void* lr_lo, const void* ref_h
     SPEI_REQUIRE(((uintptr_t)lr_hi | (uintptr_t)ref_hi | (uintptr_t)lr_lo | (uintptr_t)ref_lo) % 16 == 0, "%s: 16-byte alignment required", who);
     const bool split = lr_lo != nullptr;
     SPEI_REQUIRE(!(split && (top2 || !__is_same(LP, __bf16))), "%s: the split (bf16x3) form is bf16, top-1", who);
-    const int NI = split ? 2 : 4;
+    static const int ni_knob = spei_knob("SPEI_CORR_NI", 4);          // tuning build: 2 = one query tile per wave
+    const int NI = split ? 2 : (top2 && ni_knob == 2 ? 2 : 4);
     CorrSlabParams<LP> p;
     p.lrh = (const LP*)lr_hi; p.lrl = (const LP*)lr_lo; p.refh = (const LP*)ref_hi; p.refl = (const LP*)ref_lo;
     p.inv_lr = inv_lr; p.inv_ref = inv_ref;
@@ -447,7 +448,8 @@ static int corr_slab_run(const void* lr_hi, const void* lr_lo, const void* ref_h
         if (split) launch_corr<LP, 2, 32, true, 2>(p, itiles, splits, st);
     }
     if (!split) {
-        if (top2) launch_corr<LP, 4, 64, false, 4, true>(p, itiles, splits, st);
+        if (top2 && NI == 2) launch_corr<LP, 2, 64, false, 4, true>(p, itiles, splits, st);
+        else if (top2) launch_corr<LP, 4, 64, false, 4, true>(p, itiles, splits, st);
         else launch_corr<LP, 4, 64, false, 4>(p, itiles, splits, st);
     }
     if (top2)
