@@ -226,6 +226,7 @@ class SPEINet(nn.Module):
         self.streams = int(os.environ.get("SPEINET_STREAMS", "1"))        # HIP streams for the independent frame branches
         self.knobs = {}              # extra ops.Ctx fields (parity ablations, tools/ablate_parity.py)
         self._graphs = {}
+        self._graph_devices = set()  # devices that hold captured graphs (synchronised before the graphs are dropped)
         self._side_streams = {}      # (device index, n) -> side streams, owned by this model
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed())
 
@@ -233,9 +234,17 @@ class SPEINet(nn.Module):
     def invalidate_packed(self) -> None:
         """Drop the packed weights and captured graphs.  Called automatically after `load_state_dict` and after
         `.to()` / `.cuda()` / `.float()` (`_apply`); call it yourself after editing parameters in place
-        (`p.data.mul_()`, an optimizer step): in-place edits are invisible to the module."""
+        (`p.data.mul_()`, an optimizer step): in-place edits are invisible to the module.
+
+        A replay of one of the graphs, or an eager launch on the prefetch / side streams, may still be reading the packed weights
+        and the graphs' static buffers by raw pointer (they were allocated on the main stream, the caching allocator would hand
+        them to the next main-stream allocation): every device that holds any is synchronised before they are dropped."""
+        if self._packed or self._graphs:
+            for key in {str(k) for k in self._packed} | {str(d) for d in self._graph_devices}:
+                torch.cuda.synchronize(torch.device(key))
         self._packed = {}
         self._graphs = {}
+        self._graph_devices = set()
         self._generation += 1
 
     def _apply(self, fn, *a, **k):
@@ -293,13 +302,13 @@ class SPEINet(nn.Module):
         CPU generator in the reference's order when not given.
         """
         self._check_input(x)
-        if self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+        if _wants_autograd(self, x):
             # the differentiable fp32 graph (HIP forward AND backward kernels, speinet_amd/train.py): train() mode runs the gates'
             # BatchNorm(1) on batch statistics and DropPath, as the reference module does under
-            # trainer/trainer_swint_hsa_nsf.py:27-40; eval() with autograd recording is the same graph with running statistics
+            # trainer/trainer_swint_hsa_nsf.py:27-40; eval() with `autograd = True` (or an input that requires grad) is the same
+            # graph with running statistics.  An optimizer step may follow either way: the packed inference weights are stale.
             from . import train
-            if self.training:
-                self.invalidate_packed()      # an optimizer step follows: the packed inference weights are stale from here on
+            self.invalidate_packed()
             return train.forward_speinet(self, x, scales=drop_path_scales)
         _lib.lib()
         h, w = x.shape[-2:]
@@ -357,36 +366,47 @@ class SPEINet(nn.Module):
         # frame then costs three replays instead of ~150 launches from Python (the harness was host-bound on them)
         G = self._graphed if self.use_graph else (lambda name, ins, fn: fn(*ins))
 
-        def raw(i):
-            return cache.get((tag, keys[i], "raw")) or cache.put(
-                (tag, keys[i], "raw"), G(("raw", h, w), [x[0, i]], lambda fr: [engine.encode_raw(ctx, fr, P)])[0])
-
-        def summed(i, iters):
-            k = (tag, keys[i], iters)
-            return cache.get(k) or cache.put(
-                k, G(("sum", iters, h, w), [x[0, i], raw(i)], lambda fr, e: [engine.encode_sum(ctx, fr, iters, e, P)])[0])
-
         # The pieces run on a stream of their own (always the same one: their captured graphs share static buffers).  A caller that
-        # knows the next window (`prefetch_window`) gets that window's encoder passes under the CURRENT window's fuse-and-decode
-        # graph; without a prefetch the main stream simply waits for them here.
+        # knows the next window (`prefetch_window`) gets that window's encoder passes UNDER the current window's fuse-and-decode
+        # graph: every cache entry carries the event recorded on the prefetch stream when it was produced, and the main stream waits
+        # for the events of the entries THIS window consumes only — not for the prefetch stream's tail, which by then holds the next
+        # window's passes (round 2 waited for the tail: fuse(k-1), enc(k+1), fuse(k) ran strictly in turn).
         main = torch.cuda.current_stream(x.device)
         pf = self._prefetch_stream(x.device)
-        pf.wait_stream(main)                         # x is ready
+        pf.wait_stream(main)                         # x is ready (the caller assembled it on the main stream)
         x.record_stream(pf)
+        used = []                                    # (value, event) of every cache entry this window reads
+
+        def piece(key, make):
+            hit = cache.get(key)
+            if hit is None:
+                v = make()
+                ev = torch.cuda.Event()
+                ev.record(pf)
+                hit = cache.put(key, (v, ev))
+            used.append(hit)
+            return hit[0]
+
+        def raw(i):
+            return piece((tag, keys[i], "raw"), lambda: G(("raw", h, w), [x[0, i]], lambda fr: [engine.encode_raw(ctx, fr, P)])[0])
+
+        def summed(i, iters):
+            return piece((tag, keys[i], iters),
+                         lambda: G(("sum", iters, h, w), [x[0, i], raw(i)], lambda fr, e: [engine.encode_sum(ctx, fr, iters, e, P)])[0])
+
         with torch.cuda.stream(pf):
             f_mid = summed(mid, 5)
             feats = [summed(i, 1) for i in range(n) if i != mid]
             lv = None
             if not zero_ref:
-                k = (tag, keys[n + 1], "ref")
-                lv = cache.get(k) or cache.put(k, tuple(G(("pyr", h, w), [x[0, n + 1]], lambda fr: list(engine.reference_pyramid(ctx, fr, P)))))
-            ready = torch.cuda.Event()
-            ready.record(pf)
+                lv = piece((tag, keys[n + 1], "ref"),
+                           lambda: tuple(G(("pyr", h, w), [x[0, n + 1]], lambda fr: list(engine.reference_pyramid(ctx, fr, P)))))
         for f in [f_mid] + feats + list(lv or ()):   # produced on `pf`, consumed (and possibly freed by the cache) under `main`
             f.t.record_stream(main)
         if pieces_only:
             return None
-        main.wait_event(ready)
+        for _, ev in used:
+            main.wait_event(ev)
         out = torch.empty(1, 3, h, w, device=x.device, dtype=torch.float32)
         if not self.use_graph:
             engine.fuse_and_decode(ctx, f_mid, feats, lv, P, n, out[0], sides)
@@ -414,6 +434,7 @@ class SPEINet(nn.Module):
                 for _ in steps:
                     raise RuntimeError("fuse_and_decode_steps yielded twice")
             self._trim_graphs()
+            self._graph_devices.add(str(x.device))
             g = self._graphs[gkey] = ((g1, plan, g2), s_mid, s_feats, s_lv, s_out)
         (g1, plan, g2), s_mid, s_feats, s_lv, s_out = g
         s_mid.t.copy_(f_mid.t)
@@ -452,6 +473,7 @@ class SPEINet(nn.Module):
             with torch.cuda.graph(graph):
                 s_out = fn(*s_in)
             self._trim_graphs()
+            self._graph_devices.add(str(dev))
             g = self._graphs[key] = (graph, s_in, s_out)
         graph, s_in, s_out = g
         for d, v in zip(s_in, inputs):
@@ -492,6 +514,7 @@ class SPEINet(nn.Module):
                         raise RuntimeError("forward_sample_steps yielded twice")
                 segs.append((g1, plan, g2))
             self._trim_graphs()
+            self._graph_devices.add(str(x.device))
             g = self._graphs[key] = (segs, static_x, static_out)
         segs, static_x, static_out = g
         static_x.copy_(x)
@@ -500,6 +523,26 @@ class SPEINet(nn.Module):
             plan.launch(profile)
             g2.replay()
         return static_out.clone()
+
+
+def _wants_autograd(model: nn.Module, x: torch.Tensor) -> bool:
+    """Which graph a `forward` call builds.  train() mode: always the differentiable one (the reference trainer's step).  eval():
+    only when the caller asks for gradients — the input requires grad, or `model.autograd = True` — and autograd is recording;
+    a plain eval() call outside `torch.no_grad()` (the reference's trainers do evaluate under no_grad, trainer_swint_hsa_nsf.py:57)
+    stays on the inference path in the model's `precision`, with a one-time warning: saving every activation of a 720p frame for a
+    backward nobody asked for is what round 2 did there."""
+    if model.training:
+        return True
+    if not torch.is_grad_enabled():
+        return False
+    if x.requires_grad or getattr(model, "autograd", False):
+        return True
+    if any(p.requires_grad for p in model.parameters()) and not getattr(model, "_warned_eval_grad", False):
+        import warnings
+        model._warned_eval_grad = True
+        warnings.warn("speinet_amd: eval()-mode forward with autograd recording runs the INFERENCE kernels (no graph is built); "
+                      "set `model.autograd = True`, pass an input that requires grad, or call model.train() to differentiate")
+    return False
 
 
 class EncoderCache:

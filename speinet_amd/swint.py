@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, engine, ops, pack
-from .speinet import _Recons, _SwinIR, default_args
+from .speinet import _Recons, _SwinIR, _wants_autograd, default_args
 
 
 class SPEINet(nn.Module):
@@ -60,7 +60,10 @@ class SPEINet(nn.Module):
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed())
 
     def invalidate_packed(self) -> None:
-        """Drop the packed weights (automatic after load_state_dict / .to(); call it after in-place parameter edits)."""
+        """Drop the packed weights (automatic after load_state_dict / .to(); call it after in-place parameter edits).  Launches on the
+        side streams may still be reading them by raw pointer: the devices that hold any are synchronised first."""
+        for key in list(self._packed):
+            torch.cuda.synchronize(torch.device(key))
         self._packed = {}
 
     def _apply(self, fn, *a, **k):
@@ -83,13 +86,13 @@ class SPEINet(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("speinet_amd.swint runs on MI355X only (HIP kernels); there is no CPU path")
         _lib.lib()
-        if self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+        if _wants_autograd(self, x):
             # the differentiable graph (fp32, HIP forward and backward kernels): train() mode runs BatchNorm(1) on batch
-            # statistics and DropPath, as the reference module does under trainer/trainer_swint.py:27,39; eval() with grad enabled
-            # is the same graph with running statistics and no DropPath
+            # statistics and DropPath, as the reference module does under trainer/trainer_swint.py:27,39; eval() with
+            # `autograd = True` (or an input that requires grad) is the same graph with running statistics and no DropPath.
+            # An optimizer step may follow either way: the packed inference weights are stale from here on
             from . import train
-            if self.training:
-                self.invalidate_packed()      # an optimizer step follows: the packed inference weights are stale from here on
+            self.invalidate_packed()
             return train.forward_swint(self, x, scales=drop_path_scales)
         with torch.cuda.device(x.device):
             ctx = ops.Ctx(self.precision, "top2", device=x.device, profile=profile, **self.knobs)

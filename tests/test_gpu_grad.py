@@ -1,5 +1,5 @@
 """Training step, first slice: HIP forward + backward of the recons_net encoder stack through
-speinet_amd.autograd, against (a) torch.autograd of the same op in fp64 on the CPU, per op, and (b) the REFERENCE's own
+speinet_amd.train (the one set of autograd Functions the product ships), against (a) torch.autograd of the same op in fp64 on the CPU, per op, and (b) the REFERENCE's own
 gradients (tests/golden/make_golden_grad.py, G19: its modules, its autograd) for every parameter of inBlock /
 encoder_first / encoder_second.  Tolerances are fp32 round-off of re-ordered sums relative to the gradient's norm."""
 import os
@@ -11,7 +11,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from speinet_amd import autograd as A                    # noqa: E402
+from speinet_amd import train as T                       # noqa: E402
 from speinet_amd.speinet import SPEINet, default_args    # noqa: E402
 from speinet_amd.synth import synth_frames               # noqa: E402
 
@@ -42,7 +42,7 @@ def test_conv_forward_backward(cin, cout, k, stride, h, w, relu):
     y.backward(g.double())
     xg = rows(x).to(DEV).requires_grad_(True)
     wg, bg = wt.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
-    out = A._Conv.apply(xg, wg, bg, h, w, k, stride, relu)
+    out = T._Conv2d.apply(xg, wg, bg, None, 1, h, w, k, stride, relu)
     assert rel(out, rows(y.detach().float())) < 1e-5
     out.backward(rows(g).to(DEV))
     assert rel(xg.grad, rows(xd.grad.float())) < 2e-5, "data gradient"
@@ -57,7 +57,7 @@ def test_conv_in_backward():
     g = rnd(7, *y.shape)
     y.backward(g.double())
     wg, bg = wt.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
-    out = A._ConvIn.apply(x.to(DEV), wg, bg)
+    out = T._ConvIn.apply(x.to(DEV)[None], wg, bg)
     assert rel(out, rows(y.detach().float())) < 1e-5
     out.backward(rows(g).to(DEV))
     assert rel(wg.grad, wd.grad.float()) < 2e-5 and rel(bg.grad, bd.grad.float()) < 2e-5
@@ -90,7 +90,7 @@ def test_resblock_backward_vs_torch(synth_sd, c, h, w):
     out_ref.backward(g.double())
     # HIP
     xg = rows(x).to(DEV).requires_grad_(True)
-    out = A.resblock_train(xg, blk, h, w)
+    out = T.resblock(xg, blk, 1, h, w, False)       # eval-mode gates: BatchNorm(1) on its running statistics
     assert rel(out, rows(out_ref.detach().float())) < 1e-5
     out.backward(rows(g).to(DEV))
     assert rel(xg.grad, rows(xd.grad.float())) < 5e-5, "data gradient"
@@ -113,7 +113,7 @@ def test_encoder_gradients_vs_reference(golden_dir, synth_sd, name, h, w):
 
     def run():
         net.zero_grad()
-        lv1, lv2, lv3 = A.encoder_train(x, net.recons_net)
+        lv1, lv2, lv3 = T.encoder(x[None], net.recons_net, False, pyramid=True)
         g = torch.Generator().manual_seed(seed + 1000)
         r1, r2, r3 = (torch.randn(*s, generator=g) for s in ((1, 32, h, w), (1, 64, h // 2, w // 2), (1, 128, h // 4, w // 4)))
         loss = (lv3 * rows(r3).to(DEV)).sum() + 0.5 * (lv2 * rows(r2).to(DEV)).sum() + 0.25 * (lv1 * rows(r1).to(DEV)).sum()

@@ -437,8 +437,14 @@ def test_trainer_steps_reduce_the_loss():
     net.precision = "f32"
     with torch.no_grad():
         ev = net(x)
+    net.autograd = True                            # opt in: eval() + recording alone stays on the inference kernels
     ev2 = net(x)                                   # the differentiable graph reads the live parameters
+    assert ev2.requires_grad
     assert (ev - ev2.detach()).abs().max().item() < 2e-5
+    net.autograd = False
+    with pytest.warns(UserWarning, match="INFERENCE kernels"):
+        ev3 = net(x)                               # autograd recording, nobody asked for a graph: inference path, one warning
+    assert not ev3.requires_grad and torch.equal(ev3, ev)
 
 
 @pytest.mark.parametrize("which", ["swint", "speinet"])
@@ -463,7 +469,8 @@ def test_training_graph_matches_inference_path_at_crop_size(which):
     net.precision = "f32"
     with torch.no_grad():
         ref = net(x)
-    out = net(x)                                    # autograd recording -> the differentiable graph, eval-mode semantics
+    net.autograd = True                             # eval() + opt-in -> the differentiable graph, eval-mode semantics
+    out = net(x)
     assert out.requires_grad
     err = (out.detach() - ref).abs().max().item()
     print(f"{which}: max |training-graph output - inference output| at 200x200: {err:.2e} (values up to {ref.abs().max().item():.2f})")
