@@ -229,6 +229,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying hipGraph segments")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams for the independent neighbour-frame / reference branches of a frame")
     ap.add_argument("--branch", choices=["bs", "b"], default="bs", help="bs: with sharp reference (SearchTransfer); b: SelfTransfer")
+    ap.add_argument("--knobs", default="", help='experiments: JSON of extra speinet_amd.ops.Ctx fields, e.g. \'{"stage": {"glue": {"precision": "bf16x3"}}}\'')
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
     args = ap.parse_args()
@@ -261,6 +262,8 @@ def main():
     net.precision, net.corr_precision = args.precision, args.corr_precision
     net.use_graph = not args.no_graph
     net.streams = args.streams
+    if args.knobs:
+        net.knobs = json.loads(args.knobs)
     # each rank deblurs its own frames (clip shard = rank); two distinct windows alternate so nothing is cached
     frames = [synth_frames(1, h, w, seed=1234 + 17 * rank + i, zero_ref=(0,) if args.branch == "b" else ()).to(dev) for i in range(2)]
     routing = [args.branch == "b"]

@@ -116,6 +116,15 @@ int spei_conv_slab16_fa(int fmt, const float* x, int K, const void* x1, const fl
 int spei_mlp_fused16(int fmt, const float* x, float* out, const void* w1_frag, const float* b1, const void* w2_frag,
                      const float* b2, int64_t M, spei_stream_t stream);
 
+/* The same MLP branch, token-stationary (round 3, csrc/swin_tok16.hip): a wave keeps its 32 tokens in registers from the
+ * LayerNorm to the residual store, every GEMM is computed transposed with the weights as the A operand out of a 4-slot LDS ring
+ * that a 512-thread workgroup fills by LDS-DMA once per 256 tokens.  wstream: the block's fc1 / fc2 weights as ONE linear
+ * stream of 1 KiB MFMA fragments in consumption order (speinet_amd/pack.py MlpStreamW: 16 chunks of [fc1 tile c: 16 k-steps |
+ * fc2 n-tiles 0..7 x k-steps 2c, 2c+1], fc2's input channels in the order an accumulator tile presents them as an operand).
+ * x, out: [M][256] fp32, may alias. */
+int spei_mlp_tok16(int fmt, const float* x, float* out, const void* wstream, const float* b1, const float* b2, int64_t M,
+                   spei_stream_t stream);
+
 /* ConvTranspose2d(k = 3, stride 2, padding 1, output_padding 1) on the slab kernel (reference model/recons_video_ori.py:58-71,
  * the tails of decoder_second / decoder_first): the four output-parity classes are stride-1 convolutions over the input
  * grid with 1 / 2 / 2 / 4 taps, written with pixel stride 2.  wfrag<py><px>: fragment-ordered 16-bit weights of class

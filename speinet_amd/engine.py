@@ -164,26 +164,27 @@ def self_transfer(ctx: Ctx, f_fusion: FMap, P: dict):
 # ---- decode (reference model/speinet.py:92-120) -----------------------------------------------------------
 def decode(ctx: Ctx, ff: FMap, s: torch.Tensor, t3: FMap, t2: FMap, t1: FMap, P: dict, out: torch.Tensor) -> torch.Tensor:
     ctx = ctx.for_stage("decode")
+    g = ctx.for_stage("glue")        # the 1x1 / 3x3 convs between the stacks (conv_lv*, search*): 1 % of the frame's FLOPs
     c = lambda name: (P[name]["w"], P[name]["b"])
     h3, w3 = ff.H, ff.W
     smap = FMap(s.view(h3 * w3, 1), h3, w3, 1)
-    f_lv3 = ctx.igemm(ff, *c("conv_lv3"), 128, a1=t3, rowscale=s, residual=ff)
-    dec2 = dec_stage(ctx, f_lv3, P["decoder_second"])
+    f_lv3 = g.igemm(ff, *c("conv_lv3"), 128, a1=t3, rowscale=s, residual=ff)
+    dec2 = dec_stage(ctx.for_stage("dec2"), f_lv3, P["decoder_second"])
     s2 = ctx.upsample(smap, 2).t.view(-1)
-    f_lv2 = ctx.igemm(dec2, *c("conv_lv2"), 64, a1=t2, rowscale=s2, residual=dec2)
-    s1 = ctx.up_conv1x1_relu(f_lv3, *c("search1"), 64)
-    sr2 = ctx.igemm(f_lv2, *c("search3"), 64, ksize=3, act=ACT_RELU)
-    f_v3 = ctx.igemm(dec2, *c("search2"), 64, a1=s1, act=ACT_RELU, residual=dec2)
-    f_lv2 = ctx.igemm(f_lv2, *c("search2"), 64, a1=sr2, act=ACT_RELU, residual=f_lv2)
-    dec1 = dec_stage(ctx, f_lv2, P["decoder_first"])
+    f_lv2 = g.igemm(dec2, *c("conv_lv2"), 64, a1=t2, rowscale=s2, residual=dec2)
+    s1 = g.up_conv1x1_relu(f_lv3, *c("search1"), 64)
+    sr2 = g.igemm(f_lv2, *c("search3"), 64, ksize=3, act=ACT_RELU)
+    f_v3 = g.igemm(dec2, *c("search2"), 64, a1=s1, act=ACT_RELU, residual=dec2)
+    f_lv2 = g.igemm(f_lv2, *c("search2"), 64, a1=sr2, act=ACT_RELU, residual=f_lv2)
+    dec1 = dec_stage(ctx.for_stage("dec1"), f_lv2, P["decoder_first"])
     s4 = ctx.upsample(smap, 4).t.view(-1)
-    f_lv1 = ctx.igemm(dec1, *c("conv_lv1"), 32, a1=t1, rowscale=s4, residual=dec1)
-    s13 = ctx.up_conv1x1_relu(f_v3, *c("search13"), 32)
-    s23 = ctx.igemm(ctx.upsample(f_lv2, 2), *c("search33"), 32, ksize=3, act=ACT_RELU)
-    s33 = ctx.igemm(f_lv1, *c("search43"), 32, ksize=3, act=ACT_RELU)
-    acc = ctx.igemm(s13, *c("search33"), 32, ksize=3, a1=s23, act=ACT_RELU, residual=f_lv1)
-    ctx.igemm(s13, *c("search33"), 32, ksize=3, a1=s33, act=ACT_RELU, residual=acc, out=acc)
-    ctx.igemm(s23, *c("search33"), 32, ksize=3, a1=s33, act=ACT_RELU, residual=acc, out=acc)
+    f_lv1 = g.igemm(dec1, *c("conv_lv1"), 32, a1=t1, rowscale=s4, residual=dec1)
+    s13 = g.up_conv1x1_relu(f_v3, *c("search13"), 32)
+    s23 = g.igemm(ctx.upsample(f_lv2, 2), *c("search33"), 32, ksize=3, act=ACT_RELU)
+    s33 = g.igemm(f_lv1, *c("search43"), 32, ksize=3, act=ACT_RELU)
+    acc = g.igemm(s13, *c("search33"), 32, ksize=3, a1=s23, act=ACT_RELU, residual=f_lv1)
+    g.igemm(s13, *c("search33"), 32, ksize=3, a1=s33, act=ACT_RELU, residual=acc, out=acc)
+    g.igemm(s23, *c("search33"), 32, ksize=3, a1=s33, act=ACT_RELU, residual=acc, out=acc)
     ob = P["outBlock"]
     ctx = ctx.for_stage("out")
     f = _resblocks(ctx, acc, ob["blocks"])

@@ -142,14 +142,21 @@ class Ctx:
                       133-142 us per block at 720p, and as a 1-workgroup-per-CU kernel it shuts out the other stream's
                       kernels: 32.9 vs 30.7 ms per frame) — kept as the base for cross-group prefetching, DESIGN.md §6
       commute_upconv  16-bit: relu(conv1x1(bicubic_up(x))) evaluated as relu(bicubic_up(conv1x1(x)))
+      commute_any     (default OFF) the same in every arithmetic mode: set by stage overrides that run single layers of a 16-bit
+                      frame in split arithmetic (the f32-grade MODES keep the reference's order of operations)
       fuse_apply      (default OFF) 16-bit: the gated residual sum of a ResBlock (all but the last of a stack) is computed inside the next
                       block's first conv while that stages its input (spei_conv_slab16_fa) instead of by spei_resblock_apply.
                       Bit-identical frames; measured no faster: 30.3 vs 30.15 ms per 720p frame
+      split_decode    "f16": decoder_second (3 ResBlocks at H/4, 128 channels) and the 1x1 / 3x3 glue convolutions of `_decode`
+                      (conv_lv*, search*: model/speinet.py:92-119) run in split arithmetic (bf16x3, f32-grade).  They are 2.4 % of the
+                      frame's FLOPs and where the half-operand error weighs most on the `_forwardb` branch: |dPSNR| against the
+                      reference on that branch 0.9-1.07e-3 dB -> 1.4-4.6e-4 (every golden <= 4.6e-4; profiles/r03_parity_ablation.txt),
+                      for 1.35 ms of a 30.3 ms frame.  Off: round 2's arithmetic (tests then hold 1e-3 dB with no margin on that branch)
       corr_bf16       "f16" with corr "top2": the candidate pass of the correlation runs on bf16 operands (True, default) instead of
                       f16.  The fp32 re-score decides the winner and S either way (G14: 16 more of 57600 positions differ, dPSNR
                       +1e-6 dB); bf16 operands let the chip hold a ~7 % higher MFMA clock on this kernel (tools/bench_corr.py)
     stage        {stage name: {field: value}} overrides applied by `for_stage` (engine: "enc", "swin", "search", "decode", and inside
-                 "decode" the last stack "out" and its final conv "tail")
+                 "decode" the stacks "dec2" (decoder_second), "dec1" (decoder_first), "out" (outBlock) and its final conv "tail")
     profile      None, or {op name: [(start_event, end_event), ...]} filled on the launch stream (bench.py)
     capture      None, or a dict that receives intermediate device tensors by name ("arg", "s": what SearchTransfer
                  decided) for the parity tests; eager launches only
@@ -157,12 +164,15 @@ class Ctx:
     ACT_NONE, ACT_RELU, ACT_GELU = ACT_NONE, ACT_RELU, ACT_GELU
     CONV, CONV_T = CONV, CONV_T
     _FIELDS = ("precision", "corr_precision", "device", "use_slab", "bf16_storage", "x1_bf16", "fuse_mlp", "fuse_attn",
-               "fuse_block", "commute_upconv", "corr_bf16", "fuse_apply", "stage", "profile", "capture")
+               "fuse_block", "commute_upconv", "commute_any", "corr_bf16", "fuse_apply", "split_decode", "stage", "profile", "capture")
+    # stages of an f16 frame that run in split (bf16x3) arithmetic by default, see `split_decode`
+    SPLIT_STAGES = ("glue", "dec2")
     __slots__ = _FIELDS
 
     def __init__(self, precision: str = "f32", corr_precision: str = "bf16x3", device=None, use_slab: bool = True,
                  bf16_storage: bool = True, x1_bf16: bool = True, fuse_mlp: bool = True, fuse_attn: bool = True,
-                 fuse_block: bool = False, commute_upconv: bool = True, corr_bf16: bool = True, fuse_apply: bool = False,
+                 fuse_block: bool = False, commute_upconv: bool = True, commute_any: bool = False, corr_bf16: bool = True,
+                 fuse_apply: bool = False, split_decode: bool = True,
                  stage: Optional[dict] = None,
                  profile: Optional[dict] = None, capture: Optional[dict] = None):
         if precision not in PRECISIONS:
@@ -182,8 +192,8 @@ class Ctx:
         object.__setattr__(self, "corr_precision", corr_precision)
         object.__setattr__(self, "device", device)
         for k, v in (("use_slab", use_slab), ("bf16_storage", bf16_storage), ("x1_bf16", x1_bf16), ("fuse_mlp", fuse_mlp),
-                     ("fuse_attn", fuse_attn), ("fuse_block", fuse_block), ("commute_upconv", commute_upconv),
-                     ("corr_bf16", corr_bf16), ("fuse_apply", fuse_apply)):
+                     ("fuse_attn", fuse_attn), ("fuse_block", fuse_block), ("commute_upconv", commute_upconv), ("commute_any", commute_any),
+                     ("corr_bf16", corr_bf16), ("fuse_apply", fuse_apply), ("split_decode", split_decode)):
             object.__setattr__(self, k, bool(v))
         object.__setattr__(self, "stage", dict(stage) if stage else {})
         object.__setattr__(self, "profile", profile)
@@ -199,6 +209,8 @@ class Ctx:
 
     def for_stage(self, name: str) -> "Ctx":
         o = self.stage.get(name)
+        if o is None and self.split_decode and self.precision == "f16" and name in self.SPLIT_STAGES:
+            o = {"precision": "bf16x3", "commute_any": True}
         return self.replace(**o) if o else self
 
     # ---- plumbing ----------------------------------------------------------------------------------------------
@@ -444,6 +456,14 @@ class Ctx:
                    "spei_mlp_fused16")
         return out
 
+    def mlp_tok(self, x: torch.Tensor, ws, b1: torch.Tensor, b2: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """out = x + fc2(gelu(fc1(LN(x)))), token-stationary kernel (csrc/swin_tok16.hip); ws: pack.MlpStreamW; in place when out is x."""
+        assert x.shape[1] == 256 and x.dtype == torch.float32 and x.is_contiguous() and out.shape == x.shape and out.dtype == torch.float32
+        tp = self._tp
+        f = self.fmt
+        _lib.check(_lib.lib().spei_mlp_tok16(f, tp(x), tp(out), tp(ws.stream(f)), tp(b1), tp(b2), x.shape[0], self._stream()), "spei_mlp_tok16")
+        return out
+
     def layernorm(self, x: torch.Tensor, g: Optional[torch.Tensor] = None, b: Optional[torch.Tensor] = None,
                   out: Optional[torch.Tensor] = None, out_dtype=torch.float32) -> torch.Tensor:
         assert x.shape[1] == 256 and x.is_contiguous() and x.dtype == torch.float32
@@ -543,7 +563,7 @@ class Ctx:
         """relu(conv1x1(bicubic_up(f))) (reference model/speinet.py:96-97,108-109, model/SearchTransfer.py:73-76).  Both maps
         are linear and the bicubic weights sum to 1, so the 16-bit modes run the conv first, at 1/s^2 of the pixels and with
         half the bytes through the upsampler; the f32-grade modes keep the reference's order of operations."""
-        if self.lp16 and self.commute_upconv:
+        if (self.lp16 and self.commute_upconv) or self.commute_any:
             return self.upsample(self.igemm(f, w, b, n), s, act=ACT_RELU)
         return self.igemm(self.upsample(f, s), w, b, n, act=ACT_RELU)
 

@@ -172,14 +172,6 @@ def test_forward_bf16x3_golden(golden_dir, net, name, b, h, w):
         assert dp <= 1e-3, f"PSNR delta {dp:.2e} dB"
 
 
-def _noref_slack(is_noref: bool) -> float:
-    """PSNR-delta bounds are stated for the SearchTransfer branch (`_forwardbs`, the bench configuration).  Samples routed through
-    `_forwardb` get twice the bound: with the synthetic weights that branch's frame leaves [0,1] by 40 % and its stand-in PSNR
-    is 7.5 dB, so the same rounding error weighs about twice as much in dB (measured f16: 9.2e-4 at 720p, 1.0e-3 at 200x200,
-    against 4.3e-4 / 1.2e-4 on the `_forwardbs` cases; tools/ablate_parity.py)."""
-    return 2.0 if is_noref else 1.0
-
-
 @pytest.mark.parametrize("mode,corr,tol_err,tol_db", [("f16", "top2", 3e-3, 1e-3), ("bf16", "top2", 0.05, 1e-2)])
 @pytest.mark.parametrize("name,b,h,w", [("g10_fwd_40x60_mixed", 2, 40, 60), ("g10_fwd_100x100", 1, 100, 100),
                                         ("g10_fwd_200x200", 1, 200, 200), ("g10_fwd_200x200_noref", 1, 200, 200)])
@@ -201,7 +193,7 @@ def test_forward_16bit_golden(golden_dir, net, name, b, h, w, mode, corr, tol_er
     print(f"{name} {mode}/{corr}: max abs err {err:.3e}, rms {rms:.3e}, |dPSNR vs target| {max(dps):.2e} dB")
     assert err < tol_err
     for i in range(b):
-        assert dps[i] <= tol_db * _noref_slack(i in zr), (i, dps[i])
+        assert dps[i] <= tol_db, (i, dps[i])           # no per-branch slack (round 3): the north-star bound on `_forwardb` too
 
 
 @pytest.mark.parametrize("mode", ["bf16", "f16"])
@@ -221,6 +213,33 @@ def test_mlp_fused_vs_oracle(synth_sd, mode):
         e = ((out.cpu() - ref).abs().max() / (ref - x).abs().max()).item()      # relative to the MLP branch itself
         assert e < TOL[mode], f"M={m}: rel err {e:.2e}"
         inplace = ops.mlp_fused(xd, w1, bk["b1"].to(DEV), w2, bk["b2"].to(DEV), out=xd)
+        assert torch.equal(inplace, out)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_mlp_tok_vs_oracle(synth_sd, mode):
+    """The token-stationary MLP kernel (csrc/swin_tok16.hip: weights through an LDS ring, tokens in registers, fc2 fed from fc1's
+    accumulators) against the fp32 formula, and against the round-2 fused kernel (same operand rounding, other summation order)."""
+    ops = Ctx(mode, device=DEV)
+    p = "swin.layers.1.residual_group.blocks.2."
+    bk = pack.swin_block(synth_sd, p, 8, 5)
+    w1, w2 = pack.PackedW(bk["w1"].t, DEV), pack.PackedW(bk["w2"].t, DEV)
+    ws = pack.MlpStreamW(bk["mlp_stream"].w1, bk["mlp_stream"].w2, DEV)
+    for m in (1, 31, 256, 1000, 2500, 57600):       # one token, under a wave, one workgroup, ragged tail, many, the 720p count
+        x = rnd(40 + m, m, 256, scale=1.5) + 0.3
+        ref = x + F.linear(F.gelu(F.linear(F.layer_norm(x, (256,), synth_sd[p + "norm2.weight"], synth_sd[p + "norm2.bias"], 1e-5),
+                                           synth_sd[p + "mlp.fc1.weight"], synth_sd[p + "mlp.fc1.bias"])),
+                           synth_sd[p + "mlp.fc2.weight"], synth_sd[p + "mlp.fc2.bias"])
+        xd = x.to(DEV)
+        out = ops.mlp_tok(xd, ws, bk["b1"].to(DEV), bk["b2"].to(DEV), out=torch.empty_like(xd))
+        scale = (ref - x).abs().max()
+        e = ((out.cpu() - ref).abs().max() / scale).item()                      # relative to the MLP branch itself
+        old = ops.mlp_fused(xd, w1, bk["b1"].to(DEV), w2, bk["b2"].to(DEV), out=torch.empty_like(xd))
+        e_old = ((out - old).abs().max().cpu() / scale).item()
+        print(f"mlp_tok {mode} M={m}: rel err vs fp32 {e:.2e}, vs mlp_fused {e_old:.2e}")
+        assert e < TOL[mode], f"M={m}: rel err {e:.2e}"
+        assert e_old < TOL[mode], f"M={m}: differs from the round-2 kernel by {e_old:.2e}"
+        inplace = ops.mlp_tok(xd, ws, bk["b1"].to(DEV), bk["b2"].to(DEV), out=xd)
         assert torch.equal(inplace, out)
 
 
@@ -481,10 +500,13 @@ def test_forward_full_size_reference_golden(golden_dir, net, name):
     per-channel statistics, its PSNR, and what its SearchTransfer decided: arg-max, S, top-2 margin): the bench configuration
     (720p, `_forwardbs`), the same through `_forwardb`, a mixed-routing batch at the BSD size and an edge-dominated 720p window.
     Every mode that claims PSNR parity — exact fp32, bf16x3 and f16 / top2, the configuration bench.py times — must hold the
-    north-star bound |dPSNR| <= 1e-3 dB and 1e-3 absolute on the grid; bf16 its documented bound.
+    north-star bound |dPSNR| <= 1e-3 dB and 1e-3 absolute on the grid; bf16 its documented bound.  The PSNR bound is asserted twice:
+    against the stand-in target the fixture was made with (the reference scores 7-12 dB there) and against a synthesised ground
+    truth where the reference scores ~32 dB (~28 dB at the BSD size) — the operating point of its published logs.
     Arg-max: positions that differ from the reference's own arg-max are counted; for the f32-grade modes every one of them
     must be a reference near-tie (top-2 margin < 1e-5 in the reference's own fp32 scores: another summation order decides)."""
     d, x, gt = _golden_case(golden_dir, name)
+    tgt = np.load(os.path.join(golden_dir, name + "_target.npz"))        # synthesised ~32 / ~28 dB ground truth + the reference's PSNR
     b = x.shape[0]
     sub, mean, std = (torch.from_numpy(d[k]) for k in ("sub", "mean", "std"))
     ref_arg = torch.from_numpy(d["arg"]).long() if "arg" in d.files else None
@@ -520,7 +542,15 @@ def test_forward_full_size_reference_golden(golden_dir, net, name):
             assert err < grid_tol and dm < tol / 10 and ds < tol / 10, mode
             zr = [int(i) for i in d["zero_ref"]]
             for i in range(b):
-                assert dps[i] <= tol_db * (_noref_slack(i in zr) if mode == "f16" else 1.0), (mode, i, dps[i])
+                assert dps[i] <= tol_db, (mode, i, dps[i])
+            # the same bound at a REALISTIC operating point: against the synthesised ground truth of <case>_target.npz the reference
+            # scores ~32 dB (G16, the BSD frame size: ~28 dB) — the range of its own GoPro / BSD logs — where a given output error
+            # weighs ~10x more in dB than against the 7-12 dB stand-in targets above (tests/golden/make_golden_720p.py)
+            dpt = [abs(O.psnr_uint8(O.to_uint8(out[i:i + 1]), torch.from_numpy(tgt["target"][i]).permute(1, 2, 0)) - float(tgt["psnr"][i]))
+                   for i in range(b)]
+            print(f"{name} vs reference at its {float(tgt['psnr'].mean()):.1f} dB operating point, {mode}/{corr}: |dPSNR| {max(dpt):.1e} dB")
+            for i in range(b):
+                assert dpt[i] <= tol_db, (mode, "realistic target", i, dpt[i])
             if mode in ("f32", "bf16x3"):
                 assert hard == 0 and flips <= 40 and serr < 1e-5, (mode, flips, hard, serr)
     finally:

@@ -53,6 +53,7 @@ CONFIGS = [
     ("bf16 / corr single  (round-1 bench mode)", "bf16", "single", {}),
     ("f16 / corr bf16x3", "f16", "bf16x3", {"stage": {"search": {"precision": "bf16x3"}}}),
     ("f16 / corr top2  (bench mode)", "f16", "top2", {}),
+    ("f16 / corr top2, split_decode off (round 2)", "f16", "top2", {"split_decode": False}),
     ("f16 / corr single", "f16", "single", {}),
     ("f16 top2, x1 fp32", "f16", "top2", {"x1_bf16": False}),
     ("f16 top2, fp32 storage", "f16", "top2", {"bf16_storage": False}),
@@ -67,6 +68,16 @@ CONFIGS = [
     ("f16, enc stage bf16x3", "f16", "top2", {"stage": {"enc": {"precision": "bf16x3"}}}),
     ("f16, outBlock + tail bf16x3", "f16", "top2", {"stage": {"out": {"precision": "bf16x3"}}}),
     ("f16, tail conv f32", "f16", "top2", {"stage": {"tail": {"precision": "f32"}}}),
+    ("f16, tail conv bf16x3", "f16", "top2", {"stage": {"tail": {"precision": "bf16x3"}}}),
+    ("f16, dec2 bf16x3", "f16", "top2", {"stage": {"dec2": {"precision": "bf16x3"}}}),
+    ("f16, dec1 bf16x3", "f16", "top2", {"stage": {"dec1": {"precision": "bf16x3"}}}),
+    ("f16, out bf16x3", "f16", "top2", {"stage": {"out": {"precision": "bf16x3"}}}),
+    ("f16, glue only bf16x3", "f16", "top2", {"stage": {"glue": {"precision": "bf16x3", "commute_any": True}}}),
+    ("f16, glue + dec2 bf16x3", "f16", "top2", {"stage": {"glue": {"precision": "bf16x3", "commute_any": True}, "dec2": {"precision": "bf16x3"}}}),
+    ("f16, glue + dec2 + tail bf16x3", "f16", "top2", {"stage": {"glue": {"precision": "bf16x3", "commute_any": True}, "dec2": {"precision": "bf16x3"}, "tail": {"precision": "bf16x3"}}}),
+    ("f16, dec2+dec1 bf16x3", "f16", "top2", {"stage": {"dec2": {"precision": "bf16x3"}, "dec1": {"precision": "bf16x3"}}}),
+    ("f16, tail f32 + x1 fp32", "f16", "top2", {"x1_bf16": False, "stage": {"tail": {"precision": "f32"}}}),
+    ("f16, tail f32 + decode bf16x3", "f16", "top2", {"stage": {"tail": {"precision": "f32"}, "decode": {"precision": "bf16x3"}}}),
 ]
 
 
@@ -81,6 +92,10 @@ def load_case(name):
         d["sub"] = d["out"][:, :, ::8, ::8]
         d["psnr"] = np.array([_psnr_uint8(_to_uint8(out[i:i + 1]), _to_uint8(x[i:i + 1, 1])) for i in range(b)])
         return d, x, x[:, 1], zr
+    tp = os.path.join(GOLDEN, name + "_target.npz")
+    if os.path.exists(tp):                    # synthesised ~32 / ~28 dB ground truth and the reference's PSNR against it
+        t = np.load(tp)
+        d["target_u8"], d["target_psnr"] = t["target"], t["psnr"]
     b = d["sub"].shape[0]
     h, w = d["sub"].shape[2] * 8, d["sub"].shape[3] * 8
     zr = tuple(int(i) for i in d["zero_ref"])
@@ -133,10 +148,14 @@ def main():
             out = torch.cat(outs)
             err = (out[:, :, ::8, ::8] - sub).abs().max().item()
             dp = max(abs(_psnr_uint8(_to_uint8(out[i:i + 1]), _to_uint8(gt[i:i + 1])) - float(d["psnr"][i])) for i in range(x.shape[0]))
-            rows.append({"case": case, "config": label, "max_err_grid": err, "dpsnr_db": dp, "argmax_flips": flips,
-                         "flips_margin_ge_1e-5": tight, "max_s_err": serr})
-            print(f"{case:26s} {label:40s} max|err| {err:.2e}  |dPSNR| {dp:.2e} dB  flips {flips:5d} (non-near-tie {tight})  "
-                  f"max|dS| {serr:.1e}", flush=True)
+            sdp = [_psnr_uint8(_to_uint8(out[i:i + 1]), _to_uint8(gt[i:i + 1])) - float(d["psnr"][i]) for i in range(x.shape[0])]
+            dpt = None
+            if "target_u8" in d:
+                dpt = [_psnr_uint8(_to_uint8(out[i:i + 1]), torch.from_numpy(d["target_u8"][i:i + 1])) - float(d["target_psnr"][i]) for i in range(x.shape[0])]
+            rows.append({"case": case, "config": label, "max_err_grid": err, "dpsnr_db": dp, "dpsnr_signed": sdp, "dpsnr_realistic_signed": dpt,
+                         "argmax_flips": flips, "flips_margin_ge_1e-5": tight, "max_s_err": serr})
+            print(f"{case:26s} {label:40s} max|err| {err:.2e}  dPSNR " + ",".join(f"{v:+.2e}" for v in sdp) + " dB"
+                  + ("  at ~32/28 dB: " + ",".join(f"{v:+.2e}" for v in dpt) if dpt else "") + f"  flips {flips:5d} (non-near-tie {tight})", flush=True)
     net.knobs = {}
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump(rows, open(args.out, "w"), indent=1)

@@ -17,7 +17,7 @@ ops = Ctx(os.environ.get("PREC", "f16"), device=dev)
 LP = torch.float16 if ops.precision == "f16" else torch.bfloat16
 sd = synth_state_dict(state_dict_template())
 p = "swin.layers.0.residual_group.blocks.1."
-bk = {k: (v.to(dev) if torch.is_tensor(v) else pack.PackedW(v.t, dev)) for k, v in pack.swin_block(sd, p, 8, 5).items()}
+bk = pack._to_device(pack.swin_block(sd, p, 8, 5), dev)
 x = torch.randn(H * W, 256, device=dev)
 yhat = torch.randn(H * W, 256, device=dev).to(LP)
 out = torch.empty_like(x)
@@ -39,6 +39,11 @@ def timeit(name, fn, n=30):
 for shift in (0, 2):
     timeit(f"attn_fused shift={shift}", lambda: ops.attn_fused(x, yhat, bk, H, W, shift, out))
 timeit("mlp_fused", lambda: ops.mlp_fused(x, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out))
+timeit("mlp_tok", lambda: ops.mlp_tok(x, bk["mlp_stream"], bk["b1"], bk["b2"], out))
+x2 = torch.randn(2 * H * W, 256, device=dev)
+out2 = torch.empty_like(x2)
+timeit("mlp_fused 2x tokens", lambda: ops.mlp_fused(x2, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out2))
+timeit("mlp_tok   2x tokens", lambda: ops.mlp_tok(x2, bk["mlp_stream"], bk["b1"], bk["b2"], out2))
 for shift in (0, 2):
     timeit(f"attn + mlp shift={shift}", lambda: ops.mlp_fused(ops.attn_fused(x, yhat, bk, H, W, shift, out), bk["w1"], bk["b1"], bk["w2"], bk["b2"], out))
     timeit(f"swin_block shift={shift}", lambda: ops.swin_block(x, yhat, bk, H, W, shift, out))

@@ -4,7 +4,7 @@ every workgroup stamps s_memtime (100 MHz-independent shader clock ticks) at pha
 passed through SPEI_STAMP_PTR.  Prints the median per-phase durations in microseconds (at the measured clock) and the spread
 of workgroup start / end times across the launch.
 
-    python tools/stamp_phases.py attn|mlp|block      (block: the first of the three groups of every workgroup)
+    python tools/stamp_phases.py attn|mlp|mlptok|block      (block: the first of the three groups of every workgroup)
     python tools/stamp_phases.py conv1|conv2|conv3   (conv_slab: the 5x5 ResBlock conv at 720p level 1 / 2 / 3, f16 in and out;
                                                       stamps: 0 start, 1 slab staged, 2 barrier passed, 3 main loop done, 4 stored)
 """
@@ -29,7 +29,7 @@ from speinet_amd.synth import state_dict_template, synth_state_dict     # noqa: 
 ops = Ctx("f16", device=dev)
 sd = synth_state_dict(state_dict_template())
 p = "swin.layers.0.residual_group.blocks.1."
-bk = {k: (v.to(dev) if torch.is_tensor(v) else pack.PackedW(v.t, dev)) for k, v in pack.swin_block(sd, p, 8, 5).items()}
+bk = pack._to_device(pack.swin_block(sd, p, 8, 5), dev)
 x = torch.randn(H * W, 256, device=dev)
 yhat = torch.randn(H * W, 256, device=dev).half()
 out = torch.empty_like(x)
@@ -51,6 +51,8 @@ def run():
         ops.attn_fused(x, yhat, bk, H, W, 2, out)
     elif which == "block":
         ops.swin_block(x, yhat, bk, H, W, 2, out)
+    elif which == "mlptok":
+        ops.mlp_tok(x, bk["mlp_stream"], bk["b1"], bk["b2"], out)
     else:
         ops.mlp_fused(x, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out)
 
