@@ -82,10 +82,32 @@ def traffic_bytes(precision: str, corr_precision: str):
     return None, None, None
 
 
+def physical_cores() -> int:
+    """Physical cores visible to this process (unique (physical id, core id) pairs of /proc/cpuinfo; falls back to os.cpu_count())."""
+    try:
+        ids, cur = set(), {}
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = (t.strip() for t in line.split(":", 1))
+                cur[k] = v
+            elif cur:
+                ids.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor", "0"))))
+                cur = {}
+        if cur:
+            ids.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor", "0"))))
+        return max(1, len(ids))
+    except OSError:
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(seed: int, mode: str, budget_s: float) -> dict:
+    """The oracle (CPU restatement of the reference, PyTorch fp32) on this host: one untimed warm-up + two timed frames at 360x640
+    (threads, allocator and oneDNN primitives warm; their spread is reported), then ONE timed frame at the bench size 1280x720 — the
+    headline — unless the probe predicts it would exceed `budget_s`."""
     from oracle import speinet_oracle as O
     from speinet_amd.synth import state_dict_template, synth_frames, synth_state_dict
-    threads = min(os.cpu_count() or 1, 16)
+    phys, logical = physical_cores(), os.cpu_count() or 1
+    threads = min(phys, 16)
     torch.set_num_threads(threads)
     sd = synth_state_dict(state_dict_template(), seed=0)
 
@@ -97,20 +119,30 @@ def cpu_baseline(seed: int, mode: str, budget_s: float) -> dict:
             return time.time() - t0
 
     sh, sw = 360, 640
-    dt = run(sh, sw)
+    run(sh, sw)                                                 # warm-up, untimed
+    probes = [run(sh, sw) for _ in range(2)]
+    dt = min(probes)
     scale = path_flops(H, W) / path_flops(sh, sw)
+    host = f"{threads} threads on {phys} physical / {logical} logical cores visible"
     if mode == "720p" and dt * scale * 2.5 <= budget_s:       # measured: the quadratic term makes 720p ~2x the FLOP-scaled probe
         dt720 = run(H, W)
-        return {"value": 1.0 / dt720, "unit": "frames/s", "cores": threads, "kind": "port",
-                "sample": f"oracle (PyTorch fp32 CPU restatement), ONE {W}x{H} _forwardbs frame in {dt720:.1f} s, no warm-up "
-                          f"({sw}x{sh} probe: {dt:.1f} s)"}
-    return {"value": 1.0 / (dt * scale), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"EXTRAPOLATED: oracle on one {sw}x{sh} _forwardbs frame in {dt:.1f} s, scaled x{scale:.2f} to 720p by F(HW) of "
-                      "BASELINE.md (optimistic: the 57600^2 correlation does not scale like FLOPs)"}
+        return {"value": 1.0 / dt720, "unit": "frames/s", "cores": threads, "physical_cores": phys, "kind": "port",
+                "sample": f"oracle (PyTorch fp32 CPU restatement), {host}: ONE {W}x{H} _forwardbs frame in {dt720:.1f} s after a warm-up "
+                          f"and two timed {sw}x{sh} frames ({probes[0]:.2f} s, {probes[1]:.2f} s)"}
+    return {"value": 1.0 / (dt * scale), "unit": "frames/s", "cores": threads, "physical_cores": phys, "kind": "port",
+            "sample": f"EXTRAPOLATED: oracle, {host}: best of two timed {sw}x{sh} _forwardbs frames after a warm-up ({probes[0]:.2f} s, "
+                      f"{probes[1]:.2f} s), scaled x{scale:.2f} to 720p by F(HW) of BASELINE.md (optimistic: the 57600^2 correlation does "
+                      "not scale like FLOPs)"}
 
 
 def train_main(argv=None):
     """`bench.py --train ...`: training-step throughput (config 5), see the module docstring."""
+    line = train_measure(argv)
+    if line is not None:
+        print(json.dumps(line))
+
+
+def train_measure(argv=None):
     ap = argparse.ArgumentParser(prog="bench.py --train")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--patch", type=int, default=200)
@@ -201,13 +233,15 @@ def train_main(argv=None):
         dt = time.time() - t0
         cpu = {"value": nb / dt, "unit": "crops/s", "cores": threads, "kind": "port",
                "sample": f"oracle train-mode graph + torch autograd (fp32), forward + loss + backward of {nb} crops of {a.patch}x{a.patch} in {dt:.1f} s, no optimizer step"}
+    line = None
     if rank == 0:
-        print(json.dumps({"metric": f"training crops/s, {a.model} model, fwd + loss + bwd + Adam", "value": world * a.batch * 1e3 / ms,
-                          "unit": "crops/s", "n_gpus": world, "batch_per_gpu": a.batch, "patch": a.patch, "n_sequence": 3, "ms_per_step": ms,
-                          "ms": {"forward": float(split[0]), "loss_backward": float(split[1]), "adam": float(split[2])},
-                          "loss": float(loss.item()), "dtype": "f32", "data": "synthetic", "scaling": "weak", "cpu_baseline": cpu}))
+        line = {"metric": f"training crops/s, {a.model} model, fwd + loss + bwd + Adam", "value": world * a.batch * 1e3 / ms,
+                "unit": "crops/s", "n_gpus": world, "batch_per_gpu": a.batch, "patch": a.patch, "n_sequence": 3, "ms_per_step": ms,
+                "ms": {"forward": float(split[0]), "loss_backward": float(split[1]), "adam": float(split[2])},
+                "loss": float(loss.item()), "dtype": "f32", "data": "synthetic", "scaling": "weak", "cpu_baseline": cpu}
     if dist is not None:
         dist.destroy_process_group()
+    return line
 
 
 def main():
@@ -229,6 +263,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying hipGraph segments")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams for the independent neighbour-frame / reference branches of a frame")
     ap.add_argument("--branch", choices=["bs", "b"], default="bs", help="bs: with sharp reference (SearchTransfer); b: SelfTransfer")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="frames in flight: consecutive steps alternate over this many launch streams; step i + 1 starts when step i's "
+                         "correlation kernel has finished, so its encoder passes run beside step i's decoder (1: one frame at a time)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the bf16-to-the-letter and training sub-records of the default line")
+    ap.add_argument("--free-overlap", action="store_true", help="with --inflight > 1: let the frames overlap freely instead of gating frame i + 1 on frame i's correlation kernel")
     ap.add_argument("--knobs", default="", help='experiments: JSON of extra speinet_amd.ops.Ctx fields, e.g. \'{"stage": {"glue": {"precision": "bf16x3"}}}\'')
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
@@ -273,30 +312,52 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    checksum = torch.zeros(1, device=dev, dtype=torch.float64)
+    nfl = max(1, args.inflight)
+    checksums = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(nfl)]
     prof = {"corr_argmax": []}
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    # frames in flight: step i runs on launch stream i % nfl (its own captured graph instance), so that step i + 1's encoder passes
+    # fill the chip under step i's correlation kernel and decoder; within a stream steps stay in order
+    lanes = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(nfl - 1)]
+
+    def run_steps(n, **kw):
+        gate = None
+        for i in range(n):
+            with torch.cuda.stream(lanes[i % nfl]):
+                if gate is not None and nfl > 1 and not args.free_overlap:
+                    # the next frame starts once this frame's correlation kernel (a full-chip MFMA kernel: nothing overlaps it
+                    # productively) is done: its encoder passes then run beside THIS frame's decoder, whose small launches leave most of
+                    # the chip idle
+                    torch.cuda.current_stream().wait_event(gate)
+                pr = kw.get("profile")
+                local = pr if pr is not None else {"corr_argmax": []}
+                out = net(frames[i % 2], **dict(kw, profile=local))
+                gate = local["corr_argmax"][-1][1]
+                checksums[i % nfl].add_(out.double().sum())
+                if pr is not None:
+                    marks[i + 1].record()
+
     with torch.no_grad():
-        for i in range(args.warmup):
-            net(frames[i % 2], routing=routing)
+        run_steps(max(args.warmup, nfl), routing=routing)
+        barrier()                                  # the warm-up frames of every launch stream are done before the sums are cleared
+        for c in checksums:
+            c.zero_()
         # ---- the timed region: EXACTLY `steps` forwards, the dominant kernel bracketed live by HIP events ----------------
         barrier()
         t0 = time.perf_counter()
         marks[0].record()
-        for i in range(args.steps):
-            out = net(frames[i % 2], routing=routing, profile=prof)
-            checksum += out.double().sum()
-            marks[i + 1].record()
+        run_steps(args.steps, routing=routing, profile=prof)
         barrier()
         dt = time.perf_counter() - t0
+        checksum = sum(checksums)
         # ---- the same steps the way the reference calls forward: no routing hint (device test + one host sync per call) ----
         barrier()
         t1 = time.perf_counter()
-        for i in range(args.steps):
-            net(frames[i % 2])
+        run_steps(args.steps)
         barrier()
         dt_ref_call = time.perf_counter() - t1
-    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)] if nfl == 1 else \
+              [marks[i].elapsed_time(marks[i + nfl]) / nfl for i in range(1, args.steps + 1 - nfl)]   # same-stream neighbours
     pairs = prof["corr_argmax"]
     corr_ms = sum(s.elapsed_time(e) for s, e in pairs) / max(1, len(pairs))
     assert len(pairs) == args.steps, "the dominant kernel must be timed once per step"
@@ -324,7 +385,8 @@ def main():
                                    f"{'_forwardbs (SearchTransfer)' if args.branch == 'bs' else '_forwardb (SelfTransfer)'}, "
                                    "synthetic name-keyed weights seed 0", "frames_per_step_per_gpu": 1,
                        "sharding": "frames by rank, no data-path collective",
-                       "launch": ("2 hipGraph segments + the correlation kernel per frame" if net.use_graph else "eager") + f", {args.streams} HIP streams"},
+                       "launch": ("2 hipGraph segments + the correlation kernel per frame" if net.use_graph else "eager") + f", {args.streams} HIP streams"
+                                 + (f"; {nfl} frames in flight (step i + 1 starts when step i's correlation kernel is done)" if nfl > 1 else "")},
             "step_ms": {"median": statistics.median(step_ms), "p10": qs[0], "p90": qs[8], "min": min(step_ms), "max": max(step_ms)},
             "reference_call": {"value": world * args.steps / tmax_ref, "unit": "frames/s", "ms_per_step": 1e3 * tmax_ref / args.steps,
                                "note": "forward(x) without the routing hint: the frame-3 test runs on the device, one host sync per call"},
@@ -338,11 +400,34 @@ def main():
                          "path_hbm_frac": (path_hbm * fps / world / 8e12) if path_hbm else None},
             "checksum": float(gathered[:, 0].sum().item()),
         }
+        extras = world == 1 and not args.no_extras and (h, w) == (H, W) and args.precision == "f16"
+        if extras:
+            # BASELINE.json configs[1] to the letter ("bf16 forward"): the same steps with bf16 operands (8-bit significands: 3e-3 dB)
+            net.precision = "bf16"
+            prof_b = {"corr_argmax": []}
+            with torch.no_grad():
+                run_steps(max(3, nfl), routing=routing)
+                barrier()
+                tb = time.perf_counter()
+                run_steps(args.steps, routing=routing, profile=prof_b)
+                barrier()
+                dtb = time.perf_counter() - tb
+            pb = prof_b["corr_argmax"]
+            line["bf16_letter"] = {"value": args.steps / dtb, "unit": "frames/s", "ms_per_step": 1e3 * dtb / args.steps,
+                                   "dtype": f"bf16 (correlation {args.corr_precision})", "corr_kernel": prof_b.get("corr_kernel"),
+                                   "corr_launch_ms": sum(s_.elapsed_time(e_) for s_, e_ in pb) / max(1, len(pb)),
+                                   "parity": "|dPSNR| vs the reference 3e-3 dB (tests/test_gpu_bf16.py bound 1e-2)"}
+            net.precision = args.precision
         if world == 1 and not args.no_harness and (h, w) == (H, W) and args.precision != "f32":
             from speinet_amd.inference import harness_throughput
             del net, frames
             torch.cuda.empty_cache()
             line["harness"] = harness_throughput(100, args.precision)
+        if extras:
+            # BASELINE.json configs[4]: one training step of the swint model on 200x200 crops (trainer/trainer_swint.py), batch 20
+            torch.cuda.empty_cache()
+            tr = train_measure(["--batch", "20", "--steps", "3", "--warmup", "1"])
+            line["train"] = {k: tr[k] for k in ("metric", "value", "unit", "batch_per_gpu", "patch", "ms_per_step", "ms", "dtype")}
         mode = "none" if args.no_cpu_baseline else args.cpu_baseline
         if world == 1 and mode != "none":
             line["cpu_baseline"] = cpu_baseline(1234, mode, args.cpu_budget)

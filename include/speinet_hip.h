@@ -100,6 +100,15 @@ int spei_conv_slab16(int fmt, const void* a0, int lda0, int k0, const void* a1, 
                      const float* residual, int ldr, const float* rowscale, int Hin, int Win, int Hout, int Wout,
                      int N, int ksize, int stride, int pad, int act, int ln_input, spei_stream_t stream);
 
+/* The same convolution on `batch` dense maps in ONE launch (gridDim.y = map): the frame's 7 encoder passes go through every layer of
+ * model/recons_video_ori.py:26-56 with the same weights (model/speinet.py:82-83,125-131).  a0 [batch][Hin*Win][k0], out
+ * [batch][Hout*Wout][N], fp32 or `fmt` each; single-product arithmetic.  Per map the tiles and the arithmetic are those of
+ * spei_conv_slab16 (bit-identical results); a launch has batch x the workgroups (several resident rounds instead of half of one at
+ * H/4) and a frame needs 1/batch of the launches. */
+int spei_conv_slab16_batched(int fmt, const void* a0, int k0, int a_fmt, const void* wfrag, const float* bias, void* out, int out_fmt,
+                             int batch, int Hin, int Win, int Hout, int Wout, int N, int ksize, int stride, int pad, int act,
+                             spei_stream_t stream);
+
 /* The same convolution (stride 1, pad k/2, one dense fp32 input map, single-product arithmetic) with the PREVIOUS ResBlock's gated
  * residual sum folded into its staging (model/block.py:136-140 feeding the next block's first conv, :127-131):
  *     x'[p][c] = x[p][c] + x1[p][c] * (s[c] + g1[y][c] + g2[x][c]),    out = act(conv(x', w) + bias)
@@ -168,6 +177,15 @@ int spei_resblock_gates(const void* x1, int x1_fmt, int H, int W, int C, const f
 /* out = x + x1*s + (x1*g1 + x1*g2) [+ extra]   (model/block.py:136-140; `extra` fuses speinet.py:84,132) */
 int spei_resblock_apply(const float* x, const void* x1, int x1_fmt, const float* s, const float* g1, const float* g2,
                         const float* extra, float* out, int ldo, int H, int W, int C, spei_stream_t stream);
+
+/* spei_resblock_gates / spei_resblock_apply on `batch` dense maps in one launch each (gridDim.y = map): x1 [batch][H*W][C];
+ * s [batch][C], g1 [batch][H][C], g2 [batch][W][C]; ws: batch x spei_gate_ws_floats(H, W, C) floats; x, out [batch][H*W][C] fp32.
+ * Per map the arithmetic (and every partial-sum order) is that of the single-map entry points. */
+int spei_resblock_gates_batched(const void* x1, int x1_fmt, int batch, int H, int W, int C, const float* se_w1, const float* se_b1,
+                                const float* se_w2, const float* se_b2, const float* cw_w, const float* cw_bn, const float* hc_w,
+                                const float* hc_bn, float* s, float* g1, float* g2, float* ws, spei_stream_t stream);
+int spei_resblock_apply_batched(const float* x, const void* x1, int x1_fmt, const float* s, const float* g1, const float* g2, float* out,
+                                int batch, int H, int W, int C, spei_stream_t stream);
 
 /* K7 — LayerNorm over C=256, eps 1e-5 (model/swinir.py:244-245,279,528-529,776).  gamma/beta may be NULL
  * (affine folded into the following linear by pack.py); out_fmt: y is fp32, or 16-bit when it only feeds a GEMM. */

@@ -60,6 +60,12 @@ struct SlabParams {
     const void* fa_x1;
     const float *fa_s, *fa_g1, *fa_g2;
     float* fa_out;
+    // Batched launch (gridDim.y = number of maps, e.g. the 7 encoder passes of a frame through the same layer): map b of the input / the
+    // output starts a0_bs / out_bs BYTES after map b - 1.  Same tiles, same arithmetic as one launch per map (bit-identical); what
+    // changes is how many workgroups a launch has (450 -> 3150 at H/4: several resident rounds instead of half of one) and how many
+    // launches a frame needs.  a1, res, rowscale and the fused apply staging are not batched.
+    long long a0_bs, out_bs;
+    int batch;
     long long* stamps;       // tuning build: phase stamps (tools/stamp_phases.py conv), else NULL
     int dbg;                 // ablation switches for tools/ablate_slab.py (0 in production): 1 no staging loads, 8 weight stream from one hot group,
                              // 4 no epilogue stores
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 4 && WN == 1 && TM <= 2 && !SP
     // ---- stage the input slab ----------------------------------------------------------------------------------
     SPEI_STAMP(p.stamps, 0);
     {
-        const TA* a0 = static_cast<const TA*>(p.a0);
+        const TA* a0 = reinterpret_cast<const TA*>(static_cast<const unsigned char*>(p.a0) + (size_t)blockIdx.y * p.a0_bs);
         const TA* a1 = static_cast<const TA*>(p.a1);
         const int cpn = p.K / CH;                         // 16-byte chunks per pixel
         const int npix = p.IH * p.IW;
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 4 && WN == 1 && TM <= 2 && !SP
         // 4 instead of 16 store instructions per 32 x 32 tile.
         int fk_e = fk;
         asm volatile("" : "+v"(fk_e));
-        TO* outp = static_cast<TO*>(p.out);
+        TO* outp = reinterpret_cast<TO*>(static_cast<unsigned char*>(p.out) + (size_t)blockIdx.y * p.out_bs);
         int fr_e = fr;
         asm volatile("" : "+v"(fr_e));
         const int et = fr_e & 3, ecol = (fr_e >> 2) * 4;
@@ -483,7 +489,7 @@ int launch(const SlabParams& p, size_t lds, hipStream_t s) {
     q.stamps = spei_stamp_buffer();
     static const int stagger = spei_knob("SPEI_SLAB_STAGGER", 0), slots = spei_knob("SPEI_SLAB_SLOTS", 3);
     q.stagger = stagger; q.stagger_slots = slots;
-    dim3 grid(p.tiles_x * cdiv(p.Hout, p.TH), 1);
+    dim3 grid(p.tiles_x * cdiv(p.Hout, p.TH), p.batch > 0 ? p.batch : 1);
     hipLaunchKernelGGL((conv_slab_kernel<WM, WN, TM, TN, SPLIT, TA, TO, LP, FA>), grid, dim3(64 * WM * WN), lds, s, q);
     SPEI_CHECK_LAUNCH("spei_conv_slab16");
     return 0;
@@ -595,8 +601,11 @@ static int conv_slab16_run(int fmt, const void* a0, int lda0, int k0, const void
                            int out_fmt, const float* residual, int ldr, const float* rowscale, int Hin, int Win,
                            int Hout, int Wout, int N, int ksize, int stride, int pad, int act, int ln_input,
                            const void* fa_x1, const float* fa_s, const float* fa_g1, const float* fa_g2, float* fa_out,
-                           spei_stream_t stream) {
+                           spei_stream_t stream, int batch = 1) {
     SPEI_REQUIRE(a0 && wfrag_hi && out, "spei_conv_slab16: null pointer");
+    SPEI_REQUIRE(batch >= 1 && batch <= 65535, "spei_conv_slab16_batched: batch=%d", batch);
+    SPEI_REQUIRE(batch == 1 || (!a1 && !residual && !rowscale && !fa_x1 && !ln_input && lda0 == k0 && ldo == N && Wout > 1),
+                 "spei_conv_slab16_batched: dense maps, one input, no residual / row scale / fused staging");
     if (fa_x1) {
         SPEI_REQUIRE(fa_s && fa_g1 && fa_g2 && fa_out, "spei_conv_slab16_fa: null pointer");
         SPEI_REQUIRE(a_fmt == SPEI_F32 && !wfrag_lo && !a1 && k1 == 0 && lda0 == k0 && stride == 1 && ksize > 1 && !ln_input && Wout > 1,
@@ -636,6 +645,9 @@ static int conv_slab16_run(int fmt, const void* a0, int lda0, int k0, const void
     p.ln = ln_input;
     p.ntap = 0; p.o_mul = 1; p.o_row_add = 0; p.o_col_add = 0; p.Wfull = Wout; p.planes = 0;
     p.fa_x1 = fa_x1; p.fa_s = fa_s; p.fa_g1 = fa_g1; p.fa_g2 = fa_g2; p.fa_out = fa_out;
+    p.batch = batch;
+    p.a0_bs = (long long)Hin * Win * lda0 * (a16 ? 2 : 4);
+    p.out_bs = (long long)Hout * Wout * ldo * (o16 ? 2 : 4);
     return dispatch_fmt(p, fmt, wfrag_lo != nullptr, a16, o16, (hipStream_t)stream);
 }
 
@@ -646,6 +658,13 @@ extern "C" int spei_conv_slab16(int fmt, const void* a0, int lda0, int k0, const
                                 spei_stream_t stream) {
     return conv_slab16_run(fmt, a0, lda0, k0, a1, lda1, k1, a_fmt, wfrag_hi, wfrag_lo, bias, out, ldo, out_fmt, residual, ldr, rowscale, Hin,
                            Win, Hout, Wout, N, ksize, stride, pad, act, ln_input, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int spei_conv_slab16_batched(int fmt, const void* a0, int k0, int a_fmt, const void* wfrag, const float* bias, void* out, int out_fmt,
+                                        int batch, int Hin, int Win, int Hout, int Wout, int N, int ksize, int stride, int pad, int act,
+                                        spei_stream_t stream) {
+    return conv_slab16_run(fmt, a0, k0, k0, nullptr, 0, 0, a_fmt, wfrag, nullptr, bias, out, N, out_fmt, nullptr, 0, nullptr, Hin, Win, Hout,
+                           Wout, N, ksize, stride, pad, act, 0, nullptr, nullptr, nullptr, nullptr, nullptr, stream, batch);
 }
 
 extern "C" int spei_conv_slab16_fa(int fmt, const float* x, int K, const void* x1, const float* s, const float* g1, const float* g2,

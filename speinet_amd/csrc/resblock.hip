@@ -60,8 +60,11 @@ __device__ __forceinline__ f32x4 max4(f32x4 a, f32x4 b) {
 
 // ---- launch 1: tile statistics -----------------------------------------------------------------------------
 template <int C, typename TX>
-__global__ __launch_bounds__(256) void gate_stats_kernel(const TX* __restrict__ x1, int H, int W, GateWs g) {
+__global__ __launch_bounds__(256) void gate_stats_kernel(const TX* __restrict__ x1, int H, int W, float* ws, int64_t wsf) {
     constexpr bool LP = sizeof(TX) == 2;
+    // batched launch: blockIdx.y = map (one of the frame's encoder passes through this layer); its own map and workspace slice
+    x1 += (size_t)blockIdx.y * H * W * C;
+    const GateWs g = carve(ws + (size_t)blockIdx.y * wsf, H, W, C, LP);
     constexpr int OCT = C / 8;                   // threads per pixel (8 channels each)
     constexpr int TC = 256 / OCT;                // tile columns
     constexpr int TR = LP ? GATE_TR16 : GATE_TR32;
@@ -176,12 +179,12 @@ __global__ __launch_bounds__(256) void gate_stats_kernel(const TX* __restrict__ 
 }
 
 template <int C, typename TX>
-void launch_gate_stats(const TX* x1, int H, int W, const GateWs& g, hipStream_t st) {
+void launch_gate_stats(const TX* x1, int H, int W, const GateWs& g, float* ws, int64_t wsf, int batch, hipStream_t st) {
     constexpr bool LP = sizeof(TX) == 2;
     constexpr int OCT = C / 8, TC = 256 / OCT, TR = LP ? GATE_TR16 : GATE_TR32, EB = LP ? 16 : 32;
     const size_t lds = (size_t)TR * (TC * OCT * EB + 4 * EB) + (size_t)TR * C * sizeof(float);
     ensure_dyn_lds<&gate_stats_kernel<C, TX>>(lds);
-    hipLaunchKernelGGL((gate_stats_kernel<C, TX>), dim3(g.ntx * g.nty), dim3(256), lds, st, x1, H, W, g);
+    hipLaunchKernelGGL((gate_stats_kernel<C, TX>), dim3(g.ntx * g.nty, batch), dim3(256), lds, st, x1, H, W, ws, wsf);
 }
 
 // Reduce the `nt` tile partials of `cnt` rows (or columns) starting at line `l0` (lines outside [0, L) give -inf / 0) into
@@ -238,12 +241,16 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ pmax, 
 // A block owns 256 consecutive (row, channel) or (column, channel) outputs; it first reduces the tile partials of every
 // row / column its 7x7 / 5x5 window touches into LDS (the reduction used to be a launch of its own: ~13 us of a tiny grid
 // on the critical chain of every ResBlock), in the same fixed order over the tiles.
-__global__ __launch_bounds__(256) void gate_maps_kernel(int H, int W, int C, GateWs g, const float* __restrict__ cw_w,
+__global__ __launch_bounds__(256) void gate_maps_kernel(int H, int W, int C, float* ws, int64_t wsf, int lp, const float* __restrict__ cw_w,
                                                         const float* __restrict__ cw_bn, const float* __restrict__ hc_w,
                                                         const float* __restrict__ hc_bn, float* __restrict__ g1,
                                                         float* __restrict__ g2, const float* __restrict__ w1,
                                                         const float* __restrict__ b1, const float* __restrict__ w2,
                                                         const float* __restrict__ b2, float* __restrict__ s) {
+    const GateWs g = carve(ws + (size_t)blockIdx.y * wsf, H, W, C, lp != 0);      // blockIdx.y = map of a batched launch
+    g1 += (size_t)blockIdx.y * H * C;
+    g2 += (size_t)blockIdx.y * W * C;
+    s += (size_t)blockIdx.y * C;
     __shared__ float wk[98];
     __shared__ float zmax[1024], zmean[1024];          // (256/C + 6) * C <= 1024 reduced rows / columns incl. halo
     const int64_t n1 = (int64_t)H * C;
@@ -351,6 +358,11 @@ __global__ __launch_bounds__(256) void resblock_apply_kernel(const float* __rest
                                                              float* __restrict__ out, int ldo, int H, int W, int C) {
     const int cg = C / 4;
     const int64_t total = (int64_t)H * W * cg;
+    {   // batched launch (blockIdx.y = map; dense maps, ldo == C, no `extra`): this map's slices
+        const size_t b = blockIdx.y;
+        x += b * H * W * C; x1 += b * H * W * C; out += b * H * W * ldo;
+        s += b * C; g1 += b * H * C; g2 += b * W * C;
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % cg) * 4;
         const int64_t pix = i / cg;
@@ -383,10 +395,11 @@ extern "C" int64_t spei_gate_ws_floats(int H, int W, int C) {
     return 2 * ntx * H * C + 2 * nty * W * C + ntx * nty * C;
 }
 
-extern "C" int spei_resblock_gates(const void* x1, int x1_fmt, int H, int W, int C, const float* se_w1, const float* se_b1,
-                                   const float* se_w2, const float* se_b2, const float* cw_w, const float* cw_bn,
-                                   const float* hc_w, const float* hc_bn, float* s, float* g1, float* g2, float* ws,
-                                   spei_stream_t stream) {
+static int resblock_gates_run(const void* x1, int x1_fmt, int batch, int H, int W, int C, const float* se_w1, const float* se_b1,
+                              const float* se_w2, const float* se_b2, const float* cw_w, const float* cw_bn,
+                              const float* hc_w, const float* hc_bn, float* s, float* g1, float* g2, float* ws,
+                              spei_stream_t stream) {
+    SPEI_REQUIRE(batch >= 1 && batch <= 65535, "spei_resblock_gates_batched: batch=%d", batch);
     SPEI_REQUIRE(x1 && se_w1 && se_b1 && se_w2 && se_b2 && cw_w && cw_bn && hc_w && hc_bn && s && g1 && g2 && ws,
                  "spei_resblock_gates: null pointer");
     SPEI_REQUIRE(C == 32 || C == 64 || C == 128, "spei_resblock_gates: C=%d (32/64/128 built)", C);
@@ -395,38 +408,65 @@ extern "C" int spei_resblock_gates(const void* x1, int x1_fmt, int H, int W, int
     hipStream_t st = (hipStream_t)stream;
     SPEI_REQUIRE(x1_fmt == SPEI_F32 || x1_fmt == SPEI_BF16 || x1_fmt == SPEI_F16, "spei_resblock_gates: x1_fmt=%d", x1_fmt);
     GateWs g = carve(ws, H, W, C, x1_fmt != SPEI_F32);
+    const int64_t wsf = spei_gate_ws_floats(H, W, C);
     if (x1_fmt == SPEI_BF16) {
         const __bf16* xp = (const __bf16*)x1;
-        if (C == 32) launch_gate_stats<32>(xp, H, W, g, st);
-        else if (C == 64) launch_gate_stats<64>(xp, H, W, g, st);
-        else launch_gate_stats<128>(xp, H, W, g, st);
+        if (C == 32) launch_gate_stats<32>(xp, H, W, g, ws, wsf, batch, st);
+        else if (C == 64) launch_gate_stats<64>(xp, H, W, g, ws, wsf, batch, st);
+        else launch_gate_stats<128>(xp, H, W, g, ws, wsf, batch, st);
     } else if (x1_fmt == SPEI_F16) {
         const _Float16* xp = (const _Float16*)x1;
-        if (C == 32) launch_gate_stats<32>(xp, H, W, g, st);
-        else if (C == 64) launch_gate_stats<64>(xp, H, W, g, st);
-        else launch_gate_stats<128>(xp, H, W, g, st);
+        if (C == 32) launch_gate_stats<32>(xp, H, W, g, ws, wsf, batch, st);
+        else if (C == 64) launch_gate_stats<64>(xp, H, W, g, ws, wsf, batch, st);
+        else launch_gate_stats<128>(xp, H, W, g, ws, wsf, batch, st);
     } else {
         const float* xp = (const float*)x1;
-        if (C == 32) launch_gate_stats<32>(xp, H, W, g, st);
-        else if (C == 64) launch_gate_stats<64>(xp, H, W, g, st);
-        else launch_gate_stats<128>(xp, H, W, g, st);
+        if (C == 32) launch_gate_stats<32>(xp, H, W, g, ws, wsf, batch, st);
+        else if (C == 64) launch_gate_stats<64>(xp, H, W, g, ws, wsf, batch, st);
+        else launch_gate_stats<128>(xp, H, W, g, ws, wsf, batch, st);
     }
-    hipLaunchKernelGGL(gate_maps_kernel, dim3(cdiv((int64_t)H * C, 256) + cdiv((int64_t)W * C, 256) + 1), dim3(256), 0, st, H, W, C, g,
-                       cw_w, cw_bn, hc_w, hc_bn, g1, g2, se_w1, se_b1, se_w2, se_b2, s);
+    hipLaunchKernelGGL(gate_maps_kernel, dim3(cdiv((int64_t)H * C, 256) + cdiv((int64_t)W * C, 256) + 1, batch), dim3(256), 0, st, H, W, C, ws, wsf,
+                       (int)(x1_fmt != SPEI_F32), cw_w, cw_bn, hc_w, hc_bn, g1, g2, se_w1, se_b1, se_w2, se_b2, s);
     SPEI_CHECK_LAUNCH("spei_resblock_gates");
+    return 0;
+}
+
+extern "C" int spei_resblock_gates(const void* x1, int x1_fmt, int H, int W, int C, const float* se_w1, const float* se_b1,
+                                   const float* se_w2, const float* se_b2, const float* cw_w, const float* cw_bn,
+                                   const float* hc_w, const float* hc_bn, float* s, float* g1, float* g2, float* ws,
+                                   spei_stream_t stream) {
+    return resblock_gates_run(x1, x1_fmt, 1, H, W, C, se_w1, se_b1, se_w2, se_b2, cw_w, cw_bn, hc_w, hc_bn, s, g1, g2, ws, stream);
+}
+
+extern "C" int spei_resblock_gates_batched(const void* x1, int x1_fmt, int batch, int H, int W, int C, const float* se_w1, const float* se_b1,
+                                           const float* se_w2, const float* se_b2, const float* cw_w, const float* cw_bn,
+                                           const float* hc_w, const float* hc_bn, float* s, float* g1, float* g2, float* ws,
+                                           spei_stream_t stream) {
+    return resblock_gates_run(x1, x1_fmt, batch, H, W, C, se_w1, se_b1, se_w2, se_b2, cw_w, cw_bn, hc_w, hc_bn, s, g1, g2, ws, stream);
+}
+
+static int resblock_apply_run(const float* x, const void* x1, int x1_fmt, const float* s, const float* g1, const float* g2,
+                              const float* extra, float* out, int ldo, int batch, int H, int W, int C, spei_stream_t stream) {
+    SPEI_REQUIRE(x && x1 && s && g1 && g2 && out, "spei_resblock_apply: null pointer");
+    SPEI_REQUIRE(batch >= 1 && batch <= 65535 && (batch == 1 || (!extra && ldo == C)), "spei_resblock_apply_batched: dense maps, no `extra`");
+    SPEI_REQUIRE(C % 4 == 0 && ldo % 4 == 0 && ldo >= C && H > 0 && W > 0, "spei_resblock_apply: bad shape");
+    const int64_t total = (int64_t)H * W * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    const dim3 grid(blocks, batch);
+    SPEI_REQUIRE(x1_fmt == SPEI_F32 || x1_fmt == SPEI_BF16 || x1_fmt == SPEI_F16, "spei_resblock_apply: x1_fmt=%d", x1_fmt);
+    if (x1_fmt == SPEI_BF16) hipLaunchKernelGGL(resblock_apply_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, x, (const __bf16*)x1, s, g1, g2, extra, out, ldo, H, W, C);
+    else if (x1_fmt == SPEI_F16) hipLaunchKernelGGL(resblock_apply_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, x, (const _Float16*)x1, s, g1, g2, extra, out, ldo, H, W, C);
+    else hipLaunchKernelGGL(resblock_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, (const float*)x1, s, g1, g2, extra, out, ldo, H, W, C);
+    SPEI_CHECK_LAUNCH("spei_resblock_apply");
     return 0;
 }
 
 extern "C" int spei_resblock_apply(const float* x, const void* x1, int x1_fmt, const float* s, const float* g1, const float* g2,
                                    const float* extra, float* out, int ldo, int H, int W, int C, spei_stream_t stream) {
-    SPEI_REQUIRE(x && x1 && s && g1 && g2 && out, "spei_resblock_apply: null pointer");
-    SPEI_REQUIRE(C % 4 == 0 && ldo % 4 == 0 && ldo >= C && H > 0 && W > 0, "spei_resblock_apply: bad shape");
-    const int64_t total = (int64_t)H * W * (C / 4);
-    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    SPEI_REQUIRE(x1_fmt == SPEI_F32 || x1_fmt == SPEI_BF16 || x1_fmt == SPEI_F16, "spei_resblock_apply: x1_fmt=%d", x1_fmt);
-    if (x1_fmt == SPEI_BF16) hipLaunchKernelGGL(resblock_apply_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (const __bf16*)x1, s, g1, g2, extra, out, ldo, H, W, C);
-    else if (x1_fmt == SPEI_F16) hipLaunchKernelGGL(resblock_apply_kernel<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (const _Float16*)x1, s, g1, g2, extra, out, ldo, H, W, C);
-    else hipLaunchKernelGGL(resblock_apply_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (const float*)x1, s, g1, g2, extra, out, ldo, H, W, C);
-    SPEI_CHECK_LAUNCH("spei_resblock_apply");
-    return 0;
+    return resblock_apply_run(x, x1, x1_fmt, s, g1, g2, extra, out, ldo, 1, H, W, C, stream);
+}
+
+extern "C" int spei_resblock_apply_batched(const float* x, const void* x1, int x1_fmt, const float* s, const float* g1, const float* g2,
+                                           float* out, int batch, int H, int W, int C, spei_stream_t stream) {
+    return resblock_apply_run(x, x1, x1_fmt, s, g1, g2, nullptr, out, C, batch, H, W, C, stream);
 }

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import torch
 
-from .ops import ACT_GELU, ACT_RELU, CONV_T, Ctx, FMap
+from .ops import ACT_GELU, ACT_RELU, CONV_T, BMap, Ctx, FMap
 
 
 # ---- encoder / decoder stacks (reference model/recons_video_ori.py:26-77) -----------------------------
@@ -38,9 +38,35 @@ def enc(ctx: Ctx, frame: torch.Tensor, P: dict, extra=None, out=None) -> FMap:
     return enc_stage(ctx, enc_stage(ctx, in_block(ctx, frame, P["inBlock"]), P["encoder_first"]), P["encoder_second"], extra, out)
 
 
+def enc_batched(ctx: Ctx, frames: list, P: dict):
+    """The three encoder stages on ALL of a frame's passes at once: frames = [3,H,W] tensors (the window's frames, their
+    Richardson-Lucy priors, the sharp reference; model/speinet.py:82-83,125-131 run the same recons_net stacks on each).  Every
+    layer is one launch over the stacked maps (ops.BMap); per map the kernels, tiles and arithmetic are those of `enc` — the
+    results are bit-identical to one pass at a time.  Returns the three levels as BMaps."""
+    ctx = ctx.for_stage("enc")
+    assert ctx.batched_available()
+    b, (h, w) = len(frames), frames[0].shape[-2:]
+    ib = P["inBlock"]
+    lv1 = BMap.empty(b, h, w, ib["head_b"].numel(), frames[0].device)
+    lib_in = lambda i: ctx.conv5_in(frames[i], ib["head_w"], ib["head_b"], out=lv1.map(i))     # persistent, full-chip launches already
+    for i in range(b):
+        lib_in(i)
+    for pk in ib["blocks"]:
+        lv1 = ctx.resblock_batched(lv1, pk)
+    levels = [lv1]
+    f = lv1
+    for name in ("encoder_first", "encoder_second"):
+        st = P[name]
+        f = ctx.igemm_batched(f, st["head_w"], st["head_b"], st["head_b"].numel(), 5, stride=2, act=ACT_RELU)
+        for pk in st["blocks"]:
+            f = ctx.resblock_batched(f, pk)
+        levels.append(f)
+    return levels
+
+
 def dec_stage(ctx: Ctx, f: FMap, pk: dict) -> FMap:
     f = _resblocks(ctx, f, pk["blocks"])
-    return ctx.igemm(f, pk["tail_w"], pk["tail_b"], pk["tail_b"].numel(), ksize=3, stride=2, mode=CONV_T, act=ACT_RELU)
+    return ctx.for_stage("convt").igemm(f, pk["tail_w"], pk["tail_b"], pk["tail_b"].numel(), ksize=3, stride=2, mode=CONV_T, act=ACT_RELU)
 
 
 # ---- cross-window-attention SwinIR (reference model/swinir.py:763-810) ---------------------------------
@@ -164,7 +190,8 @@ def self_transfer(ctx: Ctx, f_fusion: FMap, P: dict):
 # ---- decode (reference model/speinet.py:92-120) -----------------------------------------------------------
 def decode(ctx: Ctx, ff: FMap, s: torch.Tensor, t3: FMap, t2: FMap, t1: FMap, P: dict, out: torch.Tensor) -> torch.Tensor:
     ctx = ctx.for_stage("decode")
-    g = ctx.for_stage("glue")        # the 1x1 / 3x3 convs between the stacks (conv_lv*, search*): 1 % of the frame's FLOPs
+    g = ctx.for_stage("glue")        # the 1x1 / 3x3 convs between the stacks (conv_lv*, search*; 1 % of the frame's FLOPs) at H/4, H/2
+    g1 = ctx.for_stage("glue1")      # ... and at full resolution
     c = lambda name: (P[name]["w"], P[name]["b"])
     h3, w3 = ff.H, ff.W
     smap = FMap(s.view(h3 * w3, 1), h3, w3, 1)
@@ -178,13 +205,13 @@ def decode(ctx: Ctx, ff: FMap, s: torch.Tensor, t3: FMap, t2: FMap, t1: FMap, P:
     f_lv2 = g.igemm(f_lv2, *c("search2"), 64, a1=sr2, act=ACT_RELU, residual=f_lv2)
     dec1 = dec_stage(ctx.for_stage("dec1"), f_lv2, P["decoder_first"])
     s4 = ctx.upsample(smap, 4).t.view(-1)
-    f_lv1 = g.igemm(dec1, *c("conv_lv1"), 32, a1=t1, rowscale=s4, residual=dec1)
+    f_lv1 = g1.igemm(dec1, *c("conv_lv1"), 32, a1=t1, rowscale=s4, residual=dec1)
     s13 = g.up_conv1x1_relu(f_v3, *c("search13"), 32)
-    s23 = g.igemm(ctx.upsample(f_lv2, 2), *c("search33"), 32, ksize=3, act=ACT_RELU)
-    s33 = g.igemm(f_lv1, *c("search43"), 32, ksize=3, act=ACT_RELU)
-    acc = g.igemm(s13, *c("search33"), 32, ksize=3, a1=s23, act=ACT_RELU, residual=f_lv1)
-    g.igemm(s13, *c("search33"), 32, ksize=3, a1=s33, act=ACT_RELU, residual=acc, out=acc)
-    g.igemm(s23, *c("search33"), 32, ksize=3, a1=s33, act=ACT_RELU, residual=acc, out=acc)
+    s23 = g1.igemm(ctx.upsample(f_lv2, 2), *c("search33"), 32, ksize=3, act=ACT_RELU)
+    s33 = g1.igemm(f_lv1, *c("search43"), 32, ksize=3, act=ACT_RELU)
+    acc = g1.igemm(s13, *c("search33"), 32, ksize=3, a1=s23, act=ACT_RELU, residual=f_lv1)
+    g1.igemm(s13, *c("search33"), 32, ksize=3, a1=s33, act=ACT_RELU, residual=acc, out=acc)
+    g1.igemm(s23, *c("search33"), 32, ksize=3, a1=s33, act=ACT_RELU, residual=acc, out=acc)
     ob = P["outBlock"]
     ctx = ctx.for_stage("out")
     f = _resblocks(ctx, acc, ob["blocks"])
@@ -223,6 +250,34 @@ def forward_sample_steps(ctx: Ctx, x: torch.Tensor, P: dict, n_seq: int, has_ref
     dev = x.device
     lanes = _lanes(ctx, sides)
     main = lanes[0]
+    if ctx.for_stage("enc").batched_available():
+        # all encoder passes of the frame in one launch per layer (main stream), then the two swin calls side by side
+        mid = x[n_seq // 2]
+        others = [i for i in range(n_seq) if i != n_seq // 2]
+        frames = [mid, ctx.rl_prior(mid, 5, 0.01)]
+        for i in others:
+            frames += [x[i], ctx.rl_prior(x[i], 1, 0.01)]
+        if has_ref:
+            frames.append(x[n_seq + 1])
+        lv1, lv2, lv3 = enc_batched(ctx, frames, P)
+        cat = FMap(torch.empty(h3 * w3, 128 * n_seq, device=dev), h3, w3, 128 * n_seq)
+        f_mid = FMap(ctx.add(lv3.map(1).t, lv3.map(0).t), h3, w3, 128)                 # enc(RL5(mid)) + enc(mid)   (speinet.py:130-132)
+        cat.t[:, :128].copy_(f_mid.t)
+        feats = [FMap(ctx.add(lv3.map(3 + 2 * k).t, lv3.map(2 + 2 * k).t), h3, w3, 128) for k in range(len(others))]
+        lv = (lv1.map(len(frames) - 1), lv2.map(len(frames) - 1), lv3.map(len(frames) - 1)) if has_ref else None
+        sx = SwinX(ctx, f_mid, P["swin"])
+        ready = torch.cuda.Event()
+        ready.record(main)
+        for slot, feat in enumerate(feats, start=1):
+            lane = lanes[(slot - 1) % len(lanes)]
+            if lane is not main:
+                lane.wait_event(ready)
+            with torch.cuda.stream(lane):
+                swin(ctx, sx, feat, P["swin"], out=cat.view(128 * slot, 128))
+        for s_ in lanes[1:]:
+            main.wait_stream(s_)                  # join
+        yield from _tail(ctx, cat, lv, P, out)
+        return
     for s_ in lanes[1:]:
         s_.wait_stream(main)                      # fork: the input frames (and anything before them) are ready
     lv = None
@@ -238,11 +293,11 @@ def forward_sample_steps(ctx: Ctx, x: torch.Tensor, P: dict, n_seq: int, has_ref
     ready.record(main)
     for slot, i in enumerate([i for i in range(n_seq) if i != n_seq // 2], start=1):
         lane = lanes[(slot - 1) % len(lanes)]
-        if lane is not main:
-            lane.wait_event(ready)
         with torch.cuda.stream(lane):
-            e = enc(ctx, x[i], P)
+            e = enc(ctx, x[i], P)                      # the neighbour frame's own passes need nothing from the middle frame:
             feat = enc(ctx, ctx.rl_prior(x[i], 1, 0.01), P, extra=e)
+            if lane is not main:
+                lane.wait_event(ready)                 # ... only its swin call does (f_mid, conv_first(f_mid))
             swin(ctx, sx, feat, P["swin"], out=cat.view(128 * slot, 128))
             del e, feat
     for s_ in lanes[1:]:

@@ -81,6 +81,29 @@ class FMap:
         return FMap(x.permute(1, 2, 0).reshape(h * w, c).contiguous().float(), h, w, c)
 
 
+class BMap:
+    """`B` dense NHWC maps of one shape stacked in one buffer [B*H*W, C] (fp32 or the mode's 16-bit format): the frame's encoder
+    passes through one layer, launched together (gridDim.y = map; csrc/conv_slab16.hip, resblock.hip).  `map(b)` is map b as an FMap
+    view."""
+    __slots__ = ("t", "B", "H", "W", "C")
+
+    def __init__(self, t: torch.Tensor, B: int, H: int, W: int, C_: int):
+        assert t.is_cuda and t.is_contiguous() and t.shape == (B * H * W, C_)
+        self.t, self.B, self.H, self.W, self.C = t, B, H, W, C_
+
+    @staticmethod
+    def empty(B: int, H: int, W: int, C_: int, device, dtype=torch.float32) -> "BMap":
+        return BMap(torch.empty(B * H * W, C_, device=device, dtype=dtype), B, H, W, C_)
+
+    @property
+    def fmt(self) -> int:
+        return fmt_of(self.t.dtype)
+
+    def map(self, b: int) -> FMap:
+        n = self.H * self.W
+        return FMap(self.t[b * n:(b + 1) * n], self.H, self.W, self.C)
+
+
 def _vp(p) -> C.c_void_p:
     return C.c_void_p(p)
 
@@ -152,6 +175,10 @@ class Ctx:
                       frame's FLOPs and where the half-operand error weighs most on the `_forwardb` branch: |dPSNR| against the
                       reference on that branch 0.9-1.07e-3 dB -> 1.4-4.6e-4 (every golden <= 4.6e-4; profiles/r03_parity_ablation.txt),
                       for 1.35 ms of a 30.3 ms frame.  Off: round 2's arithmetic (tests then hold 1e-3 dB with no margin on that branch)
+      batch_enc       16-bit: the frame's 7 encoder passes (6 without a sharp reference) go through every layer of the three encoder
+                      stages in ONE launch per layer (gridDim.y = pass; engine.enc_batched) instead of one launch per pass and layer:
+                      bit-identical frames, ~1000 fewer launches per frame, and at H/4 a launch has 3150 workgroups instead of 450
+                      (three resident rounds instead of half of one).  Off: round 2's per-pass launches on two streams
       corr_bf16       "f16" with corr "top2": the candidate pass of the correlation runs on bf16 operands (True, default) instead of
                       f16.  The fp32 re-score decides the winner and S either way (G14: 16 more of 57600 positions differ, dPSNR
                       +1e-6 dB); bf16 operands let the chip hold a ~7 % higher MFMA clock on this kernel (tools/bench_corr.py)
@@ -164,15 +191,15 @@ class Ctx:
     ACT_NONE, ACT_RELU, ACT_GELU = ACT_NONE, ACT_RELU, ACT_GELU
     CONV, CONV_T = CONV, CONV_T
     _FIELDS = ("precision", "corr_precision", "device", "use_slab", "bf16_storage", "x1_bf16", "fuse_mlp", "fuse_attn",
-               "fuse_block", "commute_upconv", "commute_any", "corr_bf16", "fuse_apply", "split_decode", "stage", "profile", "capture")
+               "fuse_block", "commute_upconv", "commute_any", "corr_bf16", "fuse_apply", "split_decode", "batch_enc", "stage", "profile", "capture")
     # stages of an f16 frame that run in split (bf16x3) arithmetic by default, see `split_decode`
-    SPLIT_STAGES = ("glue", "dec2")
+    SPLIT_STAGES = ("glue", "glue1", "dec2")
     __slots__ = _FIELDS
 
     def __init__(self, precision: str = "f32", corr_precision: str = "bf16x3", device=None, use_slab: bool = True,
                  bf16_storage: bool = True, x1_bf16: bool = True, fuse_mlp: bool = True, fuse_attn: bool = True,
                  fuse_block: bool = False, commute_upconv: bool = True, commute_any: bool = False, corr_bf16: bool = True,
-                 fuse_apply: bool = False, split_decode: bool = True,
+                 fuse_apply: bool = False, split_decode: bool = True, batch_enc: bool = True,
                  stage: Optional[dict] = None,
                  profile: Optional[dict] = None, capture: Optional[dict] = None):
         if precision not in PRECISIONS:
@@ -193,7 +220,7 @@ class Ctx:
         object.__setattr__(self, "device", device)
         for k, v in (("use_slab", use_slab), ("bf16_storage", bf16_storage), ("x1_bf16", x1_bf16), ("fuse_mlp", fuse_mlp),
                      ("fuse_attn", fuse_attn), ("fuse_block", fuse_block), ("commute_upconv", commute_upconv), ("commute_any", commute_any),
-                     ("corr_bf16", corr_bf16), ("fuse_apply", fuse_apply), ("split_decode", split_decode)):
+                     ("corr_bf16", corr_bf16), ("fuse_apply", fuse_apply), ("split_decode", split_decode), ("batch_enc", batch_enc)):
             object.__setattr__(self, k, bool(v))
         object.__setattr__(self, "stage", dict(stage) if stage else {})
         object.__setattr__(self, "profile", profile)
@@ -261,10 +288,12 @@ class Ctx:
                    "spei_rl_prior")
         return out
 
-    def conv5_in(self, img: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> FMap:
+    def conv5_in(self, img: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: Optional[FMap] = None) -> FMap:
         c, h, wd = img.shape
         assert c == 3
-        out = FMap.empty(h, wd, b.numel(), img.device)
+        if out is None:
+            out = FMap.empty(h, wd, b.numel(), img.device)
+        assert (out.H, out.W, out.C, out.ld, out.off) == (h, wd, b.numel(), b.numel(), 0) and not out.lp
         _lib.check(_lib.lib().spei_conv5_in(self._tp(img), self._tp(w), self._tp(b), self._fp(out), h, wd, b.numel(), self._stream()),
                    "spei_conv5_in")
         return out
@@ -407,6 +436,44 @@ class Ctx:
         _lib.check(_lib.lib().spei_resblock_apply(self._fp(x), self._fp(x1), x1.fmt, self._tp(s), self._tp(g1), self._tp(g2),
                                                   self._fp(extra), self._fp(out), out.ld, x.H, x.W, c, self._stream()),
                    "spei_resblock_apply")
+        return out
+
+    # ---- the same stacks on several maps per launch (the frame's encoder passes) -------------------------------------------------
+    def batched_available(self) -> bool:
+        """One launch per layer for all maps of a BMap: the single-product 16-bit modes on the slab kernel."""
+        return self.lp16 and self.use_slab and self.x1_bf16 and self.bf16_storage and not self.fuse_apply and self.batch_enc
+
+    def igemm_batched(self, a: BMap, w, bias: torch.Tensor, N: int, ksize: int, stride: int = 1, act: int = ACT_NONE,
+                      out_dtype=torch.float32) -> BMap:
+        assert self.batched_available() and not torch.is_tensor(w) and w.fhi is not None
+        pad = ksize // 2
+        ho, wo = (a.H + 2 * pad - ksize) // stride + 1, (a.W + 2 * pad - ksize) // stride + 1
+        assert tuple(w.shape) == (ksize * ksize, N, a.C) and a.t.dtype in (torch.float32, LP_DTYPE[self.fmt])
+        out = BMap.empty(a.B, ho, wo, N, a.t.device, out_dtype)
+        tp = self._tp
+        _lib.check(_lib.lib().spei_conv_slab16_batched(self.fmt, tp(a.t), a.C, a.fmt, tp(w.frag(self.fmt)), tp(bias), tp(out.t), out.fmt, a.B,
+                                                       a.H, a.W, ho, wo, N, ksize, stride, pad, act, self._stream()), "spei_conv_slab16_batched")
+        return out
+
+    def resblock_batched(self, x: BMap, pk: dict) -> BMap:
+        """`resblock` on every map of x: conv1, conv2, gate statistics, gate maps and the gated sum are ONE launch each."""
+        idt = self.inter_dtype()
+        c, dev = x.C, x.t.device
+        lib = _lib.lib()
+        tp = self._tp
+        t = self.igemm_batched(x, pk["w1"], pk["b1"], c, 5, act=ACT_RELU, out_dtype=idt)
+        x1 = self.igemm_batched(t, pk["w2"], pk["b2"], c, 5, out_dtype=idt)
+        del t
+        s = torch.empty(x.B, c, device=dev)
+        g1 = torch.empty(x.B, x.H, c, device=dev)
+        g2 = torch.empty(x.B, x.W, c, device=dev)
+        ws = torch.empty(x.B * lib.spei_gate_ws_floats(x.H, x.W, c), device=dev)
+        _lib.check(lib.spei_resblock_gates_batched(tp(x1.t), x1.fmt, x.B, x.H, x.W, c, tp(pk["se_w1"]), tp(pk["se_b1"]), tp(pk["se_w2"]),
+                                                   tp(pk["se_b2"]), tp(pk["cw_w"]), tp(pk["cw_bn"]), tp(pk["hc_w"]), tp(pk["hc_bn"]),
+                                                   tp(s), tp(g1), tp(g2), tp(ws), self._stream()), "spei_resblock_gates_batched")
+        out = BMap.empty(x.B, x.H, x.W, c, dev)
+        _lib.check(lib.spei_resblock_apply_batched(tp(x.t), tp(x1.t), x1.fmt, tp(s), tp(g1), tp(g2), tp(out.t), x.B, x.H, x.W, c,
+                                                   self._stream()), "spei_resblock_apply_batched")
         return out
 
     # ---- Swin (K6-K9) ------------------------------------------------------------------------------------------

@@ -487,7 +487,9 @@ class SPEINet(nn.Module):
         segments around the correlation arg-max kernel, which is launched directly between them: that costs two extra
         launches per frame and lets a caller bracket the path's dominant kernel with HIP events on the launch stream
         (`profile`, bench.py) inside the very run it times."""
-        key = (tuple(x.shape), tuple(zero_ref)) + self._mode_key(x.device)
+        # one captured instance per launch stream: a caller that keeps two frames in flight (bench.py --inflight 2: frame i + 1's
+        # encoder passes under frame i's correlation / decoder) calls forward from two streams, and each needs its own static buffers
+        key = (tuple(x.shape), tuple(zero_ref), torch.cuda.current_stream(x.device).cuda_stream) + self._mode_key(x.device)
         g = self._graphs.get(key)
         if g is None:
             sides = self._sides(x.device)

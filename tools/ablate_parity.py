@@ -54,6 +54,10 @@ CONFIGS = [
     ("f16 / corr bf16x3", "f16", "bf16x3", {"stage": {"search": {"precision": "bf16x3"}}}),
     ("f16 / corr top2  (bench mode)", "f16", "top2", {}),
     ("f16 / corr top2, split_decode off (round 2)", "f16", "top2", {"split_decode": False}),
+    ("f16, split glue(H/4,H/2) + dec2", "f16", "top2", {"split_decode": False, "stage": {"glue": {"precision": "bf16x3", "commute_any": True}, "dec2": {"precision": "bf16x3", "commute_any": True}}}),
+    ("f16, split glue(all) + dec2 resblocks (convT f16)", "f16", "top2", {"stage": {"convt": {"precision": "f16"}}}),
+    ("f16, split glue(H/4,H/2) + dec2 resblocks", "f16", "top2", {"split_decode": False, "stage": {"glue": {"precision": "bf16x3", "commute_any": True}, "dec2": {"precision": "bf16x3", "commute_any": True}, "convt": {"precision": "f16"}}}),
+    ("f16, split glue(H) + dec2", "f16", "top2", {"split_decode": False, "stage": {"glue1": {"precision": "bf16x3", "commute_any": True}, "dec2": {"precision": "bf16x3", "commute_any": True}}}),
     ("f16 / corr single", "f16", "single", {}),
     ("f16 top2, x1 fp32", "f16", "top2", {"x1_bf16": False}),
     ("f16 top2, fp32 storage", "f16", "top2", {"bf16_storage": False}),
