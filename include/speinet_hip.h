@@ -134,6 +134,13 @@ int spei_mlp_fused16(int fmt, const float* x, float* out, const void* w1_frag, c
 int spei_mlp_tok16(int fmt, const float* x, float* out, const void* wstream, const float* b1, const float* b2, int64_t M,
                    spei_stream_t stream);
 
+/* The attention branch of spei_attn_fused16, token-stationary (round 3, csrc/swin_tok16.hip): a wave owns one 5x5 window from the
+ * first load to the last store; Q^T, K^T, V, S^T, O^T and the projection's B operand never leave its registers; the weights arrive
+ * through the LDS ring (wstream: speinet_amd/pack.py AttnStreamW, 16 chunks of 32 fragments).  relb28: [8][25][28] relative position
+ * bias, key axis padded.  x, out: [H*W][256] fp32, must NOT alias; yhat as for spei_attn_fused16. */
+int spei_attn_tok16(int fmt, const float* x, float* out, const void* yhat, const void* wstream, const float* bq, const float* bkv,
+                    const float* bproj, const float* relb28, int H, int W, int shift, spei_stream_t stream);
+
 /* ConvTranspose2d(k = 3, stride 2, padding 1, output_padding 1) on the slab kernel (reference model/recons_video_ori.py:58-71,
  * the tails of decoder_second / decoder_first): the four output-parity classes are stride-1 convolutions over the input
  * grid with 1 / 2 / 2 / 4 taps, written with pixel stride 2.  wfrag<py><px>: fragment-ordered 16-bit weights of class

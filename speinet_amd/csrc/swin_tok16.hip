@@ -255,6 +255,275 @@ __global__ __launch_bounds__(64 * NW) void mlp_tok_kernel(const MlpTokParams<LP>
     SPEI_STAMP(p.stamps, 5);
 }
 
+
+// =====================================================================================================================================
+//     spei_attn_tok16:   out = x + proj( W-MSA( q = yhat Wq,  [k, v] = LayerNorm(x) Wkv ) )      (reference model/swinir.py:238-278, :115-149)
+//
+// A wave owns ONE 5x5 window (25 of its 32 lanes) from the first load to the last store.  Weight stream (pack.AttnStreamW), 16 chunks
+// of 32 fragments:  0-3 Wq (two heads each) | 4-11 head h: Wk_h, Wv_h | 12-15 Wproj (two 32-channel output tiles each, input
+// channels in accumulator order).  Per head everything stays in registers, as in attn_fused16.hip: Q^T_h, K^T_h (weights = A operand)
+// and V_h (tokens = A operand), S^T = K Q^T and O^T = V^T P^T straight from the accumulators; new here: the operands are the lane's
+// own LayerNorm / y-hat fragments (no LDS slab, no staging barrier), O^T_h is handed to the projection as its B operand (no LDS
+// exchange between waves), and the weights arrive through the shared ring.
+template <typename LP>
+struct AttnTokParams {
+    const float* x;
+    float* out;
+    const LP* yhat;                 // [M][256]
+    const unsigned char* wstream;   // 16 chunks x 32 fragments
+    const float* bq;                // [256] (scale folded)
+    const float* bkv;               // [512]
+    const float* bproj;             // [256]
+    const float* relb;              // [8][25][28]: relative position bias, key axis padded to 28 (pack.AttnStreamW)
+    long long* stamps;
+    int H, W, shift, nwin;
+    int dbg;
+};
+
+constexpr int RELB_FLOATS = 8 * 25 * 28;
+
+__device__ __forceinline__ void wait_vm(int n) {        // s_waitcnt vmcnt(n) for the counts this file uses (n is a constant after unrolling)
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+__device__ __forceinline__ int mask_region(int v, int n, int shift) { return v < n - 5 ? 0 : (v < n - shift ? 1 : 2); }
+
+template <typename LP, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_tok_kernel(const AttnTokParams<LP> p) {
+    typedef typename lpv<LP>::x8 lp8;
+    static_assert(NW == 8 || NW == 4, "ring shares: 32 fragments per chunk over NW waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // ring | relb | bq | bkv | bproj
+    float* relb = reinterpret_cast<float*>(smem + RING * CHUNK);
+    float* sbq = relb + RELB_FLOATS;
+    float* sbkv = sbq + 256;
+    float* sbp = sbkv + 512;
+    constexpr int PER = 32 / NW;
+    constexpr int PD = 3;
+    constexpr int NCH = 16;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, h = lane >> 5;
+    const unsigned char* wsrc = p.wstream + lane * 16;
+    auto issue = [&](int c) {
+        glds_run<PER>(wsrc + (size_t)(c * 32 + wave * PER) * FRAG, smem + (c & (RING - 1)) * CHUNK + wave * PER * FRAG);
+    };
+    SPEI_STAMP(p.stamps, 0);
+    issue(0);
+    issue(1);
+    for (int i = tid; i < RELB_FLOATS; i += 64 * NW) relb[i] = p.relb[i];
+    for (int i = tid; i < 256; i += 64 * NW) { sbq[i] = p.bq[i]; sbp[i] = p.bproj[i]; }
+    for (int i = tid; i < 512; i += 64 * NW) sbkv[i] = p.bkv[i];
+
+    // ---- the lane's token: window `win`, position fr of its 25 (lanes 25..31 idle: zero operands, no stores) ----------------
+    const int nwx = p.W / 5;
+    const int win = blockIdx.x * NW + wave;
+    const bool wok = win < p.nwin;
+    const int wc = wok ? win : p.nwin - 1;
+    const int wy = wc / nwx, wx = wc - wy * nwx;
+    const int tq = fr < 25 ? fr : 0;
+    const int ysf = wy * 5 + tq / 5, xsf = wx * 5 + tq % 5;              // shifted-frame coordinates
+    int yo = ysf + p.shift, xo = xsf + p.shift;                          // roll(-shift): shifted[y] = x[(y + shift) % H]
+    if (yo >= p.H) yo -= p.H;
+    if (xo >= p.W) xo -= p.W;
+    const size_t pix = (size_t)yo * p.W + xo;
+    const bool tok = wok && fr < 25;
+    // shift mask: bit r = the key of accumulator row r lies in another region than the lane's query (model/swinir.py:215-236)
+    unsigned mbits = 0u;
+    if (p.shift > 0) {
+        const int qreg = 3 * mask_region(ysf, p.H, p.shift) + mask_region(xsf, p.W, p.shift);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = min((r & 3) + 8 * (r >> 2) + 4 * h, 24);
+            const int kreg = 3 * mask_region(wy * 5 + key / 5, p.H, p.shift) + mask_region(wx * 5 + key % 5, p.W, p.shift);
+            if (kreg != qreg) mbits |= 1u << r;
+        }
+    }
+
+    // ---- y-hat fragments: the lane's 16 B of every k-step, straight from HBM (B operand of Q^T = Wq y^T) -------------------------
+    lp8 yh[16];
+    {
+        const LP* yp = p.yhat + pix * D + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            yh[s] = *reinterpret_cast<const lp8*>(yp + 16 * s);
+            if (!tok) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) yh[s][j] = (LP)0.0f;
+            }
+        }
+    }
+    lp8 fq[PD];
+    const unsigned lds0 = (unsigned)(uintptr_t)smem + lane * 16;
+    lp8 qo[8][2];                                   // Q^T_h as the B operand of S^T, later O^T_h as the B operand of the projection
+    lp8 xh[16];                                     // LayerNorm(x) of the lane's token: B operand of K^T, A operand of V
+    auto bias_rows = [&](const float* b32) {        // accumulator initialised with a per-ROW bias (rows = 32 channels at b32)
+        f32x16 a;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(b32 + 8 * g + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[4 * g + e] = bv[e];
+        }
+        return a;
+    };
+
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        // own share of chunk c landed; everybody's; everybody done with chunk c - 2's slot.  VM operations issued after chunk c's
+        // LDS-DMA that may stay in flight: chunk c + 1's, plus the stores (and their residual loads) of a projection chunk
+        wait_vm(c + 1 < NCH ? PER + (c >= 13 ? 16 : 0) : (c >= 13 ? 16 : 0));
+        if (!(TOK_DBG & 4)) __builtin_amdgcn_s_barrier();
+        if (c + 2 < NCH) issue(c + 2);
+        const unsigned slot = lds0 + (c & (RING - 1)) * CHUNK;
+        if (c < 4) {
+            // ---- Q^T of heads 2c, 2c + 1 ---------------------------------------------------------------------------------
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int head = 2 * c + hh;
+                f32x16 acc = bias_rows(sbq + head * 32);
+                lds_pre<PD>(fq, slot + hh * 16 * FRAG);
+                __builtin_amdgcn_s_setprio(1);
+                lds_pipe<PD, 0>(fq, slot + hh * 16 * FRAG, [&](auto ic, const lp8& a) { acc = mfma16(a, yh[decltype(ic)::value], acc); });
+                __builtin_amdgcn_s_setprio(0);
+                qo[head][0] = acc_frag<0, LP>(acc);
+                qo[head][1] = acc_frag<1, LP>(acc);
+            }
+            if (c == 3) {
+                // ---- LayerNorm(256) of the lane's token (the y-hat registers are free now) ------------------------------------
+                SPEI_STAMP(p.stamps, 1);
+                // two sweeps over the lane's half row, 4 k-steps (32 registers) at a time — the registers of a whole fp32 row on top of
+                // the Q fragments do not exist: first the moments (var = E[x^2] - mean^2 in fp32), then normalise and pack; the second
+                // sweep is served by L2
+                const float* xp = p.x + pix * D + 8 * h;
+                float sum = 0.f, sq = 0.f;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    f32x4 xr[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) xr[u] = *reinterpret_cast<const f32x4*>(xp + 64 * s4 + 16 * (u >> 1) + 4 * (u & 1));
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        sum += (xr[u][0] + xr[u][1]) + (xr[u][2] + xr[u][3]);
+                        sq += (xr[u][0] * xr[u][0] + xr[u][1] * xr[u][1]) + (xr[u][2] * xr[u][2] + xr[u][3] * xr[u][3]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const float mean = xor_combine<32, OpSum>(sum) * (1.0f / 256.0f);
+                const float var = fmaxf(xor_combine<32, OpSum>(sq) * (1.0f / 256.0f) - mean * mean, 0.f);
+                const float rstd = tok ? 1.0f / sqrtf(var + 1e-5f) : 0.f;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    f32x4 xr[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) xr[u] = *reinterpret_cast<const f32x4*>(xp + 64 * s4 + 16 * (u >> 1) + 4 * (u & 1));
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) xh[4 * s4 + (u >> 1)][4 * (u & 1) + e] = to_lp<LP>((xr[u][e] - mean) * rstd);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                SPEI_STAMP(p.stamps, 2);
+            }
+        } else if (c < 12) {
+            // ---- head c - 4: K^T, V, then the window's attention, all in registers ---------------------------------------------
+            const int head = c - 4;
+            f32x16 kT = bias_rows(sbkv + head * 32);
+            lds_pre<PD>(fq, slot);
+            __builtin_amdgcn_s_setprio(1);
+            lds_pipe<PD, 0>(fq, slot, [&](auto ic, const lp8& a) { kT = mfma16(a, xh[decltype(ic)::value], kT); });
+            __builtin_amdgcn_s_setprio(0);
+            // S^T[key][query] = sum_d K^T[d][key] Q^T[d][query]
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+            st = mfma16(acc_frag<0, LP>(kT), qo[head][0], st);
+            st = mfma16(acc_frag<1, LP>(kT), qo[head][1], st);
+            const float* rbp = relb + (head * 25 + tq) * 28 + 4 * h;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 rb = *reinterpret_cast<const f32x4*>(rbp + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const int key = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    float v = -INFINITY;
+                    if (key < 25) {
+                        v = st[r] + rb[e];
+                        if (mbits >> r & 1) v += -100.0f;
+                    }
+                    st[r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __expf(st[r] - mx);
+                st[r] = e;
+                sum += e;
+            }
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] *= inv;
+            const lp8 pf0 = acc_frag<0, LP>(st), pf1 = acc_frag<1, LP>(st);       // P^T packed before V is computed: K^T, S^T are dead by then
+            f32x16 vv;
+            {
+                const float bv = sbkv[256 + head * 32 + fr];                  // V: tokens on the rows, channel d = the lane's column
+#pragma unroll
+                for (int r = 0; r < 16; ++r) vv[r] = bv;
+            }
+            lds_pre<PD>(fq, slot + 16 * FRAG);
+            __builtin_amdgcn_s_setprio(1);
+            lds_pipe<PD, 0>(fq, slot + 16 * FRAG, [&](auto ic, const lp8& a) { vv = mfma16(xh[decltype(ic)::value], a, vv); });
+            __builtin_amdgcn_s_setprio(0);
+            // O^T[d][query] = sum_key V[key][d] P^T[key][query]
+            f32x16 ot;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[r] = 0.f;
+            ot = mfma16(acc_frag<0, LP>(vv), pf0, ot);
+            ot = mfma16(acc_frag<1, LP>(vv), pf1, ot);
+            qo[head][0] = acc_frag<0, LP>(ot);
+            qo[head][1] = acc_frag<1, LP>(ot);
+            if (c == 11) SPEI_STAMP(p.stamps, 3);
+        } else {
+            // ---- projection, output channels 64 (c - 12) .. +64: out^T = Wproj O^T, + bias + residual x, 16-byte accesses ----------
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * (c - 12) + jj;
+                f32x16 acc = bias_rows(sbp + j * 32);
+                lds_pre<PD>(fq, slot + jj * 16 * FRAG);
+                __builtin_amdgcn_s_setprio(1);
+                lds_pipe<PD, 0>(fq, slot + jj * 16 * FRAG, [&](auto ic, const lp8& a) {
+                    constexpr int i = decltype(ic)::value;
+                    acc = mfma16(a, qo[i >> 1][i & 1], acc);
+                });
+                __builtin_amdgcn_s_setprio(0);
+                f32x4 res[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) res[g] = *reinterpret_cast<const f32x4*>(p.x + pix * D + 32 * j + 8 * g + 4 * h);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = acc[4 * g + e] + res[g][e];
+                    if (tok) *reinterpret_cast<f32x4*>(p.out + pix * D + 32 * j + 8 * g + 4 * h) = o;
+                }
+            }
+        }
+    }
+    SPEI_STAMP(p.stamps, 4);
+}
+
 }  // namespace
 
 template <typename LP>
@@ -280,4 +549,34 @@ extern "C" int spei_mlp_tok16(int fmt, const float* x, float* out, const void* w
     hipStream_t st = (hipStream_t)stream;
     if (fmt == SPEI_F16) return mlp_tok_launch<_Float16>(x, out, wstream, b1, b2, M, st);
     return mlp_tok_launch<__bf16>(x, out, wstream, b1, b2, M, st);
+}
+
+template <typename LP>
+static int attn_tok_launch(const float* x, float* out, const void* yhat, const void* wstream, const float* bq, const float* bkv,
+                           const float* bproj, const float* relb, int H, int W, int shift, hipStream_t st) {
+    constexpr int NW = 8;
+    AttnTokParams<LP> p;
+    p.x = x; p.out = out; p.yhat = (const LP*)yhat; p.wstream = (const unsigned char*)wstream; p.bq = bq; p.bkv = bkv; p.bproj = bproj;
+    p.relb = relb; p.H = H; p.W = W; p.shift = shift; p.nwin = (H / 5) * (W / 5);
+    p.stamps = spei_stamp_buffer();
+    p.dbg = spei_knob("SPEI_TOK_DBG", 0);
+    const size_t lds = (size_t)RING * CHUNK + (RELB_FLOATS + 1024) * sizeof(float);
+    ensure_dyn_lds<&attn_tok_kernel<LP, NW>>(lds);
+    hipLaunchKernelGGL((attn_tok_kernel<LP, NW>), dim3(cdiv(p.nwin, NW)), dim3(64 * NW), lds, st, p);
+    SPEI_CHECK_LAUNCH("spei_attn_tok16");
+    return 0;
+}
+
+extern "C" int spei_attn_tok16(int fmt, const float* x, float* out, const void* yhat, const void* wstream, const float* bq, const float* bkv,
+                               const float* bproj, const float* relb28, int H, int W, int shift, spei_stream_t stream) {
+    SPEI_REQUIRE(x && out && yhat && wstream && bq && bkv && bproj && relb28, "spei_attn_tok16: null pointer");
+    SPEI_REQUIRE(fmt == SPEI_BF16 || fmt == SPEI_F16, "spei_attn_tok16: fmt=%d", fmt);
+    SPEI_REQUIRE(H > 0 && W > 0 && H % 5 == 0 && W % 5 == 0, "spei_attn_tok16: %dx%d is not a multiple of the 5x5 window", H, W);
+    SPEI_REQUIRE(shift >= 0 && shift < 5, "spei_attn_tok16: shift=%d", shift);
+    SPEI_REQUIRE((int64_t)H * W < (1ll << 30), "spei_attn_tok16: map too large");
+    SPEI_REQUIRE(out != x, "spei_attn_tok16: out must not alias x (a window's residual rows are re-read after other windows have stored theirs)");
+    SPEI_REQUIRE(((uintptr_t)x | (uintptr_t)out | (uintptr_t)yhat | (uintptr_t)wstream | (uintptr_t)relb28) % 16 == 0, "spei_attn_tok16: 16-byte alignment required");
+    hipStream_t st = (hipStream_t)stream;
+    if (fmt == SPEI_F16) return attn_tok_launch<_Float16>(x, out, yhat, wstream, bq, bkv, bproj, relb28, H, W, shift, st);
+    return attn_tok_launch<__bf16>(x, out, yhat, wstream, bq, bkv, bproj, relb28, H, W, shift, st);
 }

@@ -251,32 +251,7 @@ def forward_sample_steps(ctx: Ctx, x: torch.Tensor, P: dict, n_seq: int, has_ref
     lanes = _lanes(ctx, sides)
     main = lanes[0]
     if ctx.for_stage("enc").batched_available():
-        # all encoder passes of the frame in one launch per layer (main stream), then the two swin calls side by side
-        mid = x[n_seq // 2]
-        others = [i for i in range(n_seq) if i != n_seq // 2]
-        frames = [mid, ctx.rl_prior(mid, 5, 0.01)]
-        for i in others:
-            frames += [x[i], ctx.rl_prior(x[i], 1, 0.01)]
-        if has_ref:
-            frames.append(x[n_seq + 1])
-        lv1, lv2, lv3 = enc_batched(ctx, frames, P)
-        cat = FMap(torch.empty(h3 * w3, 128 * n_seq, device=dev), h3, w3, 128 * n_seq)
-        f_mid = FMap(ctx.add(lv3.map(1).t, lv3.map(0).t), h3, w3, 128)                 # enc(RL5(mid)) + enc(mid)   (speinet.py:130-132)
-        cat.t[:, :128].copy_(f_mid.t)
-        feats = [FMap(ctx.add(lv3.map(3 + 2 * k).t, lv3.map(2 + 2 * k).t), h3, w3, 128) for k in range(len(others))]
-        lv = (lv1.map(len(frames) - 1), lv2.map(len(frames) - 1), lv3.map(len(frames) - 1)) if has_ref else None
-        sx = SwinX(ctx, f_mid, P["swin"])
-        ready = torch.cuda.Event()
-        ready.record(main)
-        for slot, feat in enumerate(feats, start=1):
-            lane = lanes[(slot - 1) % len(lanes)]
-            if lane is not main:
-                lane.wait_event(ready)
-            with torch.cuda.stream(lane):
-                swin(ctx, sx, feat, P["swin"], out=cat.view(128 * slot, 128))
-        for s_ in lanes[1:]:
-            main.wait_stream(s_)                  # join
-        yield from _tail(ctx, cat, lv, P, out)
+        yield from forward_batch_steps(ctx, x[None], P, n_seq, [not has_ref], out[None], sides)
         return
     for s_ in lanes[1:]:
         s_.wait_stream(main)                      # fork: the input frames (and anything before them) are ready
@@ -303,6 +278,62 @@ def forward_sample_steps(ctx: Ctx, x: torch.Tensor, P: dict, n_seq: int, has_ref
     for s_ in lanes[1:]:
         main.wait_stream(s_)                      # join
     yield from _tail(ctx, cat, lv, P, out)
+
+
+def forward_batch_steps(ctx: Ctx, x: torch.Tensor, P: dict, n_seq: int, zero_ref: list, out: torch.Tensor, sides=(), max_maps: int = 16):
+    """x [B, n_seq+2, 3, H, W] -> out [B, 3, H, W] with ALL encoder passes of a group of samples (7 per sample with a sharp reference,
+    6 without; up to `max_maps` maps) in one launch per layer (enc_batched; the reference batches the same way, model/speinet.py:
+    150-168 runs `_forwardbs` / `_forwardb` on the sub-batches).  Yields one prepared correlation launch per sample, in sample order;
+    per sample the swin calls, the search and the decoder are those of `forward_sample`.  Bit-identical to one sample at a time."""
+    B = x.shape[0]
+    h, w = x.shape[-2:]
+    h3, w3 = h // 4, w // 4
+    dev = x.device
+    lanes = _lanes(ctx, sides)
+    main = lanes[0]
+    others = [i for i in range(n_seq) if i != n_seq // 2]
+    b0 = 0
+    while b0 < B:
+        # samples of this group: as many as fit the map budget
+        group, maps = [], 0
+        while b0 + len(group) < B:
+            need = 2 + 2 * len(others) + (0 if zero_ref[b0 + len(group)] else 1)
+            if group and maps + need > max_maps:
+                break
+            group.append(b0 + len(group))
+            maps += need
+        frames, first = [], {}
+        for b in group:
+            first[b] = len(frames)
+            mid = x[b, n_seq // 2]
+            frames += [mid, ctx.rl_prior(mid, 5, 0.01)]
+            for i in others:
+                frames += [x[b, i], ctx.rl_prior(x[b, i], 1, 0.01)]
+            if not zero_ref[b]:
+                frames.append(x[b, n_seq + 1])
+        lv1, lv2, lv3 = enc_batched(ctx, frames, P)
+        del frames
+        for b in group:
+            m0 = first[b]
+            cat = FMap(torch.empty(h3 * w3, 128 * n_seq, device=dev), h3, w3, 128 * n_seq)
+            f_mid = FMap(ctx.add(lv3.map(m0 + 1).t, lv3.map(m0).t), h3, w3, 128)            # enc(RL5(mid)) + enc(mid)   (speinet.py:130-132)
+            cat.t[:, :128].copy_(f_mid.t)
+            feats = [FMap(ctx.add(lv3.map(m0 + 3 + 2 * k).t, lv3.map(m0 + 2 + 2 * k).t), h3, w3, 128) for k in range(len(others))]
+            mr = m0 + 2 + 2 * len(others)
+            lv = None if zero_ref[b] else (lv1.map(mr), lv2.map(mr), lv3.map(mr))
+            sx = SwinX(ctx, f_mid, P["swin"])
+            ready = torch.cuda.Event()
+            ready.record(main)
+            for slot, feat in enumerate(feats, start=1):
+                lane = lanes[(slot - 1) % len(lanes)]
+                if lane is not main:
+                    lane.wait_event(ready)
+                with torch.cuda.stream(lane):
+                    swin(ctx, sx, feat, P["swin"], out=cat.view(128 * slot, 128))
+            for s_ in lanes[1:]:
+                main.wait_stream(s_)                  # join
+            yield from _tail(ctx, cat, lv, P, out[b])
+        b0 += len(group)
 
 
 def _tail(ctx: Ctx, cat: FMap, lv, P: dict, out: torch.Tensor):

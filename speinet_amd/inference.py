@@ -233,14 +233,35 @@ class Inference:
         ready.synchronize()
         finite, psnr, ssim = (float(v) for v in slot["met"].tolist())
         if not finite:
-            raise FloatingPointError(f"non-finite values in the deblurred frame {save_to or ''}: an activation left the range of the "
-                                     "16-bit operand format (half: +-65504); rerun with --precision bf16x3 or f32")
+            return None, None, time.time() - t0         # an activation left the range of the 16-bit operand format: `flush` re-runs the window
         if save_to:
             _imwrite(save_to, slot["out"].numpy())
         return (float("inf") if psnr != psnr or psnr == float("inf") else psnr), ssim, time.time() - t0
 
+    def _redo_window(self, x, zero_ref: bool, gt_u8, save_to: str):
+        """One window again in split-bf16 arithmetic (fp32 exponent range), synchronously: the fallback for a frame whose half-precision
+        pass produced a non-finite value.  Returns (PSNR, SSIM, seconds)."""
+        t0 = time.time()
+        keep = (self.net.precision, self.net.corr_precision, self.net.use_graph)
+        self.net.precision, self.net.corr_precision, self.net.use_graph = "bf16x3", "bf16x3", False
+        try:
+            with torch.no_grad():
+                out = self.net(x, routing=[zero_ref])
+        finally:
+            self.net.precision, self.net.corr_precision, self.net.use_graph = keep
+        if not bool(torch.isfinite(out).all()):
+            raise FloatingPointError(f"non-finite values in the deblurred frame {save_to or ''} in bf16x3 arithmetic as well: the input or the "
+                                     "checkpoint is at fault")
+        out_u8 = out.mul(255.0).clamp(0, 255).round()[0].to(torch.uint8).permute(1, 2, 0).contiguous()
+        psnr, ssim = metrics_gpu(out_u8[4:-4, 4:-4], gt_u8[4:-4, 4:-4])
+        if save_to:
+            _imwrite(save_to, out_u8.cpu().numpy())
+        psnr = float(psnr)
+        return (float("inf") if psnr != psnr or psnr == float("inf") else psnr), float(ssim), time.time() - t0
+
     def infer(self):
         a = self.args
+        self.range_retries = 0
         clips = sorted(os.listdir(os.path.join(a.data_path, "blur")))
         lengths = [len(glob.glob(os.path.join(a.data_path, "blur", c, "*"))) for c in clips]
         mine = shard_clips_by_length(lengths, self.world)[self.rank]
@@ -263,8 +284,16 @@ class Inference:
 
                 def flush(block: bool):
                     while pending and (block or pending[0][1].done()):
-                        name, fut, t_pre, t_fwd, t_start = pending.popleft()
+                        name, fut, t_pre, t_fwd, t_start, redo = pending.popleft()
                         psnr, ssim, t_post = fut.result()
+                        if psnr is None:
+                            # half operands do not saturate (+-65504): a frame with a non-finite value is recomputed in split-bf16
+                            # arithmetic (fp32 range, f32-grade) instead of aborting the clip; counted and logged
+                            psnr, ssim, t_redo = self._redo_window(*redo)
+                            t_post += t_redo
+                            self.range_retries += 1
+                            self.logger.write_log(f"# {clip}-{name}: non-finite value in the {a.precision} frame, recomputed in bf16x3 "
+                                                  f"({self.range_retries} so far)")
                         vp.append(psnr)
                         vs.append(ssim)
                         self.logger.write_log('> {}-{} PSNR={:.5}, SSIM={:.4} pre_time:{:.3}s, forward_time:{:.3}s, post_time:{:.3}s, total_time:{:.3}s'
@@ -324,7 +353,7 @@ class Inference:
                     t2 = time.time()
                     save_to = os.path.join(a.result_path, clip, w["name"] + ".png") if a.save_image else ""
                     slot["fut"] = self.post_pool.submit(self._post, slot, ev, save_to)
-                    pending.append((w["name"], slot["fut"], t_prep, t2 - t1, t0))        # pre_time = this window's own input preparation
+                    pending.append((w["name"], slot["fut"], t_prep, t2 - t1, t0, (x, bool(w["zero_pre"]), gt_u8, save_to)))   # pre_time = this window's own input preparation
                     flush(block=len(pending) > 2 * self.prefetch)
                 t_drain = time.time()
                 flush(block=True)

@@ -523,6 +523,18 @@ class Ctx:
                    "spei_mlp_fused16")
         return out
 
+    def attn_tok(self, x: torch.Tensor, yhat: torch.Tensor, bk: dict, H: int, W: int, shift: int, out: torch.Tensor) -> torch.Tensor:
+        """out = x + proj(window_attention(...)), token-stationary kernel (csrc/swin_tok16.hip); out must not be x."""
+        assert x.shape == (H * W, 256) and x.dtype == torch.float32 and out.shape == x.shape and out.dtype == torch.float32
+        assert out.data_ptr() != x.data_ptr()
+        f = self.fmt
+        assert yhat.shape == x.shape and yhat.dtype == LP_DTYPE[f]
+        tp = self._tp
+        ws = bk["attn_stream"]
+        _lib.check(_lib.lib().spei_attn_tok16(f, tp(x), tp(out), tp(yhat), tp(ws.stream(f)), tp(bk["bq"]), tp(bk["bkv"]), tp(bk["bproj"]),
+                                              tp(ws.relb28), H, W, shift, self._stream()), "spei_attn_tok16")
+        return out
+
     def mlp_tok(self, x: torch.Tensor, ws, b1: torch.Tensor, b2: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         """out = x + fc2(gelu(fc1(LN(x)))), token-stationary kernel (csrc/swin_tok16.hip); ws: pack.MlpStreamW; in place when out is x."""
         assert x.shape[1] == 256 and x.dtype == torch.float32 and x.is_contiguous() and out.shape == x.shape and out.dtype == torch.float32

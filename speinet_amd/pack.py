@@ -112,6 +112,39 @@ class MlpStreamW:
         return self._s[fmt]
 
 
+class AttnStreamW:
+    """The attention weights of one Swin block as the fragment stream spei_attn_tok16 consumes (16 chunks of 32 fragments): chunks
+    0-3 Wq (two heads each, 16 k-steps per head), 4-11 head h: Wk_h then Wv_h, 12-15 Wproj (two 32-channel output tiles each; its
+    input channels in accumulator order: it multiplies O^T tiles handed over from the accumulators).  `relb28`: the relative
+    position bias [8][25][25] with the key axis padded to 28 (16-byte rows for the lanes' 4-key groups)."""
+    __slots__ = ("wq", "wkv", "wp", "relb28", "_s")
+
+    def __init__(self, wq, wkv, wp, relbias, device):
+        f = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
+        self.wq, self.wkv, self.wp = f(wq).reshape(256, 256), f(wkv).reshape(512, 256), f(wp).reshape(256, 256)
+        rb = f(relbias).reshape(8, 25, 25)
+        self.relb28 = torch.cat((rb, torch.zeros(8, 25, 3, device=device)), dim=2).contiguous()
+        self._s = {}
+
+    def stream(self, fmt: int) -> torch.Tensor:
+        if fmt not in self._s:
+            lp = LP_DTYPE[fmt]
+            fq = _frag(self.wq.to(lp)[None]).reshape(8, 16, 512)                      # [head][k-step][lane x 8]
+            fkv = _frag(self.wkv.to(lp)[None]).reshape(16, 16, 512)                    # tiles 0-7 K heads, 8-15 V heads
+            fp = _frag(acc_k_order(self.wp).to(lp)[None]).reshape(8, 16, 512)          # [out tile][k-step = 2 head + s]
+            kv = torch.stack((fkv[:8], fkv[8:]), dim=1)                                # [head][K | V][16][512]
+            self._s[fmt] = torch.cat((fq.reshape(4, 32, 512), kv.reshape(8, 32, 512), fp.reshape(4, 32, 512)), dim=0).contiguous()
+        return self._s[fmt]
+
+
+class AttnStreamHost:
+    """Marker (host side of packing) -> AttnStreamW on the device."""
+    __slots__ = ("wq", "wkv", "wp", "relbias")
+
+    def __init__(self, wq, wkv, wp, relbias):
+        self.wq, self.wkv, self.wp, self.relbias = wq, wkv, wp, relbias
+
+
 class MlpStreamHost:
     """Marker (host side of packing) -> MlpStreamW on the device."""
     __slots__ = ("w1", "w2")
@@ -177,6 +210,8 @@ def swin_block(sd: SD, p: str, heads: int, ws: int) -> dict:
         "wproj": G(sd[p + "attn.proj.weight"].contiguous()), "bproj": sd[p + "attn.proj.bias"],
         "w1": G((w1 * g2[None, :]).float().contiguous()), "b1": (w1 @ b2 + bb1).float(),
         "w2": G(sd[p + "mlp.fc2.weight"].contiguous()), "b2": sd[p + "mlp.fc2.bias"],
+        "attn_stream": AttnStreamHost((scale * wq * g1[None, :]).float().contiguous(), (wkv * g1[None, :]).float().contiguous(),
+                                      sd[p + "attn.proj.weight"].contiguous(), relb.float()),
         "mlp_stream": MlpStreamHost((w1 * g2[None, :]).float().contiguous(), sd[p + "mlp.fc2.weight"].contiguous()),
         "relbias": relb.float(),
     }
@@ -187,6 +222,8 @@ def _to_device(o, device):
         return PackedW(o.t, device)
     if isinstance(o, MlpStreamHost):
         return MlpStreamW(o.w1, o.w2, device)
+    if isinstance(o, AttnStreamHost):
+        return AttnStreamW(o.wq, o.wkv, o.wp, o.relbias, device)
     if torch.is_tensor(o):
         return o.detach().to(device=device, dtype=torch.float32).contiguous()
     if isinstance(o, dict):

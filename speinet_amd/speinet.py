@@ -321,9 +321,18 @@ class SPEINet(nn.Module):
                 return self._forward_graph(ctx, x, P, zero_ref, profile)
             out = torch.empty(x.shape[0], 3, h, w, device=x.device, dtype=torch.float32)
             sides = self._sides(x.device)
-            for b in range(x.shape[0]):
-                engine.forward_sample(ctx, x[b], P, self.n_sequence, not zero_ref[b], out[b], sides)
+            for plan in self._steps(ctx, x, P, zero_ref, out, sides):
+                plan.launch()
             return out
+
+    def _steps(self, ctx: ops.Ctx, x, P, zero_ref, out, sides):
+        """The batch as a generator of prepared correlation launches, one per sample: the encoder passes of ALL samples batched per layer
+        where the mode allows it (engine.forward_batch_steps), else one sample after the other."""
+        if ctx.for_stage("enc").batched_available():
+            yield from engine.forward_batch_steps(ctx, x, P, self.n_sequence, list(zero_ref), out, sides)
+        else:
+            for b in range(x.shape[0]):
+                yield from engine.forward_sample_steps(ctx, x[b], P, self.n_sequence, not zero_ref[b], out[b], sides)
 
     def forward_window(self, x: torch.Tensor, keys: Sequence, cache: "EncoderCache", zero_ref: bool) -> torch.Tensor:
         """One window of a clip with cross-window reuse of the per-frame encoder work (not part of the
@@ -499,31 +508,32 @@ class SPEINet(nn.Module):
             side = torch.cuda.Stream(device=x.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):       # warm-up off the capture: sets kernel attributes, fills the allocator
-                for b in range(x.shape[0]):
-                    engine.forward_sample(cctx, static_x[b], P, self.n_sequence, not zero_ref[b], static_out[b], sides)
+                for plan in self._steps(cctx, static_x, P, zero_ref, static_out, sides):
+                    plan.launch()
             torch.cuda.current_stream().wait_stream(side)
+            # graph segments between the correlation launches: [g_0] plan_0 [g_1] plan_1 ... plan_{B-1} [g_B]; each plan is launched
+            # once, eagerly, so that the next segment is captured behind real data
             segs, pool = [], None
-            for b in range(x.shape[0]):
-                steps = engine.forward_sample_steps(cctx, static_x[b], P, self.n_sequence, not zero_ref[b], static_out[b], sides)
-                g1 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1, pool=pool):
-                    plan = next(steps)              # everything up to the prepared correlation
-                pool = g1.pool()
-                plan.launch()                       # once, eagerly: the second segment is captured behind real data
-                g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, pool=pool):
-                    for _ in steps:                 # resumes after the yield; there is no second one
-                        raise RuntimeError("forward_sample_steps yielded twice")
-                segs.append((g1, plan, g2))
+            steps = self._steps(cctx, static_x, P, zero_ref, static_out, sides)
+            while True:
+                gseg = torch.cuda.CUDAGraph()
+                plan = None
+                with torch.cuda.graph(gseg, pool=pool):
+                    plan = next(steps, None)
+                pool = gseg.pool()
+                segs.append((gseg, plan))
+                if plan is None:
+                    break
+                plan.launch()
             self._trim_graphs()
             self._graph_devices.add(str(x.device))
             g = self._graphs[key] = (segs, static_x, static_out)
         segs, static_x, static_out = g
         static_x.copy_(x)
-        for g1, plan, g2 in segs:
-            g1.replay()
-            plan.launch(profile)
-            g2.replay()
+        for gseg, plan in segs:
+            gseg.replay()
+            if plan is not None:
+                plan.launch(profile)
         return static_out.clone()
 
 

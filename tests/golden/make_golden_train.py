@@ -173,8 +173,34 @@ def main():
             loss.backward()
             opt.step()
             losses.append(loss.item())
-        np.savez_compressed(os.path.join(HERE, "g22_losscurve_swint_40x40.npz"), seed=seed, b=b, h=h, w=w, losses=np.asarray(losses))
+        # the same six steps by the reference in FLOAT64 (same initial weights, same HEM draws): how far fp32 round-off alone moves
+        # the reference's own curve — the scale a fp32 implementation with another summation order is judged against
+        torch.manual_seed(0)
+        net64 = mw.SPEINet(in_channels=3, n_sequence=3, out_channels=3, n_resblock=3, n_feat=32, device="cpu", args=args)
+        net64.load_state_dict(synth_state_dict(net64.state_dict(), seed=0), strict=True)
+        for m in net64.modules():
+            if isinstance(m, DropPath):
+                m.drop_prob = 0.0
+        net64.double().train()
+        opt64 = torch.optim.Adam(net64.parameters(), lr=1e-4, weight_decay=0.0)
+        np.random.seed(seed)
+        losses64 = []
+        torch.set_default_dtype(torch.float64)
+        try:
+            for _ in range(steps):
+                out = net64(x.double())
+                opt64.zero_grad()
+                loss = torch.nn.L1Loss()(out, gt.double()) + 2.0 * hem(out, gt.double())
+                loss.backward()
+                opt64.step()
+                losses64.append(loss.item())
+        finally:
+            torch.set_default_dtype(torch.float32)
+        np.savez_compressed(os.path.join(HERE, "g22_losscurve_swint_40x40.npz"), seed=seed, b=b, h=h, w=w, losses=np.asarray(losses),
+                            losses64=np.asarray(losses64))
         print("g22_losscurve_swint_40x40: " + ", ".join(f"{v:.6f}" for v in losses))
+        print("        the same in float64: " + ", ".join(f"{v:.6f}" for v in losses64))
+        print("        |fp32 - float64|:    " + ", ".join(f"{abs(a - c):.2e}" for a, c in zip(losses, losses64)))
     if "speinet" in which:
         # G21: model/speinet.py itself (trainer/trainer_swint_hsa_nsf.py): three samples, the second with an all-zero frame 3 ->
         # `_forwardb` (SelfTransfer) on a sub-batch of one, `_forwardbs` (SearchTransfer) on the other two

@@ -274,6 +274,28 @@ def test_attn_fused_vs_oracle(synth_sd, h, w, shift, mode):
     assert torch.equal(inplace, out)
 
 
+@pytest.mark.parametrize("h,w,shift", [(5, 5, 0), (5, 5, 2), (10, 15, 0), (10, 15, 2), (15, 25, 2), (20, 35, 0), (20, 35, 2), (45, 40, 2),
+                                       (180, 320, 0), (180, 320, 2)])
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_attn_tok_vs_fused(synth_sd, h, w, shift, mode):
+    """The token-stationary attention kernel (csrc/swin_tok16.hip: one window per wave, weights through the LDS ring, O^T handed to
+    the projection from the accumulators) against the round-2 fused kernel (itself pinned against the oracle above): same operand
+    rounding, other summation orders — window counts that are not a multiple of the 8 windows of a workgroup, both shifts."""
+    ops = Ctx(mode, device=DEV)
+    p = "swin.layers.2.residual_group.blocks.3."
+    bk = pack._to_device(pack.swin_block(synth_sd, p, 8, 5), DEV)
+    m = h * w
+    gen = torch.Generator().manual_seed(100 + h + shift)
+    x = (torch.randn(m, 256, generator=gen) * 1.2 + 0.3).to(DEV)
+    yhat = ops.layernorm(torch.randn(m, 256, generator=gen).to(DEV), out_dtype=LPD[mode])
+    ref = ops.attn_fused(x, yhat, bk, h, w, shift, out=torch.empty_like(x))
+    out = ops.attn_tok(x, yhat, bk, h, w, shift, out=torch.full_like(x, float("nan")))
+    scale = (ref - x).abs().max().item()
+    e = (out - ref).abs().max().item() / scale
+    print(f"attn_tok {mode} {h}x{w} shift {shift}: rel diff vs attn_fused {e:.2e} (branch magnitude {scale:.2f})")
+    assert torch.isfinite(out).all() and e < TOL[mode], e
+
+
 @pytest.mark.parametrize("h,w,shift", [(5, 5, 0), (5, 10, 2), (10, 15, 0), (10, 15, 2), (20, 35, 2), (180, 320, 2), (180, 320, 0)])
 @pytest.mark.parametrize("mode", ["bf16", "f16"])
 def test_swin_block_fused_vs_oracle(synth_sd, h, w, shift, mode):
@@ -503,6 +525,25 @@ def test_batched_encoder_bit_identical(net, mode, b, h, w, zero_ref):
     finally:
         net.knobs, net.use_graph = {}, False
         net.precision, net.corr_precision = "f32", "bf16x3"
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_batch_bit_identical_to_per_sample(net, graph):
+    """B > 1 (the reference processes [B, ...] natively, model/speinet.py:150-168): the encoder passes of all samples are batched per
+    layer (engine.forward_batch_steps: 13 maps here, two launch groups at the 16-map budget for the larger batch); every sample's frame
+    has the bits of the same sample run alone — mixed routing, eager and hipGraph."""
+    net.precision, net.corr_precision, net.use_graph = "f16", "top2", graph
+    try:
+        for b, h, w, zr in ((2, 100, 140, (1,)), (4, 60, 80, (0, 3))):
+            x = synth_frames(b, h, w, seed=50 + b, zero_ref=zr).to(DEV)
+            with torch.no_grad():
+                whole = net(x).clone()
+                if graph:
+                    whole = net(x).clone()                 # the replay, not the capture run
+                for i in range(b):
+                    assert torch.equal(net(x[i:i + 1])[0], whole[i]), (b, i)
+    finally:
+        net.precision, net.corr_precision, net.use_graph = "f32", "bf16x3", False
 
 
 def _golden_case(golden_dir, name):

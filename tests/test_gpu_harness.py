@@ -56,6 +56,57 @@ def test_harness_two_clips(tmp_path):
     assert np.array_equal(selection.tensor2numpy(out), saved)
 
 
+def test_harness_frames_vs_oracle(tmp_path, synth_sd):
+    """The harness end to end against the ORACLE, not against itself: the PNGs it writes for a clip (label file, LD selection, window
+    assembly, zeroed far references, forward, uint8 conversion) against frames computed by the CPU restatement of the reference from
+    the same files through the reference's own conversions (selection.numpy2tensor / tensor2numpy, G12): every pixel within one grey
+    level, >= 99.9 % identical, and the PSNR it logs within 0.01 dB of the oracle frame's."""
+    from oracle import speinet_oracle as O
+    root, res = str(tmp_path / "data"), str(tmp_path / "res")
+    _make_clip(root, "clipA", 6, 40, 60, 3, labels=[0, 1, 0, 0, 0, 1])
+    a = inference.build_args(["--data_path", root, "--model_path", "synthetic", "--result_path", res, "--precision", "f32"])
+    inf = inference.Inference(a)
+    inf.infer()
+    text = open(os.path.join(res, [f for f in os.listdir(res) if f.startswith("inference_log")][0])).read()
+    blur = sorted(os.path.join(root, "blur", "clipA", f) for f in os.listdir(os.path.join(root, "blur", "clipA")))
+    gts = sorted(os.path.join(root, "gt", "clipA", f) for f in os.listdir(os.path.join(root, "gt", "clipA")))
+    wins = selection.assemble_windows(blur, np.load(os.path.join(root, "label", "clipA.npy")))
+    gt_seqs, _ = selection.gene_seq(gts, 3, True)
+    for k in (0, 2, 5):
+        w = wins[k]
+        imgs = [inference._imread(p) for p in w["window"] + [w["pre"], w["sub"]]]
+        if w["zero_pre"]:
+            imgs[-2] = np.zeros_like(imgs[-2])
+        if w["zero_sub"]:
+            imgs[-1] = np.zeros_like(imgs[-1])
+        with torch.no_grad():
+            ref = O.forward(selection.numpy2tensor(imgs), synth_sd, O.Cfg())
+        ref_u8 = selection.tensor2numpy(ref)
+        saved = inference._imread(os.path.join(res, "clipA", w["name"] + ".png"))
+        diff = np.abs(saved.astype(np.int32) - ref_u8.astype(np.int32))
+        assert diff.max() <= 1 and (diff == 0).mean() >= 0.999, (k, diff.max(), (diff == 0).mean())
+        gt = inference._imread(gt_seqs[k][1])
+        psnr_ref = O.psnr_uint8(torch.from_numpy(ref_u8), torch.from_numpy(gt))
+        logged = float(re.search(rf"^> clipA-{w['name']} PSNR=([\d.]+)", text, flags=re.M).group(1))
+        assert abs(logged - psnr_ref) < 1e-2 + 5e-5 * psnr_ref, (k, logged, psnr_ref)     # the log prints 5 significant digits
+
+
+def test_harness_recomputes_non_finite_frames(tmp_path):
+    """Half operands do not saturate: a frame with a non-finite value (here: one weight beyond +-65504, infinite as a half) is
+    recomputed in split-bf16 arithmetic and counted, the clip is not aborted."""
+    root, res = str(tmp_path / "data"), str(tmp_path / "res")
+    _make_clip(root, "clipA", 4, 40, 60, 4, labels=[1, 0, 0, 1])
+    a = inference.build_args(["--data_path", root, "--model_path", "synthetic", "--result_path", res, "--precision", "f16"])
+    inf = inference.Inference(a)
+    with torch.no_grad():
+        inf.net.recons_net.outBlock[3].weight[0, 0, 0, 0] = 1.0e5
+    inf.net.invalidate_packed()
+    tot = inf.infer()
+    assert int(tot[2].item()) == 4 and inf.range_retries == 4
+    text = open(os.path.join(res, [f for f in os.listdir(res) if f.startswith("inference_log")][0])).read()
+    assert text.count("recomputed in bf16x3") == 4 and np.isfinite(tot[0].item())
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_forward_window_reuse_bit_identical(graph):
     """Cross-window reuse of the per-frame encoder passes (SURVEY.md plan step 8): sliding windows over a clip through

@@ -484,7 +484,8 @@ def test_training_graph_matches_inference_path_at_crop_size(which):
 def test_loss_curve_vs_reference(golden_dir):
     """the loss curve of N optimizer steps with DropPath disabled against the reference's own run
     (G22: swint model, two 40x40 windows, 1*L1 + 2*HEM, Adam 1e-4, BatchNorm in train mode, 6 steps).  Each step feeds on the
-    previous update, so fp32 differences compound: first loss to 2e-6, second to 5e-5, the rest of the curve to 4e-3 (see below)."""
+    previous update, so fp32 differences compound: first loss to 2e-6, second to 5e-5, the rest of the curve within ten times the distance
+    between the reference's own fp32 and float64 curves (see below)."""
     from speinet_amd.loss import Loss
     from speinet_amd.swint import SPEINet
     from speinet_amd.speinet import default_args
@@ -512,14 +513,21 @@ def test_loss_curve_vs_reference(golden_dir):
         opt.step()
         losses.append(loss.item())
     ref = [float(v) for v in d["losses"]]
-    print("HIP      :", ", ".join(f"{v:.6f}" for v in losses))
-    print("reference:", ", ".join(f"{v:.6f}" for v in ref))
-    # Measured: 0, 1.1e-5, 1.2e-3, 4e-4, 8e-4, 7e-4.  Adam's first steps move EVERY element by +-lr whatever its gradient's size
-    # (update = lr g / (|g| + 1e-8)): elements whose gradient is within fp32 round-off of zero step in a direction the summation
-    # order decides, in both runs — the reference's own curve is not monotone for the same reason (0.3396 -> 0.3448) — so from
-    # the third step on the two trajectories agree to the size of that noise, not to round-off.
-    assert abs(losses[0] - ref[0]) < 2e-6 and abs(losses[1] - ref[1]) < 5e-5
-    assert max(abs(a - r) for a, r in zip(losses, ref)) < 4e-3
+    ref64 = [float(v) for v in d["losses64"]]
+    print("HIP               :", ", ".join(f"{v:.6f}" for v in losses))
+    print("reference, fp32   :", ", ".join(f"{v:.6f}" for v in ref))
+    print("reference, float64:", ", ".join(f"{v:.6f}" for v in ref64))
+    noise = max(abs(a - c) for a, c in zip(ref, ref64))           # how far fp32 round-off alone moves the REFERENCE's curve: 3.8e-4
+    dev64 = [abs(a - c) for a, c in zip(losses, ref64)]
+    print(f"|reference fp32 - float64| max {noise:.2e};  |HIP - float64| " + ", ".join(f"{v:.1e}" for v in dev64))
+    # The fixture holds the reference's own curve in float64 (round 3): its fp32 run leaves it by up to 3.8e-4 within six steps (1e-6
+    # through step 3).  The HIP run agrees to 0 / 1e-5 on the first two steps and then sits within 1.2e-3 of the float64 curve: its
+    # gradients are 2e-4 (median) from the float64 gradients where the reference's fp32 gradients are 2e-5 (G20: other summation
+    # orders, ReLU / max-pool decisions at round-off), and Adam's first steps move EVERY element by +-lr whatever its gradient's size
+    # (update = lr g / (|g| + 1e-8)), so elements whose gradient is within round-off of zero step in a direction the summation order
+    # decides.  Bound: ten times the reference's own fp32-vs-float64 distance.
+    assert abs(losses[0] - ref64[0]) < 2e-6 and abs(losses[1] - ref64[1]) < 5e-5
+    assert max(dev64) < 10.0 * noise, (max(dev64), noise)
     assert losses[-1] < losses[0] and ref[-1] < ref[0]
 
 

@@ -38,6 +38,9 @@ def timeit(name, fn, n=30):
 
 for shift in (0, 2):
     timeit(f"attn_fused shift={shift}", lambda: ops.attn_fused(x, yhat, bk, H, W, shift, out))
+out_b = torch.empty_like(x)
+for shift in (0, 2):
+    timeit(f"attn_tok   shift={shift}", lambda: ops.attn_tok(x, yhat, bk, H, W, shift, out_b))
 timeit("mlp_fused", lambda: ops.mlp_fused(x, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out))
 timeit("mlp_tok", lambda: ops.mlp_tok(x, bk["mlp_stream"], bk["b1"], bk["b2"], out))
 x2 = torch.randn(2 * H * W, 256, device=dev)

@@ -51,6 +51,8 @@ def run():
         ops.attn_fused(x, yhat, bk, H, W, 2, out)
     elif which == "block":
         ops.swin_block(x, yhat, bk, H, W, 2, out)
+    elif which == "attntok":
+        ops.attn_tok(x, yhat, bk, H, W, 2, out)
     elif which == "mlptok":
         ops.mlp_tok(x, bk["mlp_stream"], bk["b1"], bk["b2"], out)
     else:
