@@ -150,6 +150,9 @@ def train_measure(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu-baseline", action="store_true",
                     help="also time one training step of the oracle (CPU restatement, fp32, torch autograd) on the host cores: 2 crops")
+    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="bf16x3",
+                    help="forward / data-gradient GEMMs of the step: bf16x3 = split products on the 16-bit matrix pipe (finer than the TF32 / "
+                         "bf16 matmuls the reference trains with, main_SPEINet.py:12); f32 = the form G20-G22 pin to 1e-6")
     ap.add_argument("--model", choices=["swint", "speinet"], default="swint",
                     help="swint: model/swint.py (trainer_swint.py, config 5); speinet: model/speinet.py (trainer_swint_hsa_nsf.py), every "
                          "4th crop without a sharp reference")
@@ -176,6 +179,7 @@ def train_measure(argv=None):
         net = SPEINet(n_sequence=3, args=args)
     net.load_state_dict(synth_state_dict(net.state_dict(), seed=0), strict=True)
     net = net.to(dev).train()
+    net.train_precision = a.precision
     opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=0.0)
     loss_fn = Loss("1*L1+2*HEM", device=dev)
     if a.model == "speinet":
@@ -238,7 +242,8 @@ def train_measure(argv=None):
         line = {"metric": f"training crops/s, {a.model} model, fwd + loss + bwd + Adam", "value": world * a.batch * 1e3 / ms,
                 "unit": "crops/s", "n_gpus": world, "batch_per_gpu": a.batch, "patch": a.patch, "n_sequence": 3, "ms_per_step": ms,
                 "ms": {"forward": float(split[0]), "loss_backward": float(split[1]), "adam": float(split[2])},
-                "loss": float(loss.item()), "dtype": "f32", "data": "synthetic", "scaling": "weak", "cpu_baseline": cpu}
+                "loss": float(loss.item()), "dtype": "f32" if a.precision == "f32" else "bf16x3 forward / data-gradient GEMMs, f32 weight gradients",
+                "data": "synthetic", "scaling": "weak", "cpu_baseline": cpu}
     if dist is not None:
         dist.destroy_process_group()
     return line

@@ -102,12 +102,13 @@ int spei_conv_slab16(int fmt, const void* a0, int lda0, int k0, const void* a1, 
 
 /* The same convolution on `batch` dense maps in ONE launch (gridDim.y = map): the frame's 7 encoder passes go through every layer of
  * model/recons_video_ori.py:26-56 with the same weights (model/speinet.py:82-83,125-131).  a0 [batch][Hin*Win][k0], out
- * [batch][Hout*Wout][N], fp32 or `fmt` each; single-product arithmetic.  Per map the tiles and the arithmetic are those of
+ * [batch][Hout*Wout][N], fp32 or `fmt` each; wfrag_lo != NULL: the split (bf16x3) form on fp32 maps (the training step's forward and
+ * data-gradient convolutions, speinet_amd/train.py); residual: NULL or [batch][Hout*Wout][N] fp32, added in the epilogue.  Per map the tiles and the arithmetic are those of
  * spei_conv_slab16 (bit-identical results); a launch has batch x the workgroups (several resident rounds instead of half of one at
  * H/4) and a frame needs 1/batch of the launches. */
-int spei_conv_slab16_batched(int fmt, const void* a0, int k0, int a_fmt, const void* wfrag, const float* bias, void* out, int out_fmt,
-                             int batch, int Hin, int Win, int Hout, int Wout, int N, int ksize, int stride, int pad, int act,
-                             spei_stream_t stream);
+int spei_conv_slab16_batched(int fmt, const void* a0, int k0, int a_fmt, const void* wfrag, const void* wfrag_lo, const float* bias,
+                             void* out, int out_fmt, const float* residual, int batch, int Hin, int Win, int Hout, int Wout, int N,
+                             int ksize, int stride, int pad, int act, spei_stream_t stream);
 
 /* The same convolution (stride 1, pad k/2, one dense fp32 input map, single-product arithmetic) with the PREVIOUS ResBlock's gated
  * residual sum folded into its staging (model/block.py:136-140 feeding the next block's first conv, :127-131):

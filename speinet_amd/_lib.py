@@ -50,7 +50,7 @@ SIGNATURES = {
     "spei_resblock_apply": (I, [P, P, I, P, P, P, P, P, I, I, I, I, P]),
     "spei_resblock_apply_batched": (I, [P, P, I, P, P, P, P, I, I, I, I, P]),
     "spei_resblock_gates_batched": (I, [P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),
-    "spei_conv_slab16_batched": (I, [I, P, I, I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "spei_conv_slab16_batched": (I, [I, P, I, I, P, P, P, P, I, P, I, I, I, I, I, I, I, I, I, I, P]),
     "spei_layernorm256": (I, [P, P, I, P, P, L, P]),
     "spei_window_attention": (I, [P, P, I, P, P, I, I, I, P]),
     "spei_window_attention_batched": (I, [P, P, I, P, P, I, I, I, I, P]),

@@ -63,8 +63,8 @@ struct SlabParams {
     // Batched launch (gridDim.y = number of maps, e.g. the 7 encoder passes of a frame through the same layer): map b of the input / the
     // output starts a0_bs / out_bs BYTES after map b - 1.  Same tiles, same arithmetic as one launch per map (bit-identical); what
     // changes is how many workgroups a launch has (450 -> 3150 at H/4: several resident rounds instead of half of one) and how many
-    // launches a frame needs.  a1, res, rowscale and the fused apply staging are not batched.
-    long long a0_bs, out_bs;
+    // launches a frame needs.  The residual map (res_bs) is batched like the output; a1, rowscale and the fused apply staging are not.
+    long long a0_bs, out_bs, res_bs;
     int batch;
     long long* stamps;       // tuning build: phase stamps (tools/stamp_phases.py conv), else NULL
     int dbg;                 // ablation switches for tools/ablate_slab.py (0 in production): 1 no staging loads, 8 weight stream from one hot group,
@@ -415,6 +415,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 4 && WN == 1 && TM <= 2 && !SP
         int fk_e = fk;
         asm volatile("" : "+v"(fk_e));
         TO* outp = reinterpret_cast<TO*>(static_cast<unsigned char*>(p.out) + (size_t)blockIdx.y * p.out_bs);
+        const float* resp = p.res ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(p.res) + (size_t)blockIdx.y * p.res_bs) : nullptr;
         int fr_e = fr;
         asm volatile("" : "+v"(fr_e));
         const int et = fr_e & 3, ecol = (fr_e >> 2) * 4;
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 4 && WN == 1 && TM <= 2 && !SP
                             f32x4 v = f32x4{a[0], a[1], a[2], a[3]};
                             if constexpr (!PLAIN) {
                                 if (p.rowscale) { const float rs = p.rowscale[m]; v *= rs; }
-                                if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * (unsigned)p.ldr + ncol0 + ecol);
+                                if (p.res) v += *reinterpret_cast<const f32x4*>(resp + m * (unsigned)p.ldr + ncol0 + ecol);
                                 if (p.planes) {                       // 32 -> 3 channel tail: only the lanes holding channels 0..3 store
                                     if (ncol0 + ecol == 0) {
                                         float* po = reinterpret_cast<float*>(outp) + m;
@@ -604,8 +605,8 @@ static int conv_slab16_run(int fmt, const void* a0, int lda0, int k0, const void
                            spei_stream_t stream, int batch = 1) {
     SPEI_REQUIRE(a0 && wfrag_hi && out, "spei_conv_slab16: null pointer");
     SPEI_REQUIRE(batch >= 1 && batch <= 65535, "spei_conv_slab16_batched: batch=%d", batch);
-    SPEI_REQUIRE(batch == 1 || (!a1 && !residual && !rowscale && !fa_x1 && !ln_input && lda0 == k0 && ldo == N && Wout > 1),
-                 "spei_conv_slab16_batched: dense maps, one input, no residual / row scale / fused staging");
+    SPEI_REQUIRE(batch == 1 || (!a1 && !rowscale && !fa_x1 && !ln_input && lda0 == k0 && ldo == N && (!residual || ldr == N) && Wout > 1),
+                 "spei_conv_slab16_batched: dense maps, one input, no row scale / fused staging");
     if (fa_x1) {
         SPEI_REQUIRE(fa_s && fa_g1 && fa_g2 && fa_out, "spei_conv_slab16_fa: null pointer");
         SPEI_REQUIRE(a_fmt == SPEI_F32 && !wfrag_lo && !a1 && k1 == 0 && lda0 == k0 && stride == 1 && ksize > 1 && !ln_input && Wout > 1,
@@ -648,6 +649,7 @@ static int conv_slab16_run(int fmt, const void* a0, int lda0, int k0, const void
     p.batch = batch;
     p.a0_bs = (long long)Hin * Win * lda0 * (a16 ? 2 : 4);
     p.out_bs = (long long)Hout * Wout * ldo * (o16 ? 2 : 4);
+    p.res_bs = (long long)Hout * Wout * ldr * 4;
     return dispatch_fmt(p, fmt, wfrag_lo != nullptr, a16, o16, (hipStream_t)stream);
 }
 
@@ -660,11 +662,11 @@ extern "C" int spei_conv_slab16(int fmt, const void* a0, int lda0, int k0, const
                            Win, Hout, Wout, N, ksize, stride, pad, act, ln_input, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
-extern "C" int spei_conv_slab16_batched(int fmt, const void* a0, int k0, int a_fmt, const void* wfrag, const float* bias, void* out, int out_fmt,
-                                        int batch, int Hin, int Win, int Hout, int Wout, int N, int ksize, int stride, int pad, int act,
-                                        spei_stream_t stream) {
-    return conv_slab16_run(fmt, a0, k0, k0, nullptr, 0, 0, a_fmt, wfrag, nullptr, bias, out, N, out_fmt, nullptr, 0, nullptr, Hin, Win, Hout,
-                           Wout, N, ksize, stride, pad, act, 0, nullptr, nullptr, nullptr, nullptr, nullptr, stream, batch);
+extern "C" int spei_conv_slab16_batched(int fmt, const void* a0, int k0, int a_fmt, const void* wfrag, const void* wfrag_lo, const float* bias,
+                                        void* out, int out_fmt, const float* residual, int batch, int Hin, int Win, int Hout, int Wout, int N,
+                                        int ksize, int stride, int pad, int act, spei_stream_t stream) {
+    return conv_slab16_run(fmt, a0, k0, k0, nullptr, 0, 0, a_fmt, wfrag, wfrag_lo, bias, out, N, out_fmt, residual, residual ? N : 0, nullptr, Hin,
+                           Win, Hout, Wout, N, ksize, stride, pad, act, 0, nullptr, nullptr, nullptr, nullptr, nullptr, stream, batch);
 }
 
 extern "C" int spei_conv_slab16_fa(int fmt, const float* x, int K, const void* x1, const float* s, const float* g1, const float* g2,

@@ -451,8 +451,9 @@ class Ctx:
         assert tuple(w.shape) == (ksize * ksize, N, a.C) and a.t.dtype in (torch.float32, LP_DTYPE[self.fmt])
         out = BMap.empty(a.B, ho, wo, N, a.t.device, out_dtype)
         tp = self._tp
-        _lib.check(_lib.lib().spei_conv_slab16_batched(self.fmt, tp(a.t), a.C, a.fmt, tp(w.frag(self.fmt)), tp(bias), tp(out.t), out.fmt, a.B,
-                                                       a.H, a.W, ho, wo, N, ksize, stride, pad, act, self._stream()), "spei_conv_slab16_batched")
+        _lib.check(_lib.lib().spei_conv_slab16_batched(self.fmt, tp(a.t), a.C, a.fmt, tp(w.frag(self.fmt)), _vp(0), tp(bias), tp(out.t), out.fmt,
+                                                       _vp(0), a.B, a.H, a.W, ho, wo, N, ksize, stride, pad, act, self._stream()),
+                   "spei_conv_slab16_batched")
         return out
 
     def resblock_batched(self, x: BMap, pk: dict) -> BMap:

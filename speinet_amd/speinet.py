@@ -225,6 +225,7 @@ class SPEINet(nn.Module):
         self.use_graph = os.environ.get("SPEINET_GRAPH", "0") == "1"     # hipGraph replay of a whole frame
         self.streams = int(os.environ.get("SPEINET_STREAMS", "1"))        # HIP streams for the independent frame branches
         self.knobs = {}              # extra ops.Ctx fields (parity ablations, tools/ablate_parity.py)
+        self.train_precision = os.environ.get("SPEINET_TRAIN_PRECISION", "f32")   # GEMMs of the training graph: "f32" | "bf16x3" (train.py)
         self._graphs = {}
         self._graph_devices = set()  # devices that hold captured graphs (synchronised before the graphs are dropped)
         self._side_streams = {}      # (device index, n) -> side streams, owned by this model

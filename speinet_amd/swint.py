@@ -56,6 +56,7 @@ class SPEINet(nn.Module):
         self.precision = os.environ.get("SPEINET_PRECISION", "f32")
         self.streams = int(os.environ.get("SPEINET_STREAMS", "1"))
         self.knobs = {}
+        self.train_precision = os.environ.get("SPEINET_TRAIN_PRECISION", "f32")   # GEMMs of the training graph: "f32" | "bf16x3" (train.py)
         self._side_streams = {}
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed())
 

@@ -49,6 +49,41 @@ def _ctx(device) -> Ctx:
     return Ctx("f32", "bf16x3", device=device)
 
 
+# Arithmetic of the step's forward and data-gradient GEMMs (`model.train_precision`): "f32" — v_mfma_f32_32x32x2_f32, the form
+# G20 - G22 pin to 1e-6; "bf16x3" — split products on the 16-bit matrix pipe (csrc/conv_slab16.hip, the inference kernels' SPLIT form:
+# 16-bit-significand operands, 2^-16 relative per product, fp32 accumulation): several times the rate, and still finer than the
+# arithmetic the reference trains in (main_SPEINet.py:12 `set_float32_matmul_precision('medium')`: TF32 / bf16 matmuls).  Weight
+# gradients, the stride-2 transposed forms, attention and everything pixel-sized stay fp32.  The choice is read when the graph is
+# built (a context variable around forward_swint / forward_speinet) and kept by every Function for its backward: the autograd
+# engine runs those on its own thread.
+import contextvars
+
+_PREC = contextvars.ContextVar("speinet_train_precision", default="f32")
+_PACK_CACHE: "dict" = {}
+
+
+def _split_frags(w_tnk: torch.Tensor, key=None):
+    """[tap][N][K] fp32 -> (hi, lo) bf16 in MFMA fragment order (pack._frag).  `key`: (data_ptr, version, tag) of the parameter the
+    matrix was derived from — the same weight is packed once per optimizer step however many encoder passes use it."""
+    from .pack import _frag
+    if key is not None:
+        hit = _PACK_CACHE.get(key)
+        if hit is not None:
+            return hit
+    hi = w_tnk.to(torch.bfloat16)
+    lo = (w_tnk - hi.float()).to(torch.bfloat16)
+    out = (_frag(hi), _frag(lo))
+    if key is not None:
+        if len(_PACK_CACHE) > 1024:
+            _PACK_CACHE.clear()
+        _PACK_CACHE[key] = out
+    return out
+
+
+def _wkey(weight: torch.Tensor, tag: str):
+    return (weight.data_ptr(), weight._version, tuple(weight.shape), tag)
+
+
 def _p(ctx: Ctx, t: Optional[torch.Tensor]):
     if t is None:
         return _NULL
@@ -65,13 +100,30 @@ def _w_conv(weight: torch.Tensor) -> torch.Tensor:
 
 def _igemm(ctx: Ctx, a: torch.Tensor, K: int, w_tnk: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, N: int,
            Hin: int, Win: int, Hout: int, Wout: int, ksize: int, stride: int, mode: int, act: int,
-           residual: Optional[torch.Tensor] = None, rowscale: Optional[torch.Tensor] = None, batch: int = 1) -> None:
-    """One launch over `batch` equally sized maps stored one after the other (blockIdx.z = sample)."""
+           residual: Optional[torch.Tensor] = None, rowscale: Optional[torch.Tensor] = None, batch: int = 1, prec: str = "f32",
+           wkey=None) -> None:
+    """One launch over `batch` equally sized maps stored one after the other (blockIdx.z / .y = sample)."""
     assert a.is_contiguous() and out.is_contiguous() and w_tnk.is_contiguous() and tuple(w_tnk.shape) == (ksize * ksize, N, K), \
         (tuple(w_tnk.shape), ksize, N, K)
     assert a.shape == (batch * Hin * Win, K) and out.shape == (batch * Hout * Wout, N) and K % 32 == 0 and N % 32 == 0
     assert residual is None or (residual.is_contiguous() and residual.shape == out.shape)
     lib = _lib.lib()
+    if prec == "bf16x3" and mode == CONV and (rowscale is None or batch == 1):
+        from .pack import BF16, F32
+        fhi, flo = _split_frags(w_tnk, wkey)
+        ldr = N if residual is not None else 0
+        if batch == 1 or Wout == 1:
+            rows = batch * Hin * Win
+            dims = (rows, 1, batch * Hout * Wout, 1) if (ksize == 1 and stride == 1) else (Hin, Win, Hout, Wout)
+            assert batch == 1 or (ksize == 1 and stride == 1)
+            _lib.check(lib.spei_conv_slab16(BF16, _p(ctx, a), K, K, _NULL, 0, 0, F32, ctx._tp(fhi), ctx._tp(flo), _p(ctx, bias), _p(ctx, out), N, F32,
+                                            _p(ctx, residual), ldr, _p(ctx, rowscale), *dims, N, ksize, stride, ksize // 2, act, 0, ctx._stream()),
+                       "spei_conv_slab16")
+        else:
+            _lib.check(lib.spei_conv_slab16_batched(BF16, _p(ctx, a), K, F32, ctx._tp(fhi), ctx._tp(flo), _p(ctx, bias), _p(ctx, out), F32,
+                                                    _p(ctx, residual), batch, Hin, Win, Hout, Wout, N, ksize, stride, ksize // 2, act,
+                                                    ctx._stream()), "spei_conv_slab16_batched")
+        return
     _lib.check(lib.spei_igemm_f32_batched(_p(ctx, a), K, K, _NULL, 0, 0, _p(ctx, w_tnk), _p(ctx, bias), _p(ctx, out), N,
                                           _p(ctx, residual), N if residual is not None else 0, _p(ctx, rowscale), Hin, Win, Hout, Wout, N,
                                           ksize, stride, ksize // 2, mode, act, batch, ctx._stream()), "spei_igemm_f32_batched")
@@ -121,9 +173,12 @@ class _Conv2d(torch.autograd.Function):
         b = bias.detach().contiguous()
         out = torch.empty(B * ho * wo, n, device=x.device)
         res = residual.contiguous() if residual is not None else None
-        _igemm(ctx, x, k, w, b, out, n, H, W, ho, wo, ksize, stride, CONV, ACT_RELU if relu else ACT_NONE, res, batch=B)
+        prec = _PREC.get()
+        _igemm(ctx, x, k, w, b, out, n, H, W, ho, wo, ksize, stride, CONV, ACT_RELU if relu else ACT_NONE, res, batch=B, prec=prec,
+               wkey=_wkey(weight, "fwd"))
         fctx.save_for_backward(x, weight, out if relu else None)
         fctx.meta = (B, H, W, ho, wo, ksize, stride, relu, residual is not None)
+        fctx.prec = prec
         return out
 
     @staticmethod
@@ -144,7 +199,12 @@ class _Conv2d(torch.autograd.Function):
             wt = _w_conv(weight).transpose(1, 2).contiguous()                              # [t][k][n]
             hf, wf = ho * stride, wo * stride
             dx = torch.empty(B * hf * wf, k, device=dy.device)
-            _igemm(ctx, dz, n, wt, None, dx, k, ho, wo, hf, wf, ksize, stride, CONV_T, ACT_NONE, batch=B)
+            if fctx.prec == "bf16x3" and stride == 1:
+                # stride 1: the transposed convolution IS the convolution with the taps reversed
+                _igemm(ctx, dz, n, wt.flip(0).contiguous(), None, dx, k, ho, wo, hf, wf, ksize, 1, CONV, ACT_NONE, batch=B, prec="bf16x3",
+                       wkey=_wkey(weight, "dgrad"))
+            else:
+                _igemm(ctx, dz, n, wt, None, dx, k, ho, wo, hf, wf, ksize, stride, CONV_T, ACT_NONE, batch=B)
             if (hf, wf) != (H, W):        # odd input size under stride 2: the transposed conv made one row / column too many
                 dx = dx.view(B, hf, wf, k)[:, :H, :W].reshape(B * H * W, k).contiguous()
         return dx, dweight, db, dres, None, None, None, None, None, None
@@ -225,10 +285,12 @@ class _Linear(torch.autograd.Function):
         x = x.contiguous()
         M = x.shape[0]
         out = torch.empty(M, n, device=x.device)
+        prec = _PREC.get()
         _igemm(ctx, x, k, weight.detach().reshape(1, n, k).contiguous(), bias.detach().contiguous(), out, n, M, 1, M, 1, 1, 1, CONV, ACT_NONE,
-               residual.contiguous() if residual is not None else None, rowscale)
+               residual.contiguous() if residual is not None else None, rowscale, prec=prec, wkey=_wkey(weight, "fwd"))
         fctx.save_for_backward(x, weight, rowscale)
         fctx.has_res = residual is not None
+        fctx.prec = prec
         return out
 
     @staticmethod
@@ -246,7 +308,8 @@ class _Linear(torch.autograd.Function):
         dx = None
         if fctx.needs_input_grad[0]:
             dx = torch.empty(M, k, device=dy.device)
-            _igemm(ctx, g, n, weight.detach().t().reshape(1, k, n).contiguous(), None, dx, k, M, 1, M, 1, 1, 1, CONV, ACT_NONE)
+            _igemm(ctx, g, n, weight.detach().t().reshape(1, k, n).contiguous(), None, dx, k, M, 1, M, 1, 1, 1, CONV, ACT_NONE, prec=fctx.prec,
+                   wkey=_wkey(weight, "dgrad"))
         return dx, dw.view(n, k), db, (dy if fctx.has_res else None), None
 
 
@@ -712,6 +775,21 @@ def forward_swint(model, x: torch.Tensor, scales: Optional[list] = None, bn_trai
         scales = drop_path_scales(model.cfg.depths, B, n_calls)
     h3, w3 = H // 4, W // 4
     x = x.float()
+    token = _PREC.set(_train_precision(model))
+    try:
+        return _forward_swint_graph(model, x, n, B, h3, w3, training, scales)
+    finally:
+        _PREC.reset(token)
+
+
+def _train_precision(model) -> str:
+    p = getattr(model, "train_precision", "f32")
+    if p not in ("f32", "bf16x3"):
+        raise ValueError(f"train_precision {p!r}: 'f32' or 'bf16x3'")
+    return p
+
+
+def _forward_swint_graph(model, x, n, B, h3, w3, training, scales):
     with torch.cuda.device(x.device):
         rn = model.recons_net
         f_mid = encoder(x[:, n // 2], rn, training)
@@ -840,10 +918,14 @@ def forward_speinet(model, x: torch.Tensor, scales: Optional[dict] = None, bn_tr
     if scales is None and model.training:
         scales = speinet_drop_path_scales(model.cfg.depths, zero_ref, model.n_sequence)
     out = torch.zeros(B, 3, H, W, device=x.device)
-    with torch.cuda.device(x.device):
-        for has_ref in (False, True):
-            idx = torch.tensor([i for i, z in enumerate(zero_ref) if z != has_ref], device=x.device, dtype=torch.long)
-            if idx.numel():
-                o = _branch_speinet(model, x[idx].contiguous(), has_ref, scales.get(has_ref) if scales else None, training)
-                out = out.index_copy(0, idx, o)
+    token = _PREC.set(_train_precision(model))
+    try:
+        with torch.cuda.device(x.device):
+            for has_ref in (False, True):
+                idx = torch.tensor([i for i, z in enumerate(zero_ref) if z != has_ref], device=x.device, dtype=torch.long)
+                if idx.numel():
+                    o = _branch_speinet(model, x[idx].contiguous(), has_ref, scales.get(has_ref) if scales else None, training)
+                    out = out.index_copy(0, idx, o)
+    finally:
+        _PREC.reset(token)
     return out

@@ -481,6 +481,55 @@ def test_training_graph_matches_inference_path_at_crop_size(which):
     assert all(any(a in k for a in allowed) for k in missing), missing
 
 
+@pytest.mark.parametrize("which", ["swint", "speinet"])
+def test_training_step_bf16x3_vs_f32(which):
+    """`train_precision = "bf16x3"` (forward and stride-1 data-gradient GEMMs as split products on the 16-bit matrix pipe) against the
+    fp32 step G20 / G21 pin: same batch, same DropPath factors and HEM draws — output within 2e-4 of its range (7e-6 measured), loss
+    to 1e-4.  Gradients: median 2.5e-3, worst 1e-2 of a parameter's gradient norm — ten times the distance between the fp32 step and
+    the reference's float64 gradients (G20: 2e-4 / 2e-3), and the same mechanism: the products are 2^-16-accurate instead of 2^-24, so
+    ~100x as many ReLU / max-pool / hard-example decisions within round-off of their threshold fall the other way, and each moves every
+    upstream sum by ~1/sqrt(numel).  (The reference itself trains under `set_float32_matmul_precision('medium')`, main_SPEINet.py:12:
+    TF32 / bf16 products, coarser than these.)  Bounds: worst 3e-2, median 1e-2."""
+    from speinet_amd.loss import Loss
+    from speinet_amd.speinet import default_args
+    from speinet_amd.synth import synth_frames, synth_state_dict
+    from speinet_amd import train as T
+    args = default_args()
+    args.n_sequence = 3
+    b, h, w = 3, 60, 40
+    if which == "swint":
+        from speinet_amd.swint import SPEINet
+        net = SPEINet(n_sequence=3, args=args)
+        x = synth_frames(b, h, w, seed=91)[:, :3].contiguous().to(DEV)
+        scales = T.drop_path_scales(net.cfg.depths, b, 2, generator=torch.Generator().manual_seed(3))
+    else:
+        from speinet_amd.speinet import SPEINet
+        net = SPEINet(args=args)
+        x = synth_frames(b, h, w, seed=92, zero_ref=(2,)).contiguous().to(DEV)
+        scales = T.speinet_drop_path_scales(net.cfg.depths, [False, False, True], 3, generator=torch.Generator().manual_seed(3))
+    net.load_state_dict(synth_state_dict(net.state_dict(), seed=0), strict=True)
+    net = net.to(DEV).train()
+    gt = synth_frames(b, h, w, seed=93)[:, 1].contiguous().to(DEV)
+    loss_fn = Loss("1*L1+2*HEM", device=DEV)
+    res = {}
+    for prec in ("f32", "bf16x3"):
+        net.train_precision = prec
+        net.zero_grad()
+        np.random.seed(5)
+        out = net(x, drop_path_scales=scales)
+        loss = loss_fn(out, gt)
+        loss.backward()
+        res[prec] = (out.detach().clone(), loss.item(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    net.train_precision = "f32"
+    o32, l32, g32 = res["f32"]
+    o16, l16, g16 = res["bf16x3"]
+    eo = (o16 - o32).abs().max().item() / o32.abs().max().item()
+    errs = sorted((g16[k] - g32[k]).norm().item() / max(g32[k].norm().item(), 1e-20) for k in g32 if g32[k].numel() > 4)
+    print(f"{which}: bf16x3 vs f32 step: output {eo:.1e}, loss {abs(l16 - l32):.1e}, gradients median {errs[len(errs) // 2]:.1e} worst {errs[-1]:.1e}")
+    assert set(g16) == set(g32)
+    assert eo < 2e-4 and abs(l16 - l32) < 1e-4 and errs[-1] < 3e-2 and errs[len(errs) // 2] < 1e-2
+
+
 def test_loss_curve_vs_reference(golden_dir):
     """the loss curve of N optimizer steps with DropPath disabled against the reference's own run
     (G22: swint model, two 40x40 windows, 1*L1 + 2*HEM, Adam 1e-4, BatchNorm in train mode, 6 steps).  Each step feeds on the

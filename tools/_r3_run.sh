@@ -1,4 +1,3 @@
-echo "== default"; python tools/bench_batching.py 7 2>&1 | grep ResBlocks
-for c in 1 2 3; do echo "== N32 cfg $c"; SPEI_SLAB_CFG_N32=$c python tools/bench_batching.py 7 2>&1 | grep "lv1"; done
-for c in 1 2 3 4; do echo "== N64 cfg $c"; SPEI_SLAB_CFG_N64=$c python tools/bench_batching.py 7 2>&1 | grep "lv2"; done
-for c in 1 2 3 4; do echo "== N128 cfg $c"; SPEI_SLAB_CFG_N128=$c python tools/bench_batching.py 7 2>&1 | grep "lv3"; done
+python -m pytest tests/test_gpu_train.py -x -q -k "bf16x3_vs_f32" -s 2>&1 | grep "bf16x3 vs\|passed\|failed\|Error\|error" | head
+python bench.py --train --batch 20 --steps 3 --warmup 1 --precision f32 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('f32   ', round(d['value'],1), 'crops/s', d['ms'])"
+python bench.py --train --batch 20 --steps 3 --warmup 1 --precision bf16x3 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bf16x3', round(d['value'],1), 'crops/s', d['ms'])"
