@@ -268,6 +268,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying hipGraph segments")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams for the independent neighbour-frame / reference branches of a frame")
     ap.add_argument("--branch", choices=["bs", "b"], default="bs", help="bs: with sharp reference (SearchTransfer); b: SelfTransfer")
+    ap.add_argument("--batch", type=int, default=1, help="windows per forward call (BASELINE configs[1] is batch 1; B > 1 batches the encoder passes of all samples per layer)")
     ap.add_argument("--inflight", type=int, default=2,
                     help="frames in flight: consecutive steps alternate over this many launch streams; step i + 1 starts when step i's "
                          "correlation kernel has finished, so its encoder passes run beside step i's decoder (1: one frame at a time)")
@@ -309,8 +310,9 @@ def main():
     if args.knobs:
         net.knobs = json.loads(args.knobs)
     # each rank deblurs its own frames (clip shard = rank); two distinct windows alternate so nothing is cached
-    frames = [synth_frames(1, h, w, seed=1234 + 17 * rank + i, zero_ref=(0,) if args.branch == "b" else ()).to(dev) for i in range(2)]
-    routing = [args.branch == "b"]
+    nb = max(1, args.batch)
+    frames = [synth_frames(nb, h, w, seed=1234 + 17 * rank + i, zero_ref=tuple(range(nb)) if args.branch == "b" else ()).to(dev) for i in range(2)]
+    routing = [args.branch == "b"] * nb
 
     def barrier():
         if dist is not None:
@@ -337,7 +339,7 @@ def main():
                 pr = kw.get("profile")
                 local = pr if pr is not None else {"corr_argmax": []}
                 out = net(frames[i % 2], **dict(kw, profile=local))
-                gate = local["corr_argmax"][-1][1]
+                gate = local["corr_argmax"][-1][1]            # (B > 1: the last sample's)
                 checksums[i % nfl].add_(out.double().sum())
                 if pr is not None:
                     marks[i + 1].record()
@@ -365,7 +367,7 @@ def main():
               [marks[i].elapsed_time(marks[i + nfl]) / nfl for i in range(1, args.steps + 1 - nfl)]   # same-stream neighbours
     pairs = prof["corr_argmax"]
     corr_ms = sum(s.elapsed_time(e) for s, e in pairs) / max(1, len(pairs))
-    assert len(pairs) == args.steps, "the dominant kernel must be timed once per step"
+    assert len(pairs) == args.steps * nb, "the dominant kernel must be timed once per frame"
 
     from speinet_amd.dist import gather_metrics, max_over_ranks
     tmax = max_over_ranks(dt, dev, dist)
@@ -376,7 +378,7 @@ def main():
     assert int(gathered[:, 1].sum().item()) == world * args.steps
 
     if rank == 0:
-        fps = world * args.steps / tmax
+        fps = world * args.steps * nb / tmax
         ach = corr_flops(h, w) / (corr_ms * 1e-3) / 1e12 if corr_ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.precision]
         dtype = args.precision if args.precision == "f32" else f"{args.precision} (correlation {args.corr_precision})"
@@ -386,14 +388,14 @@ def main():
             "metric": "deblurred 720p frames/sec", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * tmax / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": f"SPEINet.forward on synthetic {w}x{h} 5-frame windows, batch 1 per GPU, "
+            "config": {"workload": f"SPEINet.forward on synthetic {w}x{h} 5-frame windows, batch {nb} per GPU, "
                                    f"{'_forwardbs (SearchTransfer)' if args.branch == 'bs' else '_forwardb (SelfTransfer)'}, "
-                                   "synthetic name-keyed weights seed 0", "frames_per_step_per_gpu": 1,
+                                   "synthetic name-keyed weights seed 0", "frames_per_step_per_gpu": nb,
                        "sharding": "frames by rank, no data-path collective",
                        "launch": ("2 hipGraph segments + the correlation kernel per frame" if net.use_graph else "eager") + f", {args.streams} HIP streams"
                                  + (f"; {nfl} frames in flight (step i + 1 starts when step i's correlation kernel is done)" if nfl > 1 else "")},
             "step_ms": {"median": statistics.median(step_ms), "p10": qs[0], "p90": qs[8], "min": min(step_ms), "max": max(step_ms)},
-            "reference_call": {"value": world * args.steps / tmax_ref, "unit": "frames/s", "ms_per_step": 1e3 * tmax_ref / args.steps,
+            "reference_call": {"value": world * args.steps * nb / tmax_ref, "unit": "frames/s", "ms_per_step": 1e3 * tmax_ref / args.steps,
                                "note": "forward(x) without the routing hint: the frame-3 test runs on the device, one host sync per call"},
             "roofline": {"bound": "mfma", "kernel": prof.get("corr_kernel"), "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": ach / peak, "traffic": k_bytes, "traffic_source": tsrc, "launch_ms": corr_ms,
@@ -405,7 +407,7 @@ def main():
                          "path_hbm_frac": (path_hbm * fps / world / 8e12) if path_hbm else None},
             "checksum": float(gathered[:, 0].sum().item()),
         }
-        extras = world == 1 and not args.no_extras and (h, w) == (H, W) and args.precision == "f16"
+        extras = world == 1 and not args.no_extras and (h, w) == (H, W) and args.precision == "f16" and nb == 1
         if extras:
             # BASELINE.json configs[1] to the letter ("bf16 forward"): the same steps with bf16 operands (8-bit significands: 3e-3 dB)
             net.precision = "bf16"
@@ -423,7 +425,7 @@ def main():
                                    "corr_launch_ms": sum(s_.elapsed_time(e_) for s_, e_ in pb) / max(1, len(pb)),
                                    "parity": "|dPSNR| vs the reference 3e-3 dB (tests/test_gpu_bf16.py bound 1e-2)"}
             net.precision = args.precision
-        if world == 1 and not args.no_harness and (h, w) == (H, W) and args.precision != "f32":
+        if world == 1 and not args.no_harness and (h, w) == (H, W) and args.precision != "f32" and nb == 1:
             from speinet_amd.inference import harness_throughput
             del net, frames
             torch.cuda.empty_cache()

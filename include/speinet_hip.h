@@ -280,6 +280,13 @@ int spei_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float
 int spei_conv_wgrad_f32_batched(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* ws, int Hin, int Win,
                                 int Hout, int Wout, int N, int K, int ksize, int stride, int pad, int batch, spei_stream_t stream);
 
+/* The same weight / bias gradient with the products split on the 16-bit matrix pipe (a = ah + al in bf16: al*bh + ah*bl + ah*bh,
+ * fp32 accumulation: 2^-16 relative per product; speinet_amd/train.py `train_precision = "bf16x3"`): three v_mfma_f32_32x32x16_bf16 per
+ * 16 pixels where the fp32 kernel issues eight v_mfma_f32_32x32x2_f32.  Arguments, workspace and summation order as
+ * spei_conv_wgrad_f32_batched. */
+int spei_conv_wgrad_bf16x3_batched(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* ws, int Hin, int Win,
+                                   int Hout, int Wout, int N, int K, int ksize, int stride, int pad, int batch, spei_stream_t stream);
+
 /* ReLU backward on the output of a fused conv + ReLU: dz = dy where y > 0, else 0 (n floats, n % 4 == 0). */
 int spei_relu_bwd(const float* y, const float* dy, float* dz, int64_t n, spei_stream_t stream);
 

@@ -63,6 +63,7 @@ SIGNATURES = {
     "spei_add": (I, [P, P, P, L, P]),
     "spei_wgrad_ws_floats": (L, [I, I, I, I, I]),
     "spei_conv_wgrad_f32_batched": (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
+    "spei_conv_wgrad_bf16x3_batched": (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
     "spei_conv_wgrad_f32": (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "spei_relu_bwd": (I, [P, P, P, L, P]),
     "spei_plane_ws_floats": (L, [I, I, I]),

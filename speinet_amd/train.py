@@ -130,7 +130,7 @@ def _igemm(ctx: Ctx, a: torch.Tensor, K: int, w_tnk: torch.Tensor, bias: Optiona
 
 
 def _wgrad(ctx: Ctx, x: torch.Tensor, K: int, dy: torch.Tensor, N: int, Hin: int, Win: int, Hout: int, Wout: int, ksize: int,
-           stride: int, want_bias: bool = True, batch: int = 1):
+           stride: int, want_bias: bool = True, batch: int = 1, prec: str = "f32"):
     """dw [tap][N][K], db [N] of a Conv2d(K -> N) from its input rows x and output-gradient rows dy, summed over `batch` maps."""
     lib = _lib.lib()
     dev = x.device
@@ -144,8 +144,9 @@ def _wgrad(ctx: Ctx, x: torch.Tensor, K: int, dy: torch.Tensor, N: int, Hin: int
         ws = torch.empty(lib.spei_wgrad_ws_floats(Hout, Wout, nn_, K, ksize), device=dev)
         dyp = C.c_void_p(dy.data_ptr() + 4 * n0)
         assert dy.device == ctx.device and dy.is_contiguous() and dy.dtype == torch.float32
-        _lib.check(lib.spei_conv_wgrad_f32_batched(_p(ctx, x), K, dyp, N, _p(ctx, dwp), _p(ctx, dbp), _p(ctx, ws), Hin, Win, Hout, Wout, nn_,
-                                                   K, ksize, stride, ksize // 2, batch, ctx._stream()), "spei_conv_wgrad_f32_batched")
+        fn = lib.spei_conv_wgrad_bf16x3_batched if prec == "bf16x3" else lib.spei_conv_wgrad_f32_batched
+        _lib.check(fn(_p(ctx, x), K, dyp, N, _p(ctx, dwp), _p(ctx, dbp), _p(ctx, ws), Hin, Win, Hout, Wout, nn_,
+                      K, ksize, stride, ksize // 2, batch, ctx._stream()), "spei_conv_wgrad_batched")
         if N > 256:
             dw[:, n0:n0 + nn_] = dwp
             if want_bias:
@@ -191,7 +192,7 @@ class _Conv2d(torch.autograd.Function):
         dres = dy if has_res else None
         assert not (relu and has_res)
         dz = _relu_mask(ctx, y, dy) if relu else dy
-        dw, db = _wgrad(ctx, x, k, dz, n, H, W, ho, wo, ksize, stride, batch=B)
+        dw, db = _wgrad(ctx, x, k, dz, n, H, W, ho, wo, ksize, stride, batch=B, prec=fctx.prec)
         dweight = dw.view(ksize, ksize, n, k).permute(2, 3, 0, 1).contiguous()
         dx = None
         if fctx.needs_input_grad[0]:
@@ -304,7 +305,7 @@ class _Linear(torch.autograd.Function):
         if rowscale is not None:
             g = torch.empty_like(dy)
             _lib.check(_lib.lib().spei_scale_rows(_p(ctx, dy), _p(ctx, rowscale), _p(ctx, g), M, n, ctx._stream()), "spei_scale_rows")
-        dw, db = _wgrad(ctx, x, k, g, n, M, 1, M, 1, 1, 1)
+        dw, db = _wgrad(ctx, x, k, g, n, 1, M, 1, M, 1, 1, prec=fctx.prec)       # a 1x1 layer: the token list as ONE row of M pixels
         dx = None
         if fctx.needs_input_grad[0]:
             dx = torch.empty(M, k, device=dy.device)
