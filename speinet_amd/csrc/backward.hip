@@ -178,6 +178,107 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(const Wgrad16Params p
     }
 }
 
+// Stride-1 layers: a workgroup takes a whole ROW of taps (ty; tx = 0 .. KS-1) of its tile and chunk.  The dY fragment is gathered and
+// split once per segment for the KS taps, and the X values of the KS shifted windows are one run of 8 + KS - 1 pixels per lane,
+// gathered and split once: 3 KS MFMAs per ~(20 + 3 KS) gathers / conversions per lane instead of 3 per ~16 — the per-tap form above
+// was bound by those, not by the matrix pipe (conv_wgrad16: 193 us per layer at batch 20).
+template <int KS>
+__global__ __launch_bounds__(256) void conv_wgrad16_row_kernel(const Wgrad16Params p) {
+    typedef lpv<__bf16>::x8 bf8;
+    constexpr int NX = 8 + KS - 1;
+    __shared__ float red[4][16][64];
+    __shared__ float bred[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fk = lane >> 5;
+    int tile = blockIdx.x;
+    const int kt = tile % p.ntk; tile /= p.ntk;
+    const int nt = tile % p.ntn;
+    const int ty = tile / p.ntn;
+    const int n = nt * 32 + fr, k = kt * 32 + fr;
+    const bool nok = n < p.N, kok = k < p.K;
+    const int per_wave = p.chunk_seg / 4;
+    const int s0 = blockIdx.y * p.chunk_seg + wave * per_wave, s1 = min(p.nseg, s0 + per_wave);
+    f32x16 acc[KS];
+#pragma unroll
+    for (int t = 0; t < KS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float asum = 0.f;
+    float a[8], an[8], xx[NX], xn[NX];
+    auto load = [&](int sg, float* av, float* xv) __attribute__((always_inline)) {
+        const int row = sg / p.nseg_row, sx = sg - row * p.nseg_row;          // row = sample * Hout + oy   (Hin == Hout, Win == Wout)
+        const int smp = row / p.Hout, oy = row - smp * p.Hout;
+        const int iy = oy - p.pad + ty;
+        const bool rowok = iy >= 0 && iy < p.Hin;
+        const int ox0 = sx * 16 + 8 * fk;
+        const float* dyp = p.dy + ((size_t)row * p.Wout + ox0) * p.ldy + n;
+        const float* xp = p.x + (((size_t)smp * p.Hin + (rowok ? iy : 0)) * p.Win) * p.ldx + k;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) av[j] = (ox0 + j < p.Wout && nok) ? dyp[(size_t)j * p.ldy] : 0.f;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int ix = ox0 - p.pad + j;
+            xv[j] = (kok && rowok && ix >= 0 && ix < p.Win) ? xp[(size_t)ix * p.ldx] : 0.f;
+        }
+    };
+    if (s0 < s1) load(s0, an, xn);
+    for (int sg = s0; sg < s1; ++sg) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = an[j];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) xx[j] = xn[j];
+        if (sg + 1 < s1) load(sg + 1, an, xn);
+        bf8 ah, al;
+        __bf16 xh[NX], xl[NX];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            ah[j] = (__bf16)a[j];
+            al[j] = (__bf16)(a[j] - (float)ah[j]);
+            asum += a[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            xh[j] = (__bf16)xx[j];
+            xl[j] = (__bf16)(xx[j] - (float)xh[j]);
+        }
+        // pixels of the segment past the row's end carry dY = 0: their products vanish whatever X holds
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            bf8 bh, bl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { bh[j] = xh[j + t]; bl[j] = xl[j + t]; }
+            acc[t] = mfma16(al, bh, acc[t]);
+            acc[t] = mfma16(ah, bl, acc[t]);
+            acc[t] = mfma16(ah, bh, acc[t]);
+        }
+    }
+    bred[wave][lane] = asum;
+    __syncthreads();
+    if (p.bpart && ty == 0 && kt == 0 && tid < 32 && nt * 32 + tid < p.N) {
+        float bsum = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) bsum += bred[wv][tid] + bred[wv][tid + 32];
+        p.bpart[(size_t)blockIdx.y * p.N + nt * 32 + tid] = bsum;
+    }
+    const int T = p.ks * p.ks;
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[t][r];
+        __syncthreads();
+        if (wave == 0) {
+            float* dst = p.part + (((size_t)blockIdx.y * T + ty * p.ks + t) * p.N) * p.K;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
+                const int row = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;       // n
+                if (row < p.N && k < p.K) dst[(size_t)row * p.K + k] = v;
+            }
+        }
+    }
+}
+
 // out[i] = sum over `nparts` partials, fixed order; a second array (the bias partials) rides in the same launch: its elements follow
 // the first array's in the index space (one launch per weight gradient instead of two: 1 200 fewer launches per training step)
 __global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t count, int nparts,
@@ -348,8 +449,18 @@ __global__ __launch_bounds__(256) void resblock_apply_bwd_kernel(const ApplyBwdP
 
 }  // namespace
 
+// partial slices a weight gradient may be split into (the workspace holds that many copies of it): 64 for the per-tap kernels; the
+// tap-row kernel has 1 / ksize of the workgroups per slice and takes up to 256 slices for ~2k workgroups per launch
+static int wgrad_slices(int N, int K, int ksize) {
+    const int per_slice = ksize * cdiv(N, 32) * cdiv(K, 32);
+    int want = cdiv(2048, per_slice);
+    want = want < 16 ? 16 : (want > 256 ? 256 : want);
+    return want > 64 ? want : 64;
+}
+
 extern "C" int64_t spei_wgrad_ws_floats(int Hout, int Wout, int N, int K, int ksize) {
-    return (int64_t)64 * ksize * ksize * N * K + 64 * 256;
+    const int64_t sl = wgrad_slices(N, K, ksize);
+    return sl * ksize * ksize * N * K + sl * 256;
 }
 
 static int conv_wgrad_run(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* ws, int Hin, int Win,
@@ -370,15 +481,20 @@ static int conv_wgrad_run(const float* x, int ldx, const float* dy, int ldy, flo
         q.Hin = Hin; q.Win = Win; q.Hout = Hout; q.Wout = Wout; q.ks = ksize; q.stride = stride; q.pad = pad;
         q.nseg_row = cdiv(Wout, 16);
         q.nseg = batch * Hout * q.nseg_row;
-        int chunk = cdiv(q.nseg, 64);
+        const bool rows = stride == 1;            // a workgroup per tap ROW: 1 / ksize of the workgroups per chunk, so more chunks
+        q.ntn = cdiv(N, 32); q.ntk = cdiv(K, 32);
+        const int want = rows ? wgrad_slices(N, K, ksize) : 64;
+        int chunk = cdiv(q.nseg, want);
         chunk = ((chunk + 3) / 4) * 4;
         if (chunk < 4) chunk = 4;
         q.chunk_seg = chunk;
         const int nchunks = cdiv(q.nseg, chunk);
-        q.ntn = cdiv(N, 32); q.ntk = cdiv(K, 32);
-        float* bpart = ws + (size_t)64 * T * N * K;
+        float* bpart = ws + (size_t)wgrad_slices(N, K, ksize) * T * N * K;
         q.bpart = dbias ? bpart : nullptr;
-        hipLaunchKernelGGL(conv_wgrad16_kernel, dim3(T * q.ntn * q.ntk, nchunks), dim3(256), 0, st, q);
+        if (!rows) hipLaunchKernelGGL(conv_wgrad16_kernel, dim3(T * q.ntn * q.ntk, nchunks), dim3(256), 0, st, q);
+        else if (ksize == 5) hipLaunchKernelGGL(conv_wgrad16_row_kernel<5>, dim3(ksize * q.ntn * q.ntk, nchunks), dim3(256), 0, st, q);
+        else if (ksize == 3) hipLaunchKernelGGL(conv_wgrad16_row_kernel<3>, dim3(ksize * q.ntn * q.ntk, nchunks), dim3(256), 0, st, q);
+        else hipLaunchKernelGGL(conv_wgrad16_row_kernel<1>, dim3(ksize * q.ntn * q.ntk, nchunks), dim3(256), 0, st, q);
         const int64_t count = (int64_t)T * N * K;
         hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(count + (dbias ? N : 0), 256)), dim3(256), 0, st, ws, dw, count, nchunks,
                            dbias ? bpart : nullptr, dbias, dbias ? N : 0);
@@ -395,7 +511,7 @@ static int conv_wgrad_run(const float* x, int ldx, const float* dy, int ldy, flo
     p.chunk_px = chunk;
     const int nchunks = cdiv(M, chunk);
     p.ntn = cdiv(N, 32); p.ntk = cdiv(K, 32);
-    float* bpart = ws + (size_t)64 * T * N * K;
+    float* bpart = ws + (size_t)wgrad_slices(N, K, ksize) * T * N * K;
     p.bpart = dbias ? bpart : nullptr;
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(T * p.ntn * p.ntk, nchunks), dim3(256), 0, st, p);
     const int64_t count = (int64_t)T * N * K;

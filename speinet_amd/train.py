@@ -557,8 +557,15 @@ def _gate_maps(rowmax, rowmean, colmax, colmean, mean, prm, bn_train: bool, upda
     def conv21(z, w, k):
         # the 2 -> 1 channel k x k convolution as unfold + one matrix product: the library convolution's weight gradient is not
         # bitwise reproducible for these shapes (atomics), this form is
+        # torch's im2col runs one launch per batch element (60 maps per ResBlock at batch 20: 2 900 launches per step): the batch is laid out
+        # as ONE tall map, each sample between its own zero rows, so the whole batch is one unfold and one product
         bsz, _, a, b = z.shape
-        return (w.reshape(1, -1) @ F.unfold(z, k, padding=k // 2)).view(bsz, 1, a, b)
+        pd = k // 2
+        tall = F.pad(z, (0, 0, pd, pd)).permute(1, 0, 2, 3).reshape(1, 2, bsz * (a + 2 * pd), b)
+        cols = F.unfold(tall, k, padding=(0, pd))                              # [1, 2 k k, (bsz (a + 2 pd) - k + 1) * b]
+        out = (w.reshape(1, -1) @ cols).view(bsz * (a + 2 * pd) - 2 * pd, b)
+        out = F.pad(out, (0, 0, 0, 2 * pd)).view(bsz, a + 2 * pd, b)[:, :a]     # row r of sample i sits at i (a + 2 pd) + r
+        return out.reshape(bsz, 1, a, b)
 
     z1 = torch.stack((rowmax, rowmean), dim=1)                              # [B, 2, H, C]: conv "height" = H, "width" = C
     g1 = bn(conv21(z1, cw_w, 7), cw_g, cw_b, cw_rm, cw_rv)[:, 0]            # [B, H, C]
