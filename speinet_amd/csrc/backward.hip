@@ -279,6 +279,102 @@ __global__ __launch_bounds__(256) void conv_wgrad16_row_kernel(const Wgrad16Para
     }
 }
 
+// 1x1 layers (the Swin linears): no taps to share the gathers, so a workgroup takes a 64 x 64 tile (2 x 2 MFMA tiles): the dY values
+// of two channel tiles and the X values of two feed twelve MFMAs per 32 gathers per lane instead of three per 16.
+__global__ __launch_bounds__(256) void conv_wgrad16_1x1_kernel(const Wgrad16Params p) {
+    typedef lpv<__bf16>::x8 bf8;
+    __shared__ float red[4][16][64];
+    __shared__ float bred[4][2][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fk = lane >> 5;
+    const int ntk2 = (p.ntk + 1) / 2;
+    const int kt2 = blockIdx.x % ntk2, nt2 = blockIdx.x / ntk2;
+    const int per_wave = p.chunk_seg / 4;
+    const int s0 = blockIdx.y * p.chunk_seg + wave * per_wave, s1 = min(p.nseg, s0 + per_wave);
+    int nn[2], kk[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { nn[i] = (nt2 * 2 + i) * 32 + fr; kk[i] = (kt2 * 2 + i) * 32 + fr; }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float asum[2] = {0.f, 0.f};
+    float a[2][8], x[2][8], an[2][8], xn[2][8];
+    auto load = [&](int sg, float (*av)[8], float (*xv)[8]) __attribute__((always_inline)) {
+        const int row = sg / p.nseg_row, sx = sg - row * p.nseg_row;          // 1x1, stride 1: input pixel == output pixel
+        const int ox0 = sx * 16 + 8 * fk;
+        const size_t m = (size_t)row * p.Wout + ox0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool in = ox0 + j < p.Wout;
+                av[i][j] = (in && nn[i] < p.N) ? p.dy[(m + j) * p.ldy + nn[i]] : 0.f;
+                xv[i][j] = (in && kk[i] < p.K) ? p.x[(m + j) * p.ldx + kk[i]] : 0.f;
+            }
+    };
+    if (s0 < s1) load(s0, an, xn);
+    for (int sg = s0; sg < s1; ++sg) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a[i][j] = an[i][j]; x[i][j] = xn[i][j]; }
+        if (sg + 1 < s1) load(sg + 1, an, xn);
+        bf8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                ah[i][j] = (__bf16)a[i][j];
+                al[i][j] = (__bf16)(a[i][j] - (float)ah[i][j]);
+                bh[i][j] = (__bf16)x[i][j];
+                bl[i][j] = (__bf16)(x[i][j] - (float)bh[i][j]);
+                asum[i] += a[i][j];
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = mfma16(al[i], bh[j], acc[i][j]);
+                acc[i][j] = mfma16(ah[i], bl[j], acc[i][j]);
+                acc[i][j] = mfma16(ah[i], bh[j], acc[i][j]);
+            }
+    }
+    bred[wave][0][lane] = asum[0];
+    bred[wave][1][lane] = asum[1];
+    __syncthreads();
+    if (p.bpart && kt2 == 0 && tid < 64) {
+        const int i = tid >> 5, c = tid & 31;
+        if ((nt2 * 2 + i) * 32 + c < p.N) {
+            float bsum = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) bsum += bred[wv][i][c] + bred[wv][i][c + 32];
+            p.bpart[(size_t)blockIdx.y * p.N + (nt2 * 2 + i) * 32 + c] = bsum;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[i][j][r];
+            __syncthreads();
+            if (wave == 0) {
+                float* dst = p.part + ((size_t)blockIdx.y * p.N) * p.K;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
+                    const int row = (nt2 * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;       // n
+                    if (row < p.N && kk[j] < p.K) dst[(size_t)row * p.K + kk[j]] = v;
+                }
+            }
+        }
+}
+
 // out[i] = sum over `nparts` partials, fixed order; a second array (the bias partials) rides in the same launch: its elements follow
 // the first array's in the index space (one launch per weight gradient instead of two: 1 200 fewer launches per training step)
 __global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t count, int nparts,
@@ -494,7 +590,7 @@ static int conv_wgrad_run(const float* x, int ldx, const float* dy, int ldy, flo
         if (!rows) hipLaunchKernelGGL(conv_wgrad16_kernel, dim3(T * q.ntn * q.ntk, nchunks), dim3(256), 0, st, q);
         else if (ksize == 5) hipLaunchKernelGGL(conv_wgrad16_row_kernel<5>, dim3(ksize * q.ntn * q.ntk, nchunks), dim3(256), 0, st, q);
         else if (ksize == 3) hipLaunchKernelGGL(conv_wgrad16_row_kernel<3>, dim3(ksize * q.ntn * q.ntk, nchunks), dim3(256), 0, st, q);
-        else hipLaunchKernelGGL(conv_wgrad16_row_kernel<1>, dim3(ksize * q.ntn * q.ntk, nchunks), dim3(256), 0, st, q);
+        else hipLaunchKernelGGL(conv_wgrad16_1x1_kernel, dim3(((q.ntn + 1) / 2) * ((q.ntk + 1) / 2), nchunks), dim3(256), 0, st, q);
         const int64_t count = (int64_t)T * N * K;
         hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(count + (dbias ? N : 0), 256)), dim3(256), 0, st, ws, dw, count, nchunks,
                            dbias ? bpart : nullptr, dbias, dbias ? N : 0);
