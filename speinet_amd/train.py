@@ -59,29 +59,37 @@ def _ctx(device) -> Ctx:
 import contextvars
 
 _PREC = contextvars.ContextVar("speinet_train_precision", default="f32")
-_PACK_CACHE: "dict" = {}
 
 
-def _split_frags(w_tnk: torch.Tensor, key=None):
-    """[tap][N][K] fp32 -> (hi, lo) bf16 in MFMA fragment order (pack._frag).  `key`: (data_ptr, version, tag) of the parameter the
-    matrix was derived from — the same weight is packed once per optimizer step however many encoder passes use it."""
+def _split_frags(w_tnk: torch.Tensor, owner=None):
+    """[tap][N][K] fp32 -> (hi, lo) bf16 in MFMA fragment order (pack._frag).  `owner` = (parameter tensor, tag): the packed pair is
+    kept ON that tensor object together with the `_version` it was made from — the same weight is packed once per optimizer step
+    however many encoder passes use it, and nothing can outlive or be mistaken for another parameter (an address-keyed table can:
+    a freed parameter's address is handed to the next model's)."""
     from .pack import _frag
-    if key is not None:
-        hit = _PACK_CACHE.get(key)
-        if hit is not None:
-            return hit
+    cache = tag = None
+    if owner is not None:
+        weight, tag = owner
+        cache = getattr(weight, "_spei_split", None)
+        if cache is not None:
+            hit = cache.get(tag)
+            if hit is not None and hit[0] == weight._version:
+                return hit[1]
     hi = w_tnk.to(torch.bfloat16)
     lo = (w_tnk - hi.float()).to(torch.bfloat16)
     out = (_frag(hi), _frag(lo))
-    if key is not None:
-        if len(_PACK_CACHE) > 1024:
-            _PACK_CACHE.clear()
-        _PACK_CACHE[key] = out
+    if owner is not None:
+        try:
+            if cache is None:
+                cache = weight._spei_split = {}
+            cache[tag] = (weight._version, out)
+        except AttributeError:
+            pass
     return out
 
 
 def _wkey(weight: torch.Tensor, tag: str):
-    return (weight.data_ptr(), weight._version, tuple(weight.shape), tag)
+    return (weight, tag)
 
 
 def _p(ctx: Ctx, t: Optional[torch.Tensor]):
