@@ -41,6 +41,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import statistics
@@ -429,7 +430,8 @@ def main():
             from speinet_amd.inference import harness_throughput
             del net, frames
             torch.cuda.empty_cache()
-            line["harness"] = harness_throughput(100, args.precision)
+            with contextlib.redirect_stdout(sys.stderr):       # the harness logs its configuration; stdout carries the one JSON line
+                line["harness"] = harness_throughput(100, args.precision)
         if extras:
             # BASELINE.json configs[4]: one training step of the swint model on 200x200 crops (trainer/trainer_swint.py), batch 20
             torch.cuda.empty_cache()

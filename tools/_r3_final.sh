@@ -1,9 +1,9 @@
 set -e
-python -m pytest tests -x -q -m gpu > gpurun_out/r3_gpu_tests_final.log 2>&1 || true
-tail -3 gpurun_out/r3_gpu_tests_final.log
+REV=${1:-final}
+mkdir -p gpurun_out/r03
 python bench.py > gpurun_out/r3_bench_final.json 2> gpurun_out/r3_bench_final.err
-python -c "import json;d=json.load(open('gpurun_out/r3_bench_final.json'));print(round(d['value'],2),'fps', round(d['roofline']['launch_ms'],2),'ms corr; bf16', round(d['bf16_letter']['value'],2),'; harness', round(d['harness']['value'],2),'; train', round(d['train']['value'],1),'; cpu', d['cpu_baseline']['sample'][:120])"
-bash tools/prof_all.sh 0a68c44 > gpurun_out/r3_prof_all.log 2>&1
+python -c "import json;d=json.loads(open('gpurun_out/r3_bench_final.json').read().strip().splitlines()[-1]);print(round(d['value'],2),'fps', round(d['roofline']['launch_ms'],2),'ms corr; bf16', round(d['bf16_letter']['value'],2),'; harness', round(d['harness']['value'],2),'; train', round(d['train']['value'],1),'; cpu', d['cpu_baseline']['sample'][:120])"
+bash tools/prof_all.sh $REV > gpurun_out/r3_prof_all.log 2>&1
 tail -3 gpurun_out/r3_prof_all.log
 python tools/ablate_parity.py --out gpurun_out/r03/ablate_parity.json > gpurun_out/r03/r03_parity_ablation.txt 2>&1
 tail -3 gpurun_out/r03/r03_parity_ablation.txt | cut -c1-160
