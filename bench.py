@@ -56,7 +56,7 @@ sys.path.insert(0, ROOT)
 H, W = 720, 1280
 # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters: dense matrix peaks (never the 2:1-sparsity figures)
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0, "f16": 2500.0}
-TRAFFIC_FILES = ("r02_traffic.json", "r01_traffic.json")
+TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
 
 
 def path_flops(h: int, w: int) -> float:
