@@ -182,6 +182,9 @@ class Ctx:
       corr_bf16       "f16" with corr "top2": the candidate pass of the correlation runs on bf16 operands (True, default) instead of
                       f16.  The fp32 re-score decides the winner and S either way (G14: 16 more of 57600 positions differ, dPSNR
                       +1e-6 dB); bf16 operands let the chip hold a ~7 % higher MFMA clock on this kernel (tools/bench_corr.py)
+      corr_diag       corr "top2", query and reference map of one size (every call the model makes): the candidate pass is the
+                      diagonal-sliding kernel (corr_diag16.hip): each row-against-row term of the 3x3-patch score is computed once and
+                      shared by the three patch rows that use it — a third of the bmm's flops, same fp32 sums.  Off: the slab kernel
     stage        {stage name: {field: value}} overrides applied by `for_stage` (engine: "enc", "swin", "search", "decode", and inside
                  "decode" the stacks "dec2" (decoder_second), "dec1" (decoder_first), "out" (outBlock) and its final conv "tail")
     profile      None, or {op name: [(start_event, end_event), ...]} filled on the launch stream (bench.py)
@@ -191,7 +194,7 @@ class Ctx:
     ACT_NONE, ACT_RELU, ACT_GELU = ACT_NONE, ACT_RELU, ACT_GELU
     CONV, CONV_T = CONV, CONV_T
     _FIELDS = ("precision", "corr_precision", "device", "use_slab", "bf16_storage", "x1_bf16", "fuse_mlp", "fuse_attn",
-               "fuse_block", "commute_upconv", "commute_any", "corr_bf16", "fuse_apply", "split_decode", "batch_enc", "stage", "profile", "capture")
+               "fuse_block", "commute_upconv", "commute_any", "corr_bf16", "corr_diag", "fuse_apply", "split_decode", "batch_enc", "stage", "profile", "capture")
     # stages of an f16 frame that run in split (bf16x3) arithmetic by default, see `split_decode`
     SPLIT_STAGES = ("glue", "glue1", "dec2")
     __slots__ = _FIELDS
@@ -199,7 +202,7 @@ class Ctx:
     def __init__(self, precision: str = "f32", corr_precision: str = "bf16x3", device=None, use_slab: bool = True,
                  bf16_storage: bool = True, x1_bf16: bool = True, fuse_mlp: bool = True, fuse_attn: bool = True,
                  fuse_block: bool = False, commute_upconv: bool = True, commute_any: bool = False, corr_bf16: bool = True,
-                 fuse_apply: bool = False, split_decode: bool = True, batch_enc: bool = True,
+                 corr_diag: bool = True, fuse_apply: bool = False, split_decode: bool = True, batch_enc: bool = True,
                  stage: Optional[dict] = None,
                  profile: Optional[dict] = None, capture: Optional[dict] = None):
         if precision not in PRECISIONS:
@@ -220,7 +223,7 @@ class Ctx:
         object.__setattr__(self, "device", device)
         for k, v in (("use_slab", use_slab), ("bf16_storage", bf16_storage), ("x1_bf16", x1_bf16), ("fuse_mlp", fuse_mlp),
                      ("fuse_attn", fuse_attn), ("fuse_block", fuse_block), ("commute_upconv", commute_upconv), ("commute_any", commute_any),
-                     ("corr_bf16", corr_bf16), ("fuse_apply", fuse_apply), ("split_decode", split_decode), ("batch_enc", batch_enc)):
+                     ("corr_bf16", corr_bf16), ("corr_diag", corr_diag), ("fuse_apply", fuse_apply), ("split_decode", split_decode), ("batch_enc", batch_enc)):
             object.__setattr__(self, k, bool(v))
         object.__setattr__(self, "stage", dict(stage) if stage else {})
         object.__setattr__(self, "profile", profile)
@@ -601,11 +604,18 @@ class Ctx:
         if rescore:
             arg2 = torch.empty(n, device=dev, dtype=torch.int32)
             s2 = torch.empty(n, device=dev)
-            main = (lib.spei_corr_slab_top2_16, "spei_corr_slab_top2_16",
-                    (f16, tp(parts[0]), tp(parts[2]), tp(inv_lr), tp(inv_ref), *dims, tp(s), tp(arg), tp(s2), tp(arg2), tp(ws)))
+            diag = self.corr_diag and (lr.H, lr.W) == (ref.H, ref.W)
+            if diag:
+                ws = torch.empty(lib.spei_corr_diag_ws_floats(lr.H, lr.W), device=dev)
+                main = (lib.spei_corr_diag_top2_16, "spei_corr_diag_top2_16",
+                        (f16, tp(parts[0]), tp(parts[2]), tp(inv_ref), lr.H, lr.W, lr.C, tp(s), tp(arg), tp(s2), tp(arg2), tp(ws)))
+            else:
+                main = (lib.spei_corr_slab_top2_16, "spei_corr_slab_top2_16",
+                        (f16, tp(parts[0]), tp(parts[2]), tp(inv_lr), tp(inv_ref), *dims, tp(s), tp(arg), tp(s2), tp(arg2), tp(ws)))
             post = (lib.spei_corr_rescore, "spei_corr_rescore",
                     (fp(lr), lr.ld, fp(ref), ref.ld, tp(inv_lr), tp(inv_ref), *dims, tp(s), tp(arg), tp(s2), tp(arg2)))
-            return CorrPlan(self, s, arg, f"corr_slab_kernel<top2, {fname}>", [main], [post], (lr, ref, inv_lr, inv_ref, ws, parts, s2, arg2))
+            return CorrPlan(self, s, arg, f"corr_{'diag' if diag else 'slab'}_kernel<top2, {fname}>", [main], [post],
+                            (lr, ref, inv_lr, inv_ref, ws, parts, s2, arg2))
         args = (tp(parts[0]), tp(parts[1]), tp(parts[2]), tp(parts[3]), tp(inv_lr), tp(inv_ref), *dims, tp(s), tp(arg), tp(ws))
         if self.use_slab and lr.C == 128:
             main = (lib.spei_corr_slab16, "spei_corr_slab16", (f16, *args))

@@ -1,0 +1,91 @@
+"""The diagonal-sliding candidate kernel of the correlation (csrc/corr_diag16.hip) against the float64 oracle of
+model/SearchTransfer.py:26-34 (normalised 3x3 unfold, bmm, max over the reference positions) and against the slab kernel it
+replaces: ragged maps (partial tiles, heights that are not a multiple of the 4 diagonals of a workgroup, maps smaller than one
+tile, single rows), exact ties, walks cut into segments."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from speinet_amd.ops import Ctx, FMap  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def rnd(seed, *shape):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def fm(x):
+    n, c, h, w = x.shape
+    assert n == 1
+    return FMap(x[0].permute(1, 2, 0).reshape(h * w, c).contiguous().to(DEV), h, w, c)
+
+
+def oracle_top2(lr3, rf3):
+    lu = F.normalize(F.unfold(lr3, (3, 3), padding=1), dim=1)
+    ru = F.normalize(F.unfold(rf3, (3, 3), padding=1).permute(0, 2, 1), dim=2)
+    r = torch.bmm(ru.double(), lu.double())[0]                       # [Nr, Nl]
+    return r, torch.topk(r, min(2, r.shape[0]), dim=0)
+
+
+@pytest.mark.parametrize("h,w", [(37, 45), (20, 30), (64, 64), (9, 130), (1, 5), (3, 3), (2, 70), (50, 50), (45, 80), (4, 64), (5, 65)])
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_corr_diag_vs_oracle(h, w, mode):
+    lr3, rf3 = rnd(100 + h, 1, 128, h, w), rnd(200 + w, 1, 128, h, w)
+    r, top = oracle_top2(lr3, rf3)
+    ops = Ctx(mode, "top2", device=DEV)
+    inv_l, inv_r = ops.patch_invnorm(fm(lr3)), ops.patch_invnorm(fm(rf3))
+    plan = ops.corr_plan(fm(lr3), fm(rf3), inv_l, inv_r)
+    assert plan.kernel.startswith("corr_diag_kernel")
+    plan.launch()
+    s, arg = plan.s, plan.arg
+    diff = arg.cpu().long() != top.indices[0]
+    if top.values.shape[0] > 1:
+        margin = (top.values[0] - top.values[1])[diff]
+        assert diff.sum().item() <= 2 and (margin < 1e-6).all(), (mode, diff.sum().item(), margin)
+    else:
+        assert not diff.any()
+    assert (s.cpu().double() - top.values[0]).abs().max().item() < 1e-6
+    # same decision as the slab kernel's candidate pass + re-score
+    ops0 = ops.replace(corr_diag=False)
+    plan0 = ops0.corr_plan(fm(lr3), fm(rf3), inv_l, inv_r)
+    assert plan0.kernel.startswith("corr_slab_kernel")
+    plan0.launch()
+    assert (plan0.arg != arg).sum().item() <= 2
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_corr_diag_exact_ties(mode):
+    """Many bit-identical reference patches (a constant reference map away from its border, and a query map tiled from one
+    row): the lowest index among the exact maxima must win, as torch.max does.  Positive features, so that every score is
+    positive: the position tag in the low mantissa bits of a candidate key orders equal scores by position only then (a
+    negative maximum with exact ties is broken towards the HIGHER position by both candidate kernels; the re-score still
+    returns a maximal position)."""
+    h, w = 22, 70
+    lr3 = rnd(7, 1, 128, 1, w).abs().expand(1, 128, h, w).contiguous()
+    rf3 = rnd(8, 1, 128, 1, 1).abs().expand(1, 128, h, w).contiguous()
+    r, top = oracle_top2(lr3, rf3)
+    ops = Ctx(mode, "top2", device=DEV)
+    inv_l, inv_r = ops.patch_invnorm(fm(lr3)), ops.patch_invnorm(fm(rf3))
+    s, arg = ops.corr_argmax(fm(lr3), fm(rf3), inv_l, inv_r)
+    s0, arg0 = ops.replace(corr_diag=False).corr_argmax(fm(lr3), fm(rf3), inv_l, inv_r)
+    # the slab kernel compares candidate keys WITH their in-block position tag across reference blocks, so among exact ties it may
+    # keep a later block's first position; this kernel compares (score, index): same maximum, never a higher index
+    assert (s - s0).abs().max().item() < 1e-6 and (arg <= arg0).all()
+    # the lowest index among the positions whose float64 score equals the maximum (to round-off)
+    first = (r >= r.max(dim=0, keepdim=True).values - 1e-12).float().argmax(dim=0)
+    assert torch.equal(arg.cpu().long(), first)
+
+
+def test_corr_diag_candidates_contain_argmax_720p_rows():
+    """A 720p-wide map (5 tiles per row, walk cut into segments): the re-scored winner equals the slab kernel's everywhere."""
+    h, w = 48, 320
+    lr3, rf3 = rnd(31, 1, 128, h, w), rnd(32, 1, 128, h, w)
+    ops = Ctx("f16", "top2", device=DEV)
+    inv_l, inv_r = ops.patch_invnorm(fm(lr3)), ops.patch_invnorm(fm(rf3))
+    s, arg = ops.corr_argmax(fm(lr3), fm(rf3), inv_l, inv_r)
+    s0, arg0 = ops.replace(corr_diag=False).corr_argmax(fm(lr3), fm(rf3), inv_l, inv_r)
+    assert (arg != arg0).sum().item() <= 2
+    assert (s - s0).abs().max().item() < 1e-6
