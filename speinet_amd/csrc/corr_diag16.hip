@@ -255,13 +255,6 @@ __global__ __launch_bounds__(64 * DM) void corr_diag_kernel(const CorrDiagParams
     if (active && a_end < a1) emit(a_end, P1, 0.f);
 }
 
-// ---- version 2: the same walk, software-pipelined by query halves ---------------------------------------------------------------
-// The fold and the sliding sums are vector work (about 7 instructions per score) that version 1 runs AFTER a step's 96 MFMAs, the
-// matrix pipe idle meanwhile.  Here a step is two phases of 48 MFMAs, one per 32-query half of the tile, and the vector work of
-// the half that was completed by the PREVIOUS phase runs in the issue gaps of the current one (an MFMA holds vector issue for 8 of
-// its 32 cycles).  The step body is one basic block: loads of the next rows are clamped instead of skipped, positions beyond the
-// map carry a NaN normaliser (v_max / v_med3 drop a NaN operand) instead of a second fold variant, and only the final stores are
-// predicated.
 template <typename F, int... S>
 __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, S...>) {
     (f(std::integral_constant<int, S>{}), ...);
@@ -270,280 +263,6 @@ __device__ __forceinline__ float vmax(float a, float b) {          // v_max_f32 
     float d;
     asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
     return d;
-}
-
-template <typename LP>
-__global__ __launch_bounds__(64 * DM) void corr_diag2_kernel(const CorrDiagParams<LP> p) {
-    typedef typename lpv<LP>::x8 lp8;
-    constexpr int C = 128;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* fbuf = smem;                                      // [2][DROWB]
-    unsigned char* gring = smem + 2 * DROWB;                         // [DRING][DROWB]
-    float* inv_s = reinterpret_cast<float*>(smem + (2 + DRING) * DROWB);   // [DINV][DT]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 31, fk = lane >> 5;
-    int bid = blockIdx.x;
-    const int group = bid % p.ngroups; bid /= p.ngroups;
-    const int kxt = bid % p.xtiles; bid /= p.xtiles;
-    const int qxt = bid % p.xtiles;
-    const int seg = bid / p.xtiles;
-    const int H = p.H, W = p.W;
-    const int d0 = group * DM, delta = d0 + wave;
-    const bool active = delta < H;
-    const int a0 = seg * p.seg_len, a1 = min(H, a0 + p.seg_len);
-    const int a_start = max(a0 - 1, 0), a_end = min(a1, H - 1);
-    const int qx0 = qxt * DT, kx0 = kxt * DT;
-    const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
-    const float qnan = __builtin_nanf("");
-
-    auto ref_row = [&](int rho) { return (rho + d0) % H; };
-
-    for (int idx = tid; idx < (1 + DM) * DPIECES; idx += 64 * DM) {
-        const int which = idx / DPIECES, rem = idx - which * DPIECES;
-        const int pix = rem >> 4, c16 = rem & 15;
-        const bool q = which == 0;
-        const int rho = a_start + which - 1;
-        const int row = q ? a_start : ref_row(rho);
-        const int gx = (q ? qx0 : kx0) - 1 + pix;
-        const LP* src = q ? p.lr : p.ref;
-        const bool ok = (gx >= 0) & (gx < W);
-        unsigned char* dst = q ? fbuf : gring + (rho % DRING) * DROWB;
-        *reinterpret_cast<u32x4*>(dst + pix * DPITCH + c16 * 16) =
-            ok ? *reinterpret_cast<const u32x4*>(src + ((size_t)row * W + gx) * C + c16 * 8) : zero4;
-    }
-    for (int idx = tid; idx < DINV * DT; idx += 64 * DM) {           // every slot defined: the pipeline's first fold reads one early
-        const int k = idx >> 6, rho = a_start + k, x = kx0 + (idx & 63);
-        inv_s[(rho % DINV) * DT + (idx & 63)] = (k < DM && x < W) ? p.inv_ref[(size_t)ref_row(rho) * W + x] : qnan;
-    }
-    __syncthreads();
-
-    int abase[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) abase[i] = (32 * i + fr) * DPITCH + fk * 16;
-    const size_t pbase = ((size_t)delta * p.xtiles + kxt) * H;       // row of this wave's (delta, reference tile) slot
-
-    // D tiles by query half: S?a / S?b alternate between "being computed" and "previous row"; P? = pending two-term sums
-    f32x16 S0a[2], S0b[2], S1a[2], S1b[2], P0[2], P1[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { S0a[i][r] = 0.f; S0b[i][r] = 0.f; S1a[i][r] = 0.f; S1b[i][r] = 0.f; P0[i][r] = 0.f; P1[i][r] = 0.f; }
-
-    // One phase = the D tile of query half JW of the current row on the matrix pipe (48 MFMAs into XW: 3 taps x 8 k-steps x 2
-    // reference halves) with the vector work of the half completed by the previous phase in its issue gaps:
-    //   scores of row aq = P + m X, folded to the two best keys of this lane's query position; then P <- m Pold + X
-    // (X = D tile of row aq + 1, Pold = D tile of row aq; store: wave-uniform, row aq is one of this workgroup's rows).
-    // Every instruction of both streams is an `asm volatile`: their order in the source IS the schedule (one fold element per
-    // MFMA gap: 6 vector instructions = the 24 issue cycles an MFMA leaves), and the accumulators are pinned to VGPRs ("v"), so
-    // nothing moves between the register files.  The compiler knows no XDL hazards of these instructions: an element of X is
-    // read nine MFMAs after the one that wrote it at the earliest (X is the tile the PREVIOUS phase completed).
-    auto phase = [&](auto JW, const unsigned char* ga, const unsigned char* fb, f32x16 (&XW)[2], int aq, const f32x16 (&X)[2],
-                     const f32x16 (&Pold)[2], f32x16 (&P)[2], float m, bool store) __attribute__((always_inline)) {
-        constexpr int jw = decltype(JW)::value, jp = jw ^ 1;          // half on the matrix pipe / half on the vector pipe
-        constexpr int NS = 24;
-        lp8 fa[2][2], fq[2];
-        auto load_frags = [&](int s, int slot) __attribute__((always_inline)) {
-            const int off = (s >> 3) * DPITCH + (s & 7) * 32;
-            fa[slot][0] = *reinterpret_cast<const lp8*>(ga + abase[0] + off);
-            fa[slot][1] = *reinterpret_cast<const lp8*>(ga + abase[1] + off);
-            fq[slot] = *reinterpret_cast<const lp8*>(fb + abase[jw] + off);
-        };
-        auto mfma = [&](int s, int i, int c) __attribute__((always_inline)) {
-            if constexpr (__is_same(LP, __bf16)) {
-                if (s == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(XW[i]) : "v"(fa[c][i]), "v"(fq[c]));
-                else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(XW[i]) : "v"(fa[c][i]), "v"(fq[c]));
-            } else {
-                if (s == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(XW[i]) : "v"(fa[c][i]), "v"(fq[c]));
-                else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(XW[i]) : "v"(fa[c][i]), "v"(fq[c]));
-            }
-        };
-        const float* pinv = inv_s + ((aq + wave) & (DINV - 1)) * DT + 4 * fk;
-        f32x4 q[2];                                                  // normalisers of 4 rows, fetched one quad ahead
-        auto load_q = [&](int g4) __attribute__((always_inline)) {
-            q[g4 & 1] = *reinterpret_cast<const f32x4*>(pinv + (g4 >> 2) * 32 + (g4 & 3) * 8);
-        };
-        float lk1 = -INFINITY, lk2 = -INFINITY;
-        const unsigned keep = ~31u;
-        auto elem = [&](auto ROW) __attribute__((always_inline)) {
-            constexpr int row = decltype(ROW)::value, i = row >> 4, r = row & 15;
-            float t, pn;
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(X[i][r]), "v"(m), "v"(P[i][r]));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(pn) : "v"(Pold[i][r]), "v"(m), "v"(X[i][r]));
-            asm volatile("v_mul_f32 %0, %0, %1" : "+v"(t) : "v"(q[(row >> 2) & 1][row & 3]));
-            asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(t) : "v"(keep), "n"(31 - row));
-            asm volatile("v_med3_f32 %0, %1, %0, %2" : "+v"(lk2) : "v"(lk1), "v"(t));
-            asm volatile("v_max_f32 %0, %0, %1" : "+v"(lk1) : "v"(t));
-            P[i][r] = pn;
-        };
-        load_frags(0, 0);
-        auto gap = [&](auto G) __attribute__((always_inline)) {       // the vector work behind MFMA number G of the phase
-            constexpr int g = decltype(G)::value;
-            if constexpr (g == 4) load_q(0);
-            if constexpr (g >= 8 && g < 40) {
-                if constexpr ((g & 3) == 0 && g < 36) load_q((g - 8) / 4 + 1);
-                elem(std::integral_constant<int, g - 8>{});
-            }
-        };
-        auto kstep = [&](auto S) __attribute__((always_inline)) {
-            constexpr int s = decltype(S)::value, c = s & 1;
-            if (s + 1 < NS) load_frags(s + 1, c ^ 1);
-            mfma(s, 0, c);
-            gap(std::integral_constant<int, 2 * s>{});
-            mfma(s, 1, c);
-            gap(std::integral_constant<int, 2 * s + 1>{});
-        };
-        static_for(kstep, std::make_integer_sequence<int, NS>{});
-        // 5-bit register tag -> 6-bit position tag (position R = 32 i + 8 (r >> 2) + 4 fk + (r & 3) = 2 row - (row & 3) + 4 fk)
-        auto retag = [&](float k) __attribute__((always_inline)) {
-            const unsigned u = __float_as_uint(k);
-            const int row = 31 - (int)(u & 31u);
-            const int R = 2 * row - (row & 3) + 4 * fk;
-            return k == -INFINITY ? k : __uint_as_float((u & ~63u) | (unsigned)(63 - R));
-        };
-        const float k1 = retag(lk1), k2 = retag(lk2);
-        const float o1 = __shfl_xor(k1, 32, 64), o2 = __shfl_xor(k2, 32, 64);
-        const float m1 = vmax(k1, o1), m2 = vmax(fminf(k1, o1), vmax(k2, o2));
-        const int qx = qx0 + 32 * jp + fr;
-        if (store && fk == 0 && qx < W) {
-            float2 o; o.x = m1; o.y = m2;
-            *reinterpret_cast<float2*>(p.part + 2 * ((pbase + aq) * W + qx)) = o;
-        }
-    };
-    // the same vector work without a matrix phase beside it (pipeline drain and the map's last row)
-    auto post = [&](int jp, int aq, const f32x16 (&X)[2], const f32x16 (&Pold)[2], f32x16 (&P)[2], float m, bool store)
-                    __attribute__((always_inline)) {
-        const float* pinv = inv_s + ((aq + wave) & (DINV - 1)) * DT + 4 * fk;
-        float lk1 = -INFINITY, lk2 = -INFINITY;
-#pragma unroll
-        for (int g4 = 0; g4 < 8; ++g4) {
-            const f32x4 q = *reinterpret_cast<const f32x4*>(pinv + (g4 >> 2) * 32 + (g4 & 3) * 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = 4 * g4 + e, i = row >> 4, r = row & 15;
-                const float x = X[i][r];
-                const float v = __builtin_fmaf(x, m, P[i][r]) * q[e];
-                P[i][r] = __builtin_fmaf(Pold[i][r], m, x);
-                const float key = __uint_as_float((__float_as_uint(v) & ~31u) | (unsigned)(31 - row));
-                lk2 = __builtin_amdgcn_fmed3f(lk1, lk2, key);
-                lk1 = vmax(lk1, key);
-            }
-        }
-        auto retag = [&](float k) __attribute__((always_inline)) {
-            const unsigned u = __float_as_uint(k);
-            const int row = 31 - (int)(u & 31u);
-            const int R = 2 * row - (row & 3) + 4 * fk;
-            return k == -INFINITY ? k : __uint_as_float((u & ~63u) | (unsigned)(63 - R));
-        };
-        const float k1 = retag(lk1), k2 = retag(lk2);
-        const float o1 = __shfl_xor(k1, 32, 64), o2 = __shfl_xor(k2, 32, 64);
-        const float m1 = vmax(k1, o1), m2 = vmax(fminf(k1, o1), vmax(k2, o2));
-        const int qx = qx0 + 32 * jp + fr;
-        if (store && fk == 0 && qx < W) {
-            float2 o; o.x = m1; o.y = m2;
-            *reinterpret_cast<float2*>(p.part + 2 * ((pbase + aq) * W + qx)) = o;
-        }
-    };
-
-    // wave-uniform flags of computed row a, branch-free (a branch between the MFMAs and the vector work would end the block they
-    // are interleaved in): cont = D of row a continues row a - 1's diagonal (reference row b(a) != 0); emits = row a - 1 is one of
-    // this workgroup's rows
-    auto cont = [&](int a, int b) { return ((a > a_start) & (b != 0)) ? 1.f : 0.f; };
-    auto emits = [&](int a) { return active & (a - 1 >= a0) & (a > a_start); };
-    int bcur = (a_start + delta) % H;                               // reference row of this wave's diagonal at the current row
-    int bprev = 1;                                                  // (unused at the first row: cont(a_start - 1) is 0 by its first factor)
-    int grow_next = ref_row(a_start + DM);                          // reference row the next step stages
-
-#ifdef SPEI_TUNING
-    long long tacc[6] = {0, 0, 0, 0, 0, 0};
-    long long tprev = __builtin_amdgcn_s_memrealtime();
-#define DSTAMP(k) do { const long long t_ = __builtin_amdgcn_s_memrealtime(); tacc[k] += t_ - tprev; tprev = t_; } while (0)
-#else
-#define DSTAMP(k) do { } while (0)
-#endif
-    auto step = [&](int a, f32x16 (&X0)[2], f32x16 (&X0old)[2], f32x16 (&X1)[2], f32x16 (&X1old)[2]) __attribute__((always_inline)) {
-        const int n = a - a_start;
-        const int cur = n & 1;
-        // stage the next step's rows in registers (rows clamped to the map on the last step: loaded, stored, never read)
-        const float mA = cont(a - 1, bprev), mB = cont(a, bcur);
-        const bool eA = emits(a - 1), eB = emits(a);
-        u32x4 st[DLOADS];
-        bool stz[DLOADS];
-        const int rho_new = a + DM;
-        const int grow = grow_next, qrow = min(a + 1, H - 1);
-#pragma unroll
-        for (int u = 0; u < DLOADS; ++u) {                          // every lane loads from a clamped address, then selects
-            const int idx = min(tid + u * 256, 2 * DPIECES - 1);
-            const bool q = idx < DPIECES;
-            const int rem = q ? idx : idx - DPIECES;
-            const int pix = rem >> 4, c16 = rem & 15;
-            const int gx = (q ? qx0 : kx0) - 1 + pix;
-            const int row = q ? qrow : grow;
-            const LP* src = q ? p.lr : p.ref;
-            const bool ok = (gx >= 0) & (gx < W);
-            // staged in the accumulation registers ("a"): the vector registers hold the six tiles; global_load and ds_write take either file
-            const LP* g = src + ((size_t)row * W + min(max(gx, 0), W - 1)) * C + c16 * 8;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(st[u]) : "v"(g));
-            stz[u] = ok;
-        }
-        float riv = p.inv_ref[(size_t)grow * W + min(kx0 + (tid & 63), W - 1)];
-        riv = kx0 + (tid & 63) < W ? riv : qnan;
-        bprev = bcur;
-        bcur = bcur + 1 == H ? 0 : bcur + 1;
-        grow_next = grow + 1 == H ? 0 : grow + 1;
-        const unsigned char* ga = gring + ((a + wave) % DRING) * DROWB;
-        const unsigned char* fb = fbuf + cur * DROWB;
-        DSTAMP(0);
-        // phase A: half 0 of row a on the matrix pipe; scores of row a - 2, half 1 (X = D tile of row a - 1) on the vector pipe
-        phase(std::integral_constant<int, 0>{}, ga, fb, X0, a - 2, X1old, X1, P1, mA, eA);
-        DSTAMP(1);
-        // phase B: half 1 of row a (over the registers of row a - 2's tile, dead since phase A); scores of row a - 1, half 0
-        phase(std::integral_constant<int, 1>{}, ga, fb, X1, a - 1, X0, X0old, P0, mB, eB);
-        asm volatile("s_nop 7\n\ts_nop 7");                          // the last MFMA's result may be read by compiler-scheduled code next
-        DSTAMP(2);
-        unsigned char* fdst = fbuf + (cur ^ 1) * DROWB;
-        unsigned char* gdst = gring + (rho_new % DRING) * DROWB;
-#pragma unroll
-        for (int u = 0; u < DLOADS; ++u) {                          // unconditional: the lanes past the last piece rewrite it (same bytes)
-            const int idx = min(tid + u * 256, 2 * DPIECES - 1);
-            const bool q = idx < DPIECES;
-            const int rem = q ? idx : idx - DPIECES;
-            unsigned char* d = (q ? fdst : gdst) + (rem >> 4) * DPITCH + (rem & 15) * 16;
-            const unsigned da = (unsigned)(uintptr_t)d;           // low half of a generic LDS address = the LDS address
-            if (u == 0) { asm volatile("s_waitcnt vmcnt(0)"); DSTAMP(3); }
-            if (stz[u]) asm volatile("ds_write_b128 %0, %1" :: "v"(da), "a"(st[u]) : "memory");
-            else *reinterpret_cast<u32x4*>(d) = zero4;
-        }
-        inv_s[(rho_new & (DINV - 1)) * DT + (tid & 63)] = riv;      // four waves, the same 64 values
-        DSTAMP(4);
-        __syncthreads();
-        DSTAMP(5);
-    };
-    // after the last step: half 1 of the last row, then the last row of the map (no successor: its scores are the pending sums)
-    auto tail = [&](f32x16 (&X1)[2], f32x16 (&X1old)[2]) __attribute__((always_inline)) {
-        post(1, a_end - 1, X1, X1old, P1, cont(a_end, bprev), emits(a_end));
-        if (a_end < a1) {
-            post(0, a_end, P0, P0, P0, 0.f, active);
-            post(1, a_end, P1, P1, P1, 0.f, active);
-        }
-    };
-    for (int a = a_start;;) {
-        step(a, S0a, S0b, S1a, S1b);
-        if (a == a_end) { tail(S1a, S1b); break; }
-        ++a;
-        step(a, S0b, S0a, S1b, S1a);
-        if (a == a_end) { tail(S1b, S1a); break; }
-        ++a;
-    }
-#ifdef SPEI_TUNING
-    if (p.stamps && lane == 0) {                                     // [workgroup][wave][8]: six sums + steps
-        long long* o = p.stamps + ((size_t)blockIdx.x * DM + wave) * 8;
-        for (int k = 0; k < 6; ++k) o[k] = tacc[k];
-        o[6] = a_end - a_start + 1;
-    }
-#endif
-#undef DSTAMP
 }
 
 // ---- version 3: eight waves, two per SIMD, out of phase ------------------------------------------------------------------------
@@ -685,6 +404,13 @@ __global__ __launch_bounds__(512) void corr_diag8_kernel(const CorrDiagParams<LP
     int bcur = (a_start + delta) % H, bprev = 1;
     int grow_next = ref_row(a_start + DM);
 
+#ifdef SPEI_TUNING
+    long long tacc[6] = {0, 0, 0, 0, 0, 0};
+    long long tprev = __builtin_amdgcn_s_memrealtime();
+#define DSTAMP(k) do { const long long t_ = __builtin_amdgcn_s_memrealtime(); tacc[k] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define DSTAMP(k) do { } while (0)
+#endif
     auto step = [&](int a, f32x16 (&X)[2], f32x16 (&Xold)[2]) __attribute__((always_inline)) {
         const int n = a - a_start;
         const int cur = n & 1;
@@ -701,9 +427,13 @@ __global__ __launch_bounds__(512) void corr_diag8_kernel(const CorrDiagParams<LP
         const unsigned char* ga = gring + ((a + wd) % DRING) * DROWB;
         const unsigned char* fb = fbuf + cur * DROWB;
         // the lagging half: scores of row a - 2 first (X = D tile of row a - 1 = Xold, its predecessor = the registers X still holds)
+        DSTAMP(0);
         if (lag) post(a - 2, Xold, X, mprev, emits(a - 1));
+        DSTAMP(1);
         mfma_tile(ga, fb, X);
+        DSTAMP(2);
         if (!lag) post(a - 1, X, Xold, mcur, emits(a));
+        DSTAMP(3);
         unsigned char* fdst = fbuf + (cur ^ 1) * DROWB;
         unsigned char* gdst = gring + (rho_new % DRING) * DROWB;
 #pragma unroll
@@ -713,7 +443,9 @@ __global__ __launch_bounds__(512) void corr_diag8_kernel(const CorrDiagParams<LP
         bprev = bcur;
         bcur = bcur + 1 == H ? 0 : bcur + 1;
         grow_next = grow + 1 == H ? 0 : grow + 1;
+        DSTAMP(4);
         __syncthreads();
+        DSTAMP(5);
     };
     auto tail = [&](f32x16 (&X)[2], f32x16 (&Xold)[2]) __attribute__((always_inline)) {
         if (lag) post(a_end - 1, X, Xold, cont(a_end, bprev), emits(a_end));
@@ -727,6 +459,14 @@ __global__ __launch_bounds__(512) void corr_diag8_kernel(const CorrDiagParams<LP
         if (a == a_end) { tail(Xb, Xa); break; }
         ++a;
     }
+#ifdef SPEI_TUNING
+    if (p.stamps && lane == 0) {                                     // [workgroup][wave][8]: six section sums + the step count
+        long long* o = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+        for (int k = 0; k < 6; ++k) o[k] = tacc[k];
+        o[6] = a_end - a_start + 1;
+    }
+#endif
+#undef DSTAMP
 }
 
 __device__ __forceinline__ bool dbetter(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
@@ -812,16 +552,13 @@ int corr_diag_run(const void* lr16, const void* ref16, const float* inv_ref, int
     p.stamps = spei_stamp_buffer();
     float* pval = ws + (size_t)2 * H * p.xtiles * Nl;
     int32_t* pidx = reinterpret_cast<int32_t*>(pval + (size_t)2 * DRSPLIT * Nl);
-    static const int ver = spei_knob("SPEI_CORR_DIAG_V", 3);        // tuning build: 1 = the unpipelined kernel, 2 = one wave per SIMD
+    static const int ver = spei_knob("SPEI_CORR_DIAG_V", 3);        // tuning build: 1 = four waves, vector work after the MFMAs
     if (ver == 3) {
         ensure_dyn_lds<&corr_diag8_kernel<LP>>(DIAG_LDS);
         hipLaunchKernelGGL((corr_diag8_kernel<LP>), dim3((unsigned)(cols * nseg)), dim3(512), DIAG_LDS, st, p);
-    } else if (ver == 1) {
+    } else {
         ensure_dyn_lds<&corr_diag_kernel<LP>>(DIAG_LDS);
         hipLaunchKernelGGL((corr_diag_kernel<LP>), dim3((unsigned)(cols * nseg)), dim3(64 * DM), DIAG_LDS, st, p);
-    } else {
-        ensure_dyn_lds<&corr_diag2_kernel<LP>>(DIAG_LDS);
-        hipLaunchKernelGGL((corr_diag2_kernel<LP>), dim3((unsigned)(cols * nseg)), dim3(64 * DM), DIAG_LDS, st, p);
     }
     hipLaunchKernelGGL(corr_diag_reduce_kernel, dim3(cdiv(Nl, 256), DRSPLIT), dim3(256), 0, st, p.part, H, W, p.xtiles, pval, pidx);
     hipLaunchKernelGGL(corr_diag_final_kernel, dim3(cdiv(Nl, 256)), dim3(256), 0, st, pval, pidx, Nl, S, arg, S2, arg2);
