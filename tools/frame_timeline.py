@@ -6,12 +6,13 @@ active, the longest single-stream stretches and what runs in them.
 """
 import csv
 import glob
+import re
 import sys
 
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-corr = [i for i, r in enumerate(rows) if "corr_slab_kernel" in r["Kernel_Name"]]
+corr = [i for i, r in enumerate(rows) if re.search(r"corr_(slab|diag8?)_kernel", r["Kernel_Name"])]
 a, b = corr[-4], corr[-3]                       # one full frame between two correlation launches, late in the run
 seg = rows[a:b]
 t0, t1 = int(seg[0]["Start_Timestamp"]), int(rows[b]["Start_Timestamp"])
@@ -41,7 +42,7 @@ for r in seg:
 print("kernel time per stream: " + ", ".join(f"{k}: {v / 1e6:.2f} ms" for k, v in per.items()))
 # coarse phases: 1 ms buckets, kernels per bucket by family
 def fam(n):
-    for k in ("corr_slab", "corr_rescore", "attn_fused", "mlp_fused", "conv_slab", "conv5", "gate_", "resblock_apply", "layernorm", "bicubic", "gather_fold", "rl_", "patch_invnorm"):
+    for k in ("corr_slab", "corr_diag", "corr_rescore", "attn_fused", "mlp_fused", "conv_slab", "conv5", "gate_", "resblock_apply", "layernorm", "bicubic", "gather_fold", "rl_", "patch_invnorm"):
         if k in n:
             return k
     return "other"

@@ -8,17 +8,18 @@ MI355X_MICROARCH.md prescribes) -> profiles/<name>.json.
 import csv
 import glob
 import json
+import re
 import sys
 
 
-def counter(d, name, kernel_substr):
+def counter(d, name, kernel_re):
     f = (glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True))[0]
     vals, kname = [], None
     for r in csv.DictReader(open(f)):
-        if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == name:
+        if re.search(kernel_re, r["Kernel_Name"]) and r["Counter_Name"] == name:
             vals.append(float(r["Counter_Value"]))
             kname = r["Kernel_Name"]
-    assert vals, f"no {name} rows for {kernel_substr} in {f}"
+    assert vals, f"no {name} rows for {kernel_re} in {f}"
     return sum(vals) / len(vals), len(vals), kname
 
 
@@ -27,8 +28,9 @@ def total(d, name):
     return sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == name)
 
 
-fetch_kb, n, kname = counter(sys.argv[1], "FETCH_SIZE", "corr_slab_kernel")
-write_kb, _, _ = counter(sys.argv[2], "WRITE_SIZE", "corr_slab_kernel")
+CORR = r"corr_(slab|diag8?)_kernel"        # the candidate kernel itself, not the diagonal form's reduce / final kernels
+fetch_kb, n, kname = counter(sys.argv[1], "FETCH_SIZE", CORR)
+write_kb, _, _ = counter(sys.argv[2], "WRITE_SIZE", CORR)
 # gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE counts 32-byte units of 64-byte requests
 # as one: wide coalesced reads report half their bytes -> double it; WRITE_SIZE is taken as reported.  Units are KiB.
 hbm = (2.0 * fetch_kb + write_kb) * 1024.0
@@ -36,7 +38,8 @@ KEY = sys.argv[5] if len(sys.argv) > 5 else "f16/top2"
 out = {"commit": sys.argv[6] if len(sys.argv) > 6 else "n/a", KEY: {"kernel": kname.replace("(anonymous namespace)::", "")[:80], "launches_averaged": n,
                      "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb, "hbm_bytes_per_launch": hbm,
                      "note": sys.argv[4] + "; FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md "
-                             "HBM section); algorithmic compulsory bytes = 2 maps x 14.7 MB (16-bit) + 0.9 MB outputs"}}
+                             "HBM section); algorithmic compulsory bytes = 2 maps x 14.7 MB (16-bit) + 0.9 MB outputs; the diagonal kernel also writes one "
+                             "key pair per (query, diagonal, reference tile): 415 MB at 720p, read back once by its reduce kernel"}}
 # whole frame: every dispatch of the run (n frames = n launches of the correlation kernel; the one-off weight packing of
 # the first call is included, < 1 %), same corrections
 out[KEY]["path_hbm_bytes_per_frame"] = (2.0 * total(sys.argv[1], "FETCH_SIZE") + total(sys.argv[2], "WRITE_SIZE")) * 1024.0 / n
