@@ -48,6 +48,7 @@ struct CorrDiagParams {
     const float* inv_ref;
     float* part;                           // [H (delta)][xtiles][H * W] key pairs
     int H, W, xtiles, ngroups, seg_len;
+    int nwg, xcd;                          // workgroups that have work; xcd: consecutive logical workgroups share an XCD (and its L2)
     long long* stamps;                     // tuning build: per-workgroup phase-time sums (tools/stamp_corr_diag.py)
 };
 
@@ -286,7 +287,11 @@ __global__ __launch_bounds__(512) void corr_diag8_kernel(const CorrDiagParams<LP
     const int wd = wave & 3, jq = wave >> 2;                         // diagonal inside the group, query half
     const bool lag = jq != 0;                                        // vector work of a row one step late, ahead of the MFMAs
     const int fr = lane & 31, fk = lane >> 5;
-    int bid = blockIdx.x;
+    // Workgroup b runs on XCD b % 8.  The 32 workgroups an XCD holds at a time should be NEIGHBOURING diagonal groups of one tile
+    // pair: they read the same query row and, four steps apart, the same reference rows — one fetch per XCD instead of one per
+    // workgroup (the grid is padded to a multiple of 8; logical ids past the last workgroup exit).
+    int bid = p.xcd ? (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    if (bid >= p.nwg) return;
     const int group = bid % p.ngroups; bid /= p.ngroups;
     const int kxt = bid % p.xtiles; bid /= p.xtiles;
     const int qxt = bid % p.xtiles;
@@ -426,6 +431,14 @@ __global__ __launch_bounds__(512) void corr_diag8_kernel(const CorrDiagParams<LP
         riv = kx0 + lane < W ? riv : qnan;
         const unsigned char* ga = gring + ((a + wd) % DRING) * DROWB;
         const unsigned char* fb = fbuf + cur * DROWB;
+        auto stores = [&]() __attribute__((always_inline)) {
+            unsigned char* fdst = fbuf + (cur ^ 1) * DROWB;
+            unsigned char* gdst = gring + (rho_new % DRING) * DROWB;
+#pragma unroll
+            for (int u = 0; u < NLD; ++u)
+                *reinterpret_cast<u32x4*>((sq[u] ? fdst : gdst) + sdst[u]) = sok[u] ? st[u] : zero4;
+            if (wave == 0) inv_s[(rho_new & (DINV - 1)) * DT + lane] = riv;
+        };
         // the lagging half: scores of row a - 2 first (X = D tile of row a - 1 = Xold, its predecessor = the registers X still holds)
         DSTAMP(0);
         if (lag) post(a - 2, Xold, X, mprev, emits(a - 1));
@@ -434,12 +447,7 @@ __global__ __launch_bounds__(512) void corr_diag8_kernel(const CorrDiagParams<LP
         DSTAMP(2);
         if (!lag) post(a - 1, X, Xold, mcur, emits(a));
         DSTAMP(3);
-        unsigned char* fdst = fbuf + (cur ^ 1) * DROWB;
-        unsigned char* gdst = gring + (rho_new % DRING) * DROWB;
-#pragma unroll
-        for (int u = 0; u < NLD; ++u)
-            *reinterpret_cast<u32x4*>((sq[u] ? fdst : gdst) + sdst[u]) = sok[u] ? st[u] : zero4;
-        if (wave == 0) inv_s[(rho_new & (DINV - 1)) * DT + lane] = riv;
+        stores();
         bprev = bcur;
         bcur = bcur + 1 == H ? 0 : bcur + 1;
         grow_next = grow + 1 == H ? 0 : grow + 1;
@@ -553,9 +561,11 @@ int corr_diag_run(const void* lr16, const void* ref16, const float* inv_ref, int
     float* pval = ws + (size_t)2 * H * p.xtiles * Nl;
     int32_t* pidx = reinterpret_cast<int32_t*>(pval + (size_t)2 * DRSPLIT * Nl);
     static const int ver = spei_knob("SPEI_CORR_DIAG_V", 3);        // tuning build: 1 = four waves, vector work after the MFMAs
+    p.nwg = (int)(cols * nseg);
+    p.xcd = spei_knob("SPEI_CORR_DIAG_XCD", 1);
     if (ver == 3) {
         ensure_dyn_lds<&corr_diag8_kernel<LP>>(DIAG_LDS);
-        hipLaunchKernelGGL((corr_diag8_kernel<LP>), dim3((unsigned)(cols * nseg)), dim3(512), DIAG_LDS, st, p);
+        hipLaunchKernelGGL((corr_diag8_kernel<LP>), dim3((unsigned)(p.xcd ? cdiv(p.nwg, 8) * 8 : p.nwg)), dim3(512), DIAG_LDS, st, p);
     } else {
         ensure_dyn_lds<&corr_diag_kernel<LP>>(DIAG_LDS);
         hipLaunchKernelGGL((corr_diag_kernel<LP>), dim3((unsigned)(cols * nseg)), dim3(64 * DM), DIAG_LDS, st, p);
