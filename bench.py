@@ -245,7 +245,7 @@ def train_measure(argv=None):
         line = {"metric": f"training crops/s, {a.model} model, fwd + loss + bwd + Adam", "value": world * a.batch * 1e3 / ms,
                 "unit": "crops/s", "n_gpus": world, "batch_per_gpu": a.batch, "patch": a.patch, "n_sequence": 3, "ms_per_step": ms,
                 "ms": {"forward": float(split[0]), "loss_backward": float(split[1]), "adam": float(split[2])},
-                "loss": float(loss.item()), "dtype": "f32" if a.precision == "f32" else "bf16x3 forward / data-gradient GEMMs, f32 weight gradients",
+                "loss": float(loss.item()), "dtype": "f32" if a.precision == "f32" else "bf16x3 (split products on the 16-bit matrix pipe, f32-grade): forward, data-gradient and weight-gradient GEMMs; everything else fp32",
                 "data": "synthetic", "scaling": "weak", "cpu_baseline": cpu}
     if dist is not None:
         dist.destroy_process_group()
