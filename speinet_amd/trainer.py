@@ -17,13 +17,21 @@ import torch
 
 
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20) -> int:
-    """Average `.grad` of every parameter over the ranks of `group`, in buckets of about `bucket_bytes`.  Parameters without a
-    gradient on this rank contribute zeros (every rank must issue the same collectives).  Returns the number of all-reduces."""
+    """Average `.grad` of every parameter over the ranks of `group`, in buckets of about `bucket_bytes`.  A parameter without a
+    gradient on this rank contributes zeros (every rank must issue the same collectives); a parameter without a gradient on ANY
+    rank keeps `.grad = None` — the reference's single-process step leaves it None and Adam skips it (no weight decay, no stale
+    momentum: SearchTransfer.search1/2 are never used in forward, the SelfTransfer convs only on steps with a reference-less
+    sample).  One extra all-reduce (MAX) of a has-gradient byte per parameter decides that.  Returns the number of all-reduces."""
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return 0
     world = dist.get_world_size(group)
     plist = [p for p in params if p.requires_grad]
+    if not plist:
+        return 0
+    has = torch.tensor([0 if p.grad is None else 1 for p in plist], dtype=torch.int32, device=plist[0].device)
+    dist.all_reduce(has, op=dist.ReduceOp.MAX, group=group)
+    any_grad = dict(zip((id(p) for p in plist), has.tolist()))
     buckets: List[List[torch.nn.Parameter]] = [[]]
     size = 0
     for p in plist:
@@ -43,13 +51,28 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket
         off = 0
         for p in b:
             g = flat[off:off + p.numel()].view_as(p)
-            if p.grad is None:
+            if not any_grad[id(p)]:
+                pass                                          # no rank produced a gradient: stays None
+            elif p.grad is None:
                 p.grad = g.clone()
             else:
                 p.grad.copy_(g)
             off += p.numel()
         n += 1
-    return n
+    return n + 1
+
+
+def seed_rank(seed: int, group=None) -> int:
+    """Seed the generators the training step draws from — torch's CPU generator (DropPath factors, train.drop_path_scales) and numpy's
+    global generator (the HEM random mask, as in the reference's Loss/hard_example_mining.py) — with `seed + rank`, so that the ranks
+    draw DIFFERENT masks for their shares of the batch, as the samples of one nn.DataParallel batch do in the reference.  Returns the
+    seed used."""
+    import numpy as np
+    import torch.distributed as dist
+    rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+    torch.manual_seed(seed + rank)
+    np.random.seed((seed + rank) % (1 << 32))
+    return seed + rank
 
 
 def broadcast_buffers(module: torch.nn.Module, src: int = 0, group=None) -> None:
