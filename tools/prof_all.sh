@@ -26,4 +26,5 @@ python3 tools/pmc_traffic.py $T/pmc_fetch $T/pmc_write $O/r03_traffic.json "rocp
 python3 tools/pmc_summary.py --top=30 $T/pmc_sq > $O/r03_pmc_sq_kernels.body.md
 python3 tools/pmc_summary.py --top=30 $T/pmc_fetch $T/pmc_write > $O/r03_pmc_hbm_kernels.body.md
 python3 tools/frame_timeline.py $T/excl_trace > $O/r03_frame_timeline.txt 2>&1 || true
+python3 tools/frame_timeline.py $T/bench_trace > $O/r03_frame_timeline_default.txt 2>&1 || true
 ls -la $O

@@ -1,3 +1,5 @@
+# Round-end evidence in one GPU call: `gpurun -- bash tools/round_end.sh <commit>`: the default bench line, tools/prof_all.sh (kernel traces, PMC passes,
+# training trace, timeline) and the parity ablation; outputs under gpurun_out/ (copy gpurun_out/r03/* and the bench line into profiles/).
 set -e
 REV=${1:-final}
 mkdir -p gpurun_out/r03
