@@ -242,14 +242,15 @@ int spei_corr_slab16(int fmt, const void* lr_hi, const void* lr_lo, const void* 
 int spei_corr_slab_top2_16(int fmt, const void* lr16, const void* ref16, const float* inv_lr, const float* inv_ref,
                            int Hl, int Wl, int Hr, int Wr, int C, float* S, int32_t* arg, float* S2, int32_t* arg2,
                            float* ws, spei_stream_t stream);
-/* Diagonal-sliding form of the candidate pass for maps of ONE size (H x W both; csrc/corr_diag16.hip): the score of
- * (y, x) against (y', x') is the sum of three row-against-row terms shared along the diagonal y' - y, so each term is
- * computed once — a third of the flops of model/SearchTransfer.py:33's bmm reach the matrix pipe, every score is still
- * the full 9 C-term fp32 sum.  Same outputs as spei_corr_slab_top2_16 (feed spei_corr_rescore);  workspace floats:
- * spei_corr_diag_ws_floats(H, W). */
-int64_t spei_corr_diag_ws_floats(int H, int W);
-int spei_corr_diag_top2_16(int fmt, const void* lr16, const void* ref16, const float* inv_ref, int H, int W, int C,
-                           float* S, int32_t* arg, float* S2, int32_t* arg2, float* ws, spei_stream_t stream);
+/* Diagonal-sliding form of the candidate pass (csrc/corr_diag16.hip) for a reference map at least as high as the query
+ * map (Hr >= Hl: SearchTransfer's maps of one size, SelfTransfer's rotated landscape map): the score of (y, x) against
+ * (y', x') is the sum of three row-against-row terms shared along the diagonal y' - y, so each term is computed once — a
+ * third of the flops of model/SearchTransfer.py:33's bmm reach the matrix pipe, every score is still the full 9 C-term
+ * fp32 sum.  Same outputs as spei_corr_slab_top2_16 (feed spei_corr_rescore); workspace floats:
+ * spei_corr_diag_ws_floats(Hl, Wl, Hr, Wr). */
+int64_t spei_corr_diag_ws_floats(int Hl, int Wl, int Hr, int Wr);
+int spei_corr_diag_top2_16(int fmt, const void* lr16, const void* ref16, const float* inv_ref, int Hl, int Wl, int Hr, int Wr,
+                           int C, float* S, int32_t* arg, float* S2, int32_t* arg2, float* ws, spei_stream_t stream);
 int spei_corr_rescore(const float* lr, int ldl, const float* ref, int ldr, const float* inv_lr, const float* inv_ref,
                       int Hl, int Wl, int Hr, int Wr, int C, float* S, int32_t* arg, const float* S2, const int32_t* arg2,
                       spei_stream_t stream);

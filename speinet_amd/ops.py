@@ -182,8 +182,8 @@ class Ctx:
       corr_bf16       "f16" with corr "top2": the candidate pass of the correlation runs on bf16 operands (True, default) instead of
                       f16.  The fp32 re-score decides the winner and S either way (G14: 16 more of 57600 positions differ, dPSNR
                       +1e-6 dB); bf16 operands let the chip hold a ~7 % higher MFMA clock on this kernel (tools/bench_corr.py)
-      corr_diag       corr "top2", query and reference map of one size (every call the model makes): the candidate pass is the
-                      diagonal-sliding kernel (corr_diag16.hip): each row-against-row term of the 3x3-patch score is computed once and
+      corr_diag       corr "top2", reference map at least as high as the query map (SearchTransfer's maps of one size, SelfTransfer's
+                      rotated landscape map): the candidate pass is the diagonal-sliding kernel (corr_diag16.hip): each row-against-row term of the 3x3-patch score is computed once and
                       shared by the three patch rows that use it — a third of the bmm's flops, same fp32 sums.  Off: the slab kernel
     stage        {stage name: {field: value}} overrides applied by `for_stage` (engine: "enc", "swin", "search", "decode", and inside
                  "decode" the stacks "dec2" (decoder_second), "dec1" (decoder_first), "out" (outBlock) and its final conv "tail")
@@ -604,11 +604,11 @@ class Ctx:
         if rescore:
             arg2 = torch.empty(n, device=dev, dtype=torch.int32)
             s2 = torch.empty(n, device=dev)
-            diag = self.corr_diag and (lr.H, lr.W) == (ref.H, ref.W)
+            diag = self.corr_diag and ref.H >= lr.H
             if diag:
-                ws = torch.empty(lib.spei_corr_diag_ws_floats(lr.H, lr.W), device=dev)
+                ws = torch.empty(lib.spei_corr_diag_ws_floats(lr.H, lr.W, ref.H, ref.W), device=dev)
                 main = (lib.spei_corr_diag_top2_16, "spei_corr_diag_top2_16",
-                        (f16, tp(parts[0]), tp(parts[2]), tp(inv_ref), lr.H, lr.W, lr.C, tp(s), tp(arg), tp(s2), tp(arg2), tp(ws)))
+                        (f16, tp(parts[0]), tp(parts[2]), tp(inv_ref), *dims, tp(s), tp(arg), tp(s2), tp(arg2), tp(ws)))
             else:
                 main = (lib.spei_corr_slab_top2_16, "spei_corr_slab_top2_16",
                         (f16, tp(parts[0]), tp(parts[2]), tp(inv_lr), tp(inv_ref), *dims, tp(s), tp(arg), tp(s2), tp(arg2), tp(ws)))

@@ -1,7 +1,8 @@
 """The diagonal-sliding candidate kernel of the correlation (csrc/corr_diag16.hip) against the float64 oracle of
 model/SearchTransfer.py:26-34 (normalised 3x3 unfold, bmm, max over the reference positions) and against the slab kernel it
 replaces: ragged maps (partial tiles, heights that are not a multiple of the 4 diagonals of a workgroup, maps smaller than one
-tile, single rows), exact ties, walks cut into segments."""
+tile, single rows), reference maps of another size than the query map (higher: the diagonals are cyclic in the reference height;
+SelfTransfer's rotated map), exact ties, walks cut into segments."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -89,3 +90,39 @@ def test_corr_diag_candidates_contain_argmax_720p_rows():
     s0, arg0 = ops.replace(corr_diag=False).corr_argmax(fm(lr3), fm(rf3), inv_l, inv_r)
     assert (arg != arg0).sum().item() <= 2
     assert (s - s0).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("hl,wl,hr,wr", [(29, 51, 37, 45), (20, 70, 70, 20), (45, 80, 80, 45), (1, 5, 9, 3), (12, 130, 13, 66), (37, 45, 37, 70)])
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_corr_diag_other_reference_size(hl, wl, hr, wr, mode):
+    """Reference map of another size, at least as high as the query map (hr >= hl) — incl. the transposed shapes SelfTransfer
+    produces for landscape frames (model/SearchTransfer.py:60)."""
+    lr3, rf3 = rnd(300 + hl, 1, 128, hl, wl), rnd(400 + wr, 1, 128, hr, wr)
+    r, top = oracle_top2(lr3, rf3)
+    ops = Ctx(mode, "top2", device=DEV)
+    inv_l, inv_r = ops.patch_invnorm(fm(lr3)), ops.patch_invnorm(fm(rf3))
+    plan = ops.corr_plan(fm(lr3), fm(rf3), inv_l, inv_r)
+    assert plan.kernel.startswith("corr_diag_kernel")
+    plan.launch()
+    diff = plan.arg.cpu().long() != top.indices[0]
+    margin = (top.values[0] - top.values[1])[diff]
+    assert diff.sum().item() <= 2 and (margin < 1e-6).all(), (mode, diff.sum().item(), margin)
+    assert (plan.s.cpu().double() - top.values[0]).abs().max().item() < 1e-6
+
+
+def test_corr_diag_lower_reference_map_takes_the_slab_kernel():
+    """hr < hl: the cyclic walk would leave the reference map; ops falls back to the slab kernel and the C entry refuses."""
+    from speinet_amd import _lib
+    lr3, rf3 = rnd(61, 1, 128, 37, 45), rnd(62, 1, 128, 29, 51)
+    ops = Ctx("f16", "top2", device=DEV)
+    inv_l, inv_r = ops.patch_invnorm(fm(lr3)), ops.patch_invnorm(fm(rf3))
+    plan = ops.corr_plan(fm(lr3), fm(rf3), inv_l, inv_r)
+    assert plan.kernel.startswith("corr_slab_kernel")
+    n = 37 * 45
+    z = torch.zeros(n, device=DEV)
+    zi = torch.zeros(n, device=DEV, dtype=torch.int32)
+    h16 = torch.zeros(n, 128, device=DEV, dtype=torch.float16)
+    ws = torch.zeros(int(_lib.lib().spei_corr_diag_ws_floats(37, 45, 29, 51)), device=DEV)
+    tp = ops._tp
+    rc = _lib.lib().spei_corr_diag_top2_16(2, tp(h16), tp(h16), tp(inv_r), 37, 45, 29, 51, 128, tp(z), tp(zi), tp(z), tp(zi), tp(ws), ops._stream())
+    assert rc != 0 and b"Hr" in _lib.lib().spei_last_error()

@@ -12,7 +12,7 @@ import sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-corr = [i for i, r in enumerate(rows) if re.search(r"corr_(slab|diag8?)_kernel", r["Kernel_Name"])]
+corr = [i for i, r in enumerate(rows) if re.search(r"corr_(slab|diag)_kernel", r["Kernel_Name"])]
 a, b = corr[-4], corr[-3]                       # one full frame between two correlation launches, late in the run
 seg = rows[a:b]
 t0, t1 = int(seg[0]["Start_Timestamp"]), int(rows[b]["Start_Timestamp"])

@@ -38,7 +38,7 @@ def main():
     f = glob.glob(trace + "/**/*kernel_trace.csv", recursive=True)[0]
     for r in csv.DictReader(open(f)):
         dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    frames = float(sum(len(v) for k, v in dur.items() if k.startswith(("corr_slab_kernel", "corr_argmax_kernel", "corr_diag8_kernel", "corr_diag_kernel<"))) or 1)
+    frames = float(sum(len(v) for k, v in dur.items() if k.startswith(("corr_slab_kernel", "corr_argmax_kernel", "corr_diag_kernel<"))) or 1)
     fe, wr, sq = pmc(dfetch), pmc(dwrite), pmc(dsq)
     rows = sorted(dur.items(), key=lambda kv: -sum(kv[1]))[:top]
     tot = sum(sum(v) for v in dur.values())

@@ -28,7 +28,7 @@ def total(d, name):
     return sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == name)
 
 
-CORR = r"corr_(slab|diag8?)_kernel"        # the candidate kernel itself, not the diagonal form's reduce / final kernels
+CORR = r"corr_(slab|diag)_kernel"        # the candidate kernel itself, not the diagonal form's reduce / final kernels
 fetch_kb, n, kname = counter(sys.argv[1], "FETCH_SIZE", CORR)
 write_kb, _, _ = counter(sys.argv[2], "WRITE_SIZE", CORR)
 # gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE counts 32-byte units of 64-byte requests
