@@ -289,6 +289,12 @@ int spei_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float
 int spei_conv_wgrad_f32_batched(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* ws, int Hin, int Win,
                                 int Hout, int Wout, int N, int K, int ksize, int stride, int pad, int batch, spei_stream_t stream);
 
+/* Training: a weight in the reference's layout (Conv2d [N][K][ks][ks] / Linear [N][K], fp32) -> the split pair
+ * hi = bf16(w), lo = bf16(w - hi) in the slab kernels' fragment order, one launch.  mode 0: the forward GEMM weight
+ * [tap][N][K]; mode 1: the stride-1 data-gradient weight (taps reversed, channel axes swapped: [tap][K][N]).  The
+ * weights of a training step change every optimizer step (trainer/trainer_swint.py:39-44). */
+int spei_pack_split16(const float* w, int N, int K, int ksize, int mode, void* frag_hi, void* frag_lo, spei_stream_t stream);
+
 /* The same weight / bias gradient with the products split on the 16-bit matrix pipe (a = ah + al in bf16: al*bh + ah*bl + ah*bh,
  * fp32 accumulation: 2^-16 relative per product; speinet_amd/train.py `train_precision = "bf16x3"`): three v_mfma_f32_32x32x16_bf16 per
  * 16 pixels where the fp32 kernel issues eight v_mfma_f32_32x32x2_f32.  Arguments, workspace and summation order as

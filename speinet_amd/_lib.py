@@ -43,6 +43,7 @@ SIGNATURES = {
     "spei_split16": (I, [I, P, I, P, P, L, I, P]),
     "spei_corr_slab16": (I, [I, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P]),
     "spei_corr_slab_top2_16": (I, [I, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P]),
+    "spei_pack_split16": (I, [P, I, I, I, I, P, P, P]),
     "spei_corr_diag_ws_floats": (L, [I, I, I, I]),
     "spei_corr_diag_top2_16": (I, [I, P, P, P, I, I, I, I, I, P, P, P, P, P, P]),
     "spei_corr_rescore": (I, [P, I, P, I, P, P, I, I, I, I, I, P, P, P, P, P]),

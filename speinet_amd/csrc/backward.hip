@@ -701,3 +701,52 @@ extern "C" int spei_resblock_apply_bwd(const float* dout, const float* x1, const
     SPEI_CHECK_LAUNCH("spei_resblock_apply_bwd");
     return 0;
 }
+
+// ---- training: a weight in the reference's layout -> the split (hi, lo) bf16 pair in MFMA fragment order, ONE launch -----------------
+// The weights change every optimizer step, so every step re-packs each of the ~260 GEMM weights twice (forward, data gradient).  As
+// torch ops that is permute + contiguous, two bf16 casts, a subtraction and two fragment-order copies per weight and use: ~3 700
+// launches per step.  Here one thread writes one 16-byte fragment piece of hi and of lo.
+//   mode 0 (forward):        GEMM weight [t][n][k] = w[n][k][t]                 (Conv2d [N][K][ks][ks] / Linear [N][K], ks = 1)
+//   mode 1 (data gradient):  GEMM weight [t][n'][k'] = w[k'][n'][T - 1 - t]     (n' over the layer's INPUT channels K, k' over its
+//                            outputs N: the stride-1 data gradient is the convolution with the taps reversed and the channel axes swapped)
+// Fragment order (pack._frag): [n-tile][tap][k-step of 16][lane = h * 32 + n % 32][8], k = 16 ks + 8 h + j.
+namespace {
+__global__ __launch_bounds__(256) void pack_split16_kernel(const float* __restrict__ w, int N, int K, int T, int mode,
+                                                           __bf16* __restrict__ fhi, __bf16* __restrict__ flo) {
+    const int NN = mode ? K : N, KK = mode ? N : K;                 // rows / contraction length of the GEMM weight
+    const int64_t pieces = (int64_t)T * NN * KK / 8;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= pieces) return;
+    const int lane = (int)(i & 63);
+    int64_t r = i >> 6;
+    const int ksteps = KK / 16;
+    const int ks = (int)(r % ksteps); r /= ksteps;
+    const int t = (int)(r % T);
+    const int nt = (int)(r / T);
+    const int n = nt * 32 + (lane & 31), k0 = 16 * ks + 8 * (lane >> 5);
+    typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+    bf8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        const float v = mode ? w[((size_t)k * K + n) * T + (T - 1 - t)] : w[((size_t)n * K + k) * T + t];
+        const __bf16 h = (__bf16)v;
+        hi[j] = h;
+        lo[j] = (__bf16)(v - (float)h);
+    }
+    *reinterpret_cast<bf8*>(fhi + i * 8) = hi;
+    *reinterpret_cast<bf8*>(flo + i * 8) = lo;
+}
+}  // namespace
+
+extern "C" int spei_pack_split16(const float* w, int N, int K, int ksize, int mode, void* frag_hi, void* frag_lo, spei_stream_t stream) {
+    SPEI_REQUIRE(w && frag_hi && frag_lo, "spei_pack_split16: null pointer");
+    SPEI_REQUIRE(N > 0 && K > 0 && N % 32 == 0 && K % 32 == 0 && ksize >= 1 && (mode == 0 || mode == 1), "spei_pack_split16: N=%d K=%d ksize=%d mode=%d", N, K, ksize, mode);
+    SPEI_REQUIRE(((uintptr_t)frag_hi | (uintptr_t)frag_lo) % 16 == 0, "spei_pack_split16: 16-byte alignment required");
+    const int T = ksize * ksize;
+    const int64_t pieces = (int64_t)T * N * K / 8;
+    hipLaunchKernelGGL(pack_split16_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, N, K, T, mode,
+                       (__bf16*)frag_hi, (__bf16*)frag_lo);
+    SPEI_CHECK_LAUNCH("spei_pack_split16");
+    return 0;
+}

@@ -61,30 +61,33 @@ import contextvars
 _PREC = contextvars.ContextVar("speinet_train_precision", default="f32")
 
 
-def _split_frags(w_tnk: torch.Tensor, owner=None):
-    """[tap][N][K] fp32 -> (hi, lo) bf16 in MFMA fragment order (pack._frag).  `owner` = (parameter tensor, tag): the packed pair is
-    kept ON that tensor object together with the `_version` it was made from — the same weight is packed once per optimizer step
-    however many encoder passes use it, and nothing can outlive or be mistaken for another parameter (an address-keyed table can:
-    a freed parameter's address is handed to the next model's)."""
-    from .pack import _frag
-    cache = tag = None
-    if owner is not None:
-        weight, tag = owner
-        cache = getattr(weight, "_spei_split", None)
-        if cache is not None:
-            hit = cache.get(tag)
-            if hit is not None and hit[0] == weight._version:
-                return hit[1]
-    hi = w_tnk.to(torch.bfloat16)
-    lo = (w_tnk - hi.float()).to(torch.bfloat16)
-    out = (_frag(hi), _frag(lo))
-    if owner is not None:
-        try:
-            if cache is None:
-                cache = weight._spei_split = {}
-            cache[tag] = (weight._version, out)
-        except AttributeError:
-            pass
+def _split_frags(ctx: "Ctx", owner):
+    """(hi, lo) bf16 halves of a GEMM weight in MFMA fragment order, straight from the parameter in the reference's layout (ONE launch,
+    spei_pack_split16).  `owner` = (parameter tensor, tag): tag "fwd" = the forward weight [tap][N][K], "dgrad" = the stride-1
+    data-gradient weight (taps reversed, channel axes swapped).  The pair is kept ON the parameter object together with the `_version`
+    it was made from — the same weight is packed once per optimizer step however many encoder passes use it, and nothing can outlive
+    or be mistaken for another parameter (an address-keyed table can: a freed parameter's address is handed to the next model's)."""
+    weight, tag = owner
+    cache = getattr(weight, "_spei_split", None)
+    if cache is not None:
+        hit = cache.get(tag)
+        if hit is not None and hit[0] == weight._version:
+            return hit[1]
+    w = weight.detach()
+    w = w if w.is_contiguous() else w.contiguous()
+    assert w.dtype == torch.float32 and w.dim() in (2, 4) and (w.dim() == 2 or w.shape[2] == w.shape[3])
+    n, k, ks = w.shape[0], w.shape[1], (w.shape[2] if w.dim() == 4 else 1)
+    hi = torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16)
+    lo = torch.empty_like(hi)
+    _lib.check(_lib.lib().spei_pack_split16(ctx._tp(w), n, k, ks, {"fwd": 0, "dgrad": 1}[tag], ctx._tp(hi), ctx._tp(lo), ctx._stream()),
+               "spei_pack_split16")
+    out = (hi, lo)
+    try:
+        if cache is None:
+            cache = weight._spei_split = {}
+        cache[tag] = (weight._version, out)
+    except AttributeError:
+        pass
     return out
 
 
@@ -110,15 +113,15 @@ def _igemm(ctx: Ctx, a: torch.Tensor, K: int, w_tnk: torch.Tensor, bias: Optiona
            Hin: int, Win: int, Hout: int, Wout: int, ksize: int, stride: int, mode: int, act: int,
            residual: Optional[torch.Tensor] = None, rowscale: Optional[torch.Tensor] = None, batch: int = 1, prec: str = "f32",
            wkey=None) -> None:
-    """One launch over `batch` equally sized maps stored one after the other (blockIdx.z / .y = sample)."""
-    assert a.is_contiguous() and out.is_contiguous() and w_tnk.is_contiguous() and tuple(w_tnk.shape) == (ksize * ksize, N, K), \
-        (tuple(w_tnk.shape), ksize, N, K)
+    """One launch over `batch` equally sized maps stored one after the other (blockIdx.z / .y = sample).  `w_tnk`: the [tap][N][K] fp32
+    weight or a callable that makes it (only the fp32 kernel needs it: the split path packs from the parameter behind `wkey`)."""
+    assert a.is_contiguous() and out.is_contiguous()
     assert a.shape == (batch * Hin * Win, K) and out.shape == (batch * Hout * Wout, N) and K % 32 == 0 and N % 32 == 0
     assert residual is None or (residual.is_contiguous() and residual.shape == out.shape)
     lib = _lib.lib()
     if prec == "bf16x3" and mode == CONV and (rowscale is None or batch == 1):
         from .pack import BF16, F32
-        fhi, flo = _split_frags(w_tnk, wkey)
+        fhi, flo = _split_frags(ctx, wkey)
         ldr = N if residual is not None else 0
         if batch == 1 or Wout == 1:
             rows = batch * Hin * Win
@@ -132,6 +135,8 @@ def _igemm(ctx: Ctx, a: torch.Tensor, K: int, w_tnk: torch.Tensor, bias: Optiona
                                                     _p(ctx, residual), batch, Hin, Win, Hout, Wout, N, ksize, stride, ksize // 2, act,
                                                     ctx._stream()), "spei_conv_slab16_batched")
         return
+    w_tnk = w_tnk() if callable(w_tnk) else w_tnk
+    assert w_tnk.is_contiguous() and tuple(w_tnk.shape) == (ksize * ksize, N, K), (tuple(w_tnk.shape), ksize, N, K)
     _lib.check(lib.spei_igemm_f32_batched(_p(ctx, a), K, K, _NULL, 0, 0, _p(ctx, w_tnk), _p(ctx, bias), _p(ctx, out), N,
                                           _p(ctx, residual), N if residual is not None else 0, _p(ctx, rowscale), Hin, Win, Hout, Wout, N,
                                           ksize, stride, ksize // 2, mode, act, batch, ctx._stream()), "spei_igemm_f32_batched")
@@ -178,13 +183,12 @@ class _Conv2d(torch.autograd.Function):
         n, k = weight.shape[0], weight.shape[1]
         ho, wo = (H + 2 * (ksize // 2) - ksize) // stride + 1, (W + 2 * (ksize // 2) - ksize) // stride + 1
         x = x.contiguous()
-        w = _w_conv(weight)
         b = bias.detach().contiguous()
         out = torch.empty(B * ho * wo, n, device=x.device)
         res = residual.contiguous() if residual is not None else None
         prec = _PREC.get()
-        _igemm(ctx, x, k, w, b, out, n, H, W, ho, wo, ksize, stride, CONV, ACT_RELU if relu else ACT_NONE, res, batch=B, prec=prec,
-               wkey=_wkey(weight, "fwd"))
+        _igemm(ctx, x, k, lambda: _w_conv(weight), b, out, n, H, W, ho, wo, ksize, stride, CONV, ACT_RELU if relu else ACT_NONE, res, batch=B,
+               prec=prec, wkey=_wkey(weight, "fwd"))
         fctx.save_for_backward(x, weight, out if relu else None)
         fctx.meta = (B, H, W, ho, wo, ksize, stride, relu, residual is not None)
         fctx.prec = prec
@@ -205,13 +209,13 @@ class _Conv2d(torch.autograd.Function):
         dx = None
         if fctx.needs_input_grad[0]:
             # data gradient = transposed convolution of dZ with the weights' channel axes swapped (include/speinet_hip.h)
-            wt = _w_conv(weight).transpose(1, 2).contiguous()                              # [t][k][n]
+            wt = lambda: _w_conv(weight).transpose(1, 2).contiguous()                      # [t][k][n]
             hf, wf = ho * stride, wo * stride
             dx = torch.empty(B * hf * wf, k, device=dy.device)
             if fctx.prec == "bf16x3" and stride == 1:
                 # stride 1: the transposed convolution IS the convolution with the taps reversed
-                _igemm(ctx, dz, n, wt.flip(0).contiguous(), None, dx, k, ho, wo, hf, wf, ksize, 1, CONV, ACT_NONE, batch=B, prec="bf16x3",
-                       wkey=_wkey(weight, "dgrad"))
+                _igemm(ctx, dz, n, lambda: wt().flip(0).contiguous(), None, dx, k, ho, wo, hf, wf, ksize, 1, CONV, ACT_NONE, batch=B,
+                       prec="bf16x3", wkey=_wkey(weight, "dgrad"))
             else:
                 _igemm(ctx, dz, n, wt, None, dx, k, ho, wo, hf, wf, ksize, stride, CONV_T, ACT_NONE, batch=B)
             if (hf, wf) != (H, W):        # odd input size under stride 2: the transposed conv made one row / column too many
@@ -295,7 +299,7 @@ class _Linear(torch.autograd.Function):
         M = x.shape[0]
         out = torch.empty(M, n, device=x.device)
         prec = _PREC.get()
-        _igemm(ctx, x, k, weight.detach().reshape(1, n, k).contiguous(), bias.detach().contiguous(), out, n, M, 1, M, 1, 1, 1, CONV, ACT_NONE,
+        _igemm(ctx, x, k, lambda: weight.detach().reshape(1, n, k).contiguous(), bias.detach().contiguous(), out, n, M, 1, M, 1, 1, 1, CONV, ACT_NONE,
                residual.contiguous() if residual is not None else None, rowscale, prec=prec, wkey=_wkey(weight, "fwd"))
         fctx.save_for_backward(x, weight, rowscale)
         fctx.has_res = residual is not None
@@ -317,7 +321,7 @@ class _Linear(torch.autograd.Function):
         dx = None
         if fctx.needs_input_grad[0]:
             dx = torch.empty(M, k, device=dy.device)
-            _igemm(ctx, g, n, weight.detach().t().reshape(1, k, n).contiguous(), None, dx, k, M, 1, M, 1, 1, 1, CONV, ACT_NONE, prec=fctx.prec,
+            _igemm(ctx, g, n, lambda: weight.detach().t().reshape(1, k, n).contiguous(), None, dx, k, M, 1, M, 1, 1, 1, CONV, ACT_NONE, prec=fctx.prec,
                    wkey=_wkey(weight, "dgrad"))
         return dx, dw.view(n, k), db, (dy if fctx.has_res else None), None
 

@@ -644,3 +644,26 @@ def test_training_step_ragged_size_vs_oracle(which):
     print(f"{which} B=3 60x40: output {err:.1e}, loss {loss.item():.6f} vs {ref_loss.item():.6f}; gradients vs float64: worst "
           + ", ".join(f"{k} {e:.1e}" for e, k in devs[:3]) + f"; median {np.median([e for e, _ in devs]):.1e}")
     assert devs[0][0] < 5e-3 and np.median([e for e, _ in devs]) < 1e-3
+
+
+@pytest.mark.parametrize("n,k,ks", [(32, 32, 5), (64, 32, 3), (256, 128, 1), (128, 64, 3), (96, 160, 1)])
+def test_pack_split16_matches_the_torch_formulation(n, k, ks):
+    """spei_pack_split16 (one launch: reference-layout weight -> split bf16 halves in fragment order) against the tensor arithmetic
+    it replaces: hi = bf16(w), lo = bf16(w - hi), pack._frag of the [tap][N][K] view; and for the stride-1 data gradient the same of
+    the tap-reversed, channel-swapped view.  Bit for bit."""
+    from speinet_amd import _lib, pack
+    from speinet_amd.ops import Ctx
+    ctx = Ctx("f32", device=DEV)
+    w = torch.randn(n, k, ks, ks, generator=torch.Generator().manual_seed(n + k + ks)).to(DEV)
+    w = w if ks > 1 else w.reshape(n, k)
+    w4 = w.reshape(n, k, ks, ks)
+    fwd = w4.permute(2, 3, 0, 1).reshape(ks * ks, n, k).contiguous()
+    views = {0: fwd, 1: fwd.transpose(1, 2).flip(0).contiguous()}
+    for mode, v in views.items():
+        hi = v.to(torch.bfloat16)
+        lo = (v - hi.float()).to(torch.bfloat16)
+        fhi = torch.empty(w.numel(), device=DEV, dtype=torch.bfloat16)
+        flo = torch.empty_like(fhi)
+        _lib.check(_lib.lib().spei_pack_split16(ctx._tp(w.contiguous()), n, k, ks, mode, ctx._tp(fhi), ctx._tp(flo), ctx._stream()), "spei_pack_split16")
+        assert torch.equal(fhi.view(torch.int16), pack._frag(hi).reshape(-1).view(torch.int16)), (mode, "hi")
+        assert torch.equal(flo.view(torch.int16), pack._frag(lo).reshape(-1).view(torch.int16)), (mode, "lo")
