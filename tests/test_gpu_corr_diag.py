@@ -126,3 +126,29 @@ def test_corr_diag_lower_reference_map_takes_the_slab_kernel():
     tp = ops._tp
     rc = _lib.lib().spei_corr_diag_top2_16(2, tp(h16), tp(h16), tp(inv_r), 37, 45, 29, 51, 128, tp(z), tp(zi), tp(z), tp(zi), tp(ws), ops._stream())
     assert rc != 0 and b"Hr" in _lib.lib().spei_last_error()
+
+
+def test_corr_diag_random_shapes():
+    """A seeded sweep of 24 ragged shape pairs (query hl x wl, reference hr x wr with hr >= hl): segment boundaries, wraps of the cyclic
+    diagonals inside a segment, partial tiles on either map, groups of diagonals that are not full — against the float64 oracle."""
+    import random
+    rng = random.Random(20260403)
+    ops = Ctx("f16", "top2", device=DEV)
+    for case in range(24):
+        hl, wl = rng.randint(1, 60), rng.randint(1, 140)
+        hr, wr = hl + rng.choice((0, 0, 1, 3, 17, 40)), rng.choice((wl, rng.randint(1, 140)))
+        lr3, rf3 = rnd(1000 + case, 1, 128, hl, wl), rnd(2000 + case, 1, 128, hr, wr)
+        r, top = oracle_top2(lr3, rf3)
+        inv_l, inv_r = ops.patch_invnorm(fm(lr3)), ops.patch_invnorm(fm(rf3))
+        plan = ops.corr_plan(fm(lr3), fm(rf3), inv_l, inv_r)
+        assert plan.kernel.startswith("corr_diag_kernel")
+        plan.launch()
+        arg = plan.arg.cpu().long()
+        chosen = r.gather(0, arg.view(1, -1))[0]                      # float64 score of the position the kernels chose
+        # S is the exact score of the chosen position (fp64 re-score); the choice is the maximum except where three or more positions
+        # lie within the noise of the 16-bit candidate scores (~5e-5 for white-noise features: the true winner was not among the two
+        # candidates) — then the chosen score is within that noise of the maximum
+        assert (plan.s.cpu().double() - chosen).abs().max().item() < 1e-6, (case, (hl, wl, hr, wr))
+        gap = top.values[0] - chosen
+        nflip = int((arg != top.indices[0]).sum())
+        assert gap.max().item() < 2e-4 and nflip <= max(2, arg.numel() // 1000), (case, (hl, wl, hr, wr), nflip, gap.max().item())
