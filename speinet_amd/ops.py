@@ -181,7 +181,8 @@ class Ctx:
                       (three resident rounds instead of half of one).  Off: round 2's per-pass launches on two streams
       corr_bf16       "f16" with corr "top2": the candidate pass of the correlation runs on bf16 operands (True, default) instead of
                       f16.  The fp32 re-score decides the winner and S either way (G14: 16 more of 57600 positions differ, dPSNR
-                      +1e-6 dB); bf16 operands let the chip hold a ~7 % higher MFMA clock on this kernel (tools/bench_corr.py)
+                      +1e-6 dB); bf16 operands let the chip hold a ~7 % higher MFMA clock on the slab kernel (tools/bench_corr.py); on the diagonal
+                      kernel, which is not limited by the matrix pipe, the difference is 1-5 % (2.60-2.73 vs 2.73-2.76 ms)
       corr_diag       corr "top2", reference map at least as high as the query map (SearchTransfer's maps of one size, SelfTransfer's
                       rotated landscape map): the candidate pass is the diagonal-sliding kernel (corr_diag16.hip): each row-against-row term of the 3x3-patch score is computed once and
                       shared by the three patch rows that use it — a third of the bmm's flops, same fp32 sums.  Off: the slab kernel
