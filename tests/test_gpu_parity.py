@@ -299,6 +299,30 @@ def test_forward_golden(golden_dir, net, name, b, h, w):
         assert dp <= 1e-3, f"PSNR delta {dp:.2e} dB"
 
 
+@pytest.mark.parametrize("h,w", [(60, 40), (100, 60), (60, 140)])
+def test_forward_portrait_and_wide_vs_oracle(net, synth_sd, h, w):
+    """Frame shapes the goldens do not hold — portrait (SelfTransfer's rotated reference map is LOWER than the query map there: the
+    diagonal correlation kernel hands over to the slab kernel) and a wide strip — mixed batch (one sample per routing branch), against
+    the oracle run here on the CPU; the f16 / top2 throughput mode against the same output with its PSNR bound."""
+    x = synth_frames(2, h, w, seed=100 + h, zero_ref=(1,))
+    ref = O.forward(x, synth_sd, O.Cfg())
+    with torch.no_grad():
+        out = net(x.to(DEV)).cpu()
+    assert (out - ref).abs().max().item() < 1e-3
+    saved = (net.precision, net.corr_precision)
+    net.precision, net.corr_precision = "f16", "top2"
+    try:
+        with torch.no_grad():
+            out16 = net(x.to(DEV)).cpu()
+    finally:
+        net.precision, net.corr_precision = saved
+    assert torch.isfinite(out16).all()
+    for i in range(2):
+        tgt = O.to_uint8(x[i:i + 1, 1])
+        dp = abs(O.psnr_uint8(O.to_uint8(out16[i:i + 1]), tgt) - O.psnr_uint8(O.to_uint8(ref[i:i + 1]), tgt))
+        assert dp <= 2e-3, f"sample {i}: PSNR delta {dp:.2e} dB"          # tiny frames: a handful of uint8 steps move the PSNR more than at 720p
+
+
 def test_forward_routing_argument(net):
     x = synth_frames(1, 40, 60, seed=7).to(DEV)
     with torch.no_grad():
