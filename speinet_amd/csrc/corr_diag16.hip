@@ -46,7 +46,7 @@ struct CorrDiagParams {
     const float* inv_ref;
     float* part;                           // [Hr (delta)][ktiles][Hl * Wl] key pairs
     int Hl, Wl, Hr, Wr;                    // query map, reference map (Hr >= Hl)
-    int qtiles, ktiles, ngroups, seg_len;
+    int qtiles, ktiles, ngroups, seg_len, nseg;
     int nwg, xcd;                          // workgroups that have work; xcd: consecutive logical workgroups share an XCD (and its L2)
     long long* stamps;                     // tuning build: per-workgroup phase-time sums (tools/stamp_corr_diag.py)
 };
@@ -82,10 +82,12 @@ __global__ __launch_bounds__(512) void corr_diag_kernel(const CorrDiagParams<LP>
     // workgroup (the grid is padded to a multiple of 8; logical ids past the last workgroup exit).
     int bid = p.xcd ? (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
     if (bid >= p.nwg) return;
+    // fastest to slowest: diagonal group, segment, query tile, reference tile — the tile pairs an XCD works through one after the other
+    // keep their reference column (all Hr rows of one 64-pixel tile: 2.9 MB at 720p) in its L2
     const int group = bid % p.ngroups; bid /= p.ngroups;
-    const int kxt = bid % p.ktiles; bid /= p.ktiles;
+    const int seg = bid % p.nseg; bid /= p.nseg;
     const int qxt = bid % p.qtiles;
-    const int seg = bid / p.qtiles;
+    const int kxt = bid / p.qtiles;
     const int Hl = p.Hl, Wl = p.Wl, Hr = p.Hr, Wr = p.Wr;            // diagonals are cyclic in the reference height Hr >= Hl
     const int d0 = group * DM, delta = d0 + wd;
     const bool active = delta < Hr;
@@ -348,7 +350,7 @@ int corr_diag_run(const void* lr16, const void* ref16, const float* inv_ref, int
         if (eff > best_eff + 0.02) { best_eff = eff; best_n = n; }
     }
     p.seg_len = cdiv(Hl, best_n);
-    const int nseg = cdiv(Hl, p.seg_len);
+    const int nseg = p.nseg = cdiv(Hl, p.seg_len);
     p.part = ws;
     p.stamps = spei_stamp_buffer();
     float* pval = ws + (size_t)2 * Hr * p.ktiles * Nl;
