@@ -548,14 +548,24 @@ __global__ __launch_bounds__(256) void resblock_apply_bwd_kernel(const ApplyBwdP
 // partial slices a weight gradient may be split into (the workspace holds that many copies of it): 64 for the per-tap kernels; the
 // tap-row kernel has 1 / ksize of the workgroups per slice and takes up to 256 slices for ~2k workgroups per launch
 static int wgrad_slices(int N, int K, int ksize) {
+    if (ksize == 1) {
+        // 1x1 layers (the Swin linears): 2 x 2 tiles per workgroup; their partial volume (slices x N x K floats, written and read back by
+        // the partial-sum launch) is what the extra slices cost, so only as many as give ~512 workgroups
+        const int per = cdiv(cdiv(N, 32), 2) * cdiv(cdiv(K, 32), 2);
+        const int want = cdiv(512, per);
+        return want < 8 ? 8 : (want > 64 ? 64 : want);
+    }
     const int per_slice = ksize * cdiv(N, 32) * cdiv(K, 32);
     int want = cdiv(2048, per_slice);
     want = want < 16 ? 16 : (want > 256 ? 256 : want);
     return want > 64 ? want : 64;
 }
 
+// slices the workspace holds: the fp32 kernel always cuts the pixels into up to 64 chunks
+static int wgrad_ws_slices(int N, int K, int ksize) { const int s = wgrad_slices(N, K, ksize); return s > 64 ? s : 64; }
+
 extern "C" int64_t spei_wgrad_ws_floats(int Hout, int Wout, int N, int K, int ksize) {
-    const int64_t sl = wgrad_slices(N, K, ksize);
+    const int64_t sl = wgrad_ws_slices(N, K, ksize);
     return sl * ksize * ksize * N * K + sl * 256;
 }
 
@@ -585,7 +595,7 @@ static int conv_wgrad_run(const float* x, int ldx, const float* dy, int ldy, flo
         if (chunk < 4) chunk = 4;
         q.chunk_seg = chunk;
         const int nchunks = cdiv(q.nseg, chunk);
-        float* bpart = ws + (size_t)wgrad_slices(N, K, ksize) * T * N * K;
+        float* bpart = ws + (size_t)wgrad_ws_slices(N, K, ksize) * T * N * K;
         q.bpart = dbias ? bpart : nullptr;
         if (!rows) hipLaunchKernelGGL(conv_wgrad16_kernel, dim3(T * q.ntn * q.ntk, nchunks), dim3(256), 0, st, q);
         else if (ksize == 5) hipLaunchKernelGGL(conv_wgrad16_row_kernel<5>, dim3(ksize * q.ntn * q.ntk, nchunks), dim3(256), 0, st, q);
@@ -607,7 +617,7 @@ static int conv_wgrad_run(const float* x, int ldx, const float* dy, int ldy, flo
     p.chunk_px = chunk;
     const int nchunks = cdiv(M, chunk);
     p.ntn = cdiv(N, 32); p.ntk = cdiv(K, 32);
-    float* bpart = ws + (size_t)wgrad_slices(N, K, ksize) * T * N * K;
+    float* bpart = ws + (size_t)wgrad_ws_slices(N, K, ksize) * T * N * K;
     p.bpart = dbias ? bpart : nullptr;
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(T * p.ntn * p.ntk, nchunks), dim3(256), 0, st, p);
     const int64_t count = (int64_t)T * N * K;
