@@ -324,6 +324,11 @@ int spei_plane_stats_batched(const float* a, const float* b, int prod, int H, in
 int spei_resblock_apply_bwd(const float* dout, const float* x1, const float* s, const float* g1, const float* g2, const float* rowmax,
                             const float* colmax, const float* d_rowmax, const float* d_rowmean, const float* d_colmax,
                             const float* d_colmean, const float* d_mean, float* dx1, int H, int W, int C, spei_stream_t stream);
+/* The same for `batch` dense maps stored one after the other (and their statistics / gate maps likewise) in one launch. */
+int spei_resblock_apply_bwd_batched(const float* dout, const float* x1, const float* s, const float* g1, const float* g2,
+                                    const float* rowmax, const float* colmax, const float* d_rowmax, const float* d_rowmean,
+                                    const float* d_colmax, const float* d_colmean, const float* d_mean, float* dx1, int batch, int H,
+                                    int W, int C, spei_stream_t stream);
 
 /* ---- backward of the cross-window-attention SwinIR blocks (model/swinir.py:238-281 under loss.backward(), the training step of
  * trainer/trainer_swint.py:34-44).  fp32; fixed-order reductions. ---- */

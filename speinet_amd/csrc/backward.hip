@@ -523,15 +523,18 @@ __global__ __launch_bounds__(256) void resblock_apply_bwd_kernel(const ApplyBwdP
     const int cg = p.C / 4;
     const int64_t total = (int64_t)p.H * p.W * cg;
     const float iw = 1.0f / (float)p.W, ih = 1.0f / (float)p.H, ihw = 1.0f / ((float)p.H * (float)p.W);
+    // batched launch (blockIdx.y = map): dense maps one after the other, per-map statistics and gate maps likewise
+    const size_t mb = blockIdx.y;
+    const size_t mo = mb * p.H * p.W * p.C, mr = mb * p.H * p.C, mc = mb * p.W * p.C, mm = mb * p.C;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % cg) * 4;
         const int64_t pix = i / cg;
         const int x = (int)(pix % p.W), y = (int)(pix / p.W);
-        const size_t o = pix * p.C + c, ro = (size_t)y * p.C + c, co = (size_t)x * p.C + c;
+        const size_t o = mo + pix * p.C + c, ro = mr + (size_t)y * p.C + c, co = mc + (size_t)x * p.C + c;
         const f32x4 d = *reinterpret_cast<const f32x4*>(p.dout + o), v = *reinterpret_cast<const f32x4*>(p.x1 + o);
-        const f32x4 gate = *reinterpret_cast<const f32x4*>(p.s + c) + (*reinterpret_cast<const f32x4*>(p.g1 + ro) + *reinterpret_cast<const f32x4*>(p.g2 + co));
+        const f32x4 gate = *reinterpret_cast<const f32x4*>(p.s + mm + c) + (*reinterpret_cast<const f32x4*>(p.g1 + ro) + *reinterpret_cast<const f32x4*>(p.g2 + co));
         f32x4 r = d * gate + *reinterpret_cast<const f32x4*>(p.d_rowmean + ro) * iw + *reinterpret_cast<const f32x4*>(p.d_colmean + co) * ih +
-                  *reinterpret_cast<const f32x4*>(p.d_mean + c) * ihw;
+                  *reinterpret_cast<const f32x4*>(p.d_mean + mm + c) * ihw;
         const f32x4 rm = *reinterpret_cast<const f32x4*>(p.rowmax + ro), cm = *reinterpret_cast<const f32x4*>(p.colmax + co);
         const f32x4 drm = *reinterpret_cast<const f32x4*>(p.d_rowmax + ro), dcm = *reinterpret_cast<const f32x4*>(p.d_colmax + co);
 #pragma unroll
@@ -696,20 +699,33 @@ extern "C" int spei_plane_stats_batched(const float* a, const float* b, int prod
     return plane_stats_run(a, b, prod, H, W, C, rowmax, rowmean, colmax, colmean, mean, ws, batch, stream);
 }
 
-extern "C" int spei_resblock_apply_bwd(const float* dout, const float* x1, const float* s, const float* g1, const float* g2, const float* rowmax,
-                                       const float* colmax, const float* d_rowmax, const float* d_rowmean, const float* d_colmax,
-                                       const float* d_colmean, const float* d_mean, float* dx1, int H, int W, int C, spei_stream_t stream) {
+static int resblock_apply_bwd_run(const float* dout, const float* x1, const float* s, const float* g1, const float* g2, const float* rowmax,
+                                  const float* colmax, const float* d_rowmax, const float* d_rowmean, const float* d_colmax,
+                                  const float* d_colmean, const float* d_mean, float* dx1, int batch, int H, int W, int C, spei_stream_t stream) {
     SPEI_REQUIRE(dout && x1 && s && g1 && g2 && rowmax && colmax && d_rowmax && d_rowmean && d_colmax && d_colmean && d_mean && dx1,
                  "spei_resblock_apply_bwd: null pointer");
-    SPEI_REQUIRE(C % 4 == 0 && H > 0 && W > 0, "spei_resblock_apply_bwd: bad shape");
+    SPEI_REQUIRE(C % 4 == 0 && H > 0 && W > 0 && batch >= 1 && batch <= 65535, "spei_resblock_apply_bwd: bad shape");
     ApplyBwdParams p;
     p.dout = dout; p.x1 = x1; p.s = s; p.g1 = g1; p.g2 = g2; p.rowmax = rowmax; p.colmax = colmax; p.d_rowmax = d_rowmax;
     p.d_rowmean = d_rowmean; p.d_colmax = d_colmax; p.d_colmean = d_colmean; p.d_mean = d_mean; p.dx1 = dx1; p.H = H; p.W = W; p.C = C;
     const int64_t total = (int64_t)H * W * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(resblock_apply_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(resblock_apply_bwd_kernel, dim3(blocks, batch), dim3(256), 0, (hipStream_t)stream, p);
     SPEI_CHECK_LAUNCH("spei_resblock_apply_bwd");
     return 0;
+}
+
+extern "C" int spei_resblock_apply_bwd(const float* dout, const float* x1, const float* s, const float* g1, const float* g2, const float* rowmax,
+                                       const float* colmax, const float* d_rowmax, const float* d_rowmean, const float* d_colmax,
+                                       const float* d_colmean, const float* d_mean, float* dx1, int H, int W, int C, spei_stream_t stream) {
+    return resblock_apply_bwd_run(dout, x1, s, g1, g2, rowmax, colmax, d_rowmax, d_rowmean, d_colmax, d_colmean, d_mean, dx1, 1, H, W, C, stream);
+}
+
+extern "C" int spei_resblock_apply_bwd_batched(const float* dout, const float* x1, const float* s, const float* g1, const float* g2,
+                                               const float* rowmax, const float* colmax, const float* d_rowmax, const float* d_rowmean,
+                                               const float* d_colmax, const float* d_colmean, const float* d_mean, float* dx1, int batch, int H,
+                                               int W, int C, spei_stream_t stream) {
+    return resblock_apply_bwd_run(dout, x1, s, g1, g2, rowmax, colmax, d_rowmax, d_rowmean, d_colmax, d_colmean, d_mean, dx1, batch, H, W, C, stream);
 }
 
 // ---- training: a weight in the reference's layout -> the split (hi, lo) bf16 pair in MFMA fragment order, ONE launch -----------------

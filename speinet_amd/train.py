@@ -608,10 +608,10 @@ class _GatedSum(torch.autograd.Function):
         with torch.no_grad():
             s, g1, g2 = _gate_maps(rowmax, rowmean, colmax, colmean, mean, prm, bn_train, update_running=bn_train)
         out = torch.empty_like(x)
-        for i in range(B):
-            sl = slice(i * hw, (i + 1) * hw)
-            _lib.check(lib.spei_resblock_apply(_p(ctx, x[sl]), _p(ctx, x1[sl]), 0, _p(ctx, s[i]), _p(ctx, g1[i]), _p(ctx, g2[i]), _NULL,
-                                               _p(ctx, out[sl]), c, H, W, c, ctx._stream()), "spei_resblock_apply")
+        s, g1, g2 = s.contiguous(), g1.contiguous(), g2.contiguous()
+        assert s.shape == (B, c) and g1.shape == (B, H, c) and g2.shape == (B, W, c)
+        _lib.check(lib.spei_resblock_apply_batched(_p(ctx, x), _p(ctx, x1), 0, _p(ctx, s), _p(ctx, g1), _p(ctx, g2), _p(ctx, out), B, H, W, c,
+                                                   ctx._stream()), "spei_resblock_apply_batched")
         # the running buffers move again when the same block runs on the next frame (the encoder is applied to every frame of the
         # window): the backward of a train-mode call does not read them, so it keeps detached copies
         keep = [t.detach().clone() if i in (7, 8, 12, 13) else t for i, t in enumerate(params)]
@@ -643,12 +643,11 @@ class _GatedSum(torch.autograd.Function):
             grads = torch.autograd.grad([s2, g1b, g2b], leaves, [ds, dg1, dg2], allow_unused=True)
         d_stats = [g.contiguous() if g is not None else torch.zeros_like(t) for g, t in zip(grads[:5], stats)]
         dx1 = torch.empty_like(x1)
-        for i in range(B):
-            sl = slice(i * hw, (i + 1) * hw)
-            _lib.check(lib.spei_resblock_apply_bwd(_p(ctx, dout[sl]), _p(ctx, x1[sl]), _p(ctx, s[i]), _p(ctx, g1[i]), _p(ctx, g2[i]),
-                                                   _p(ctx, rowmax[i]), _p(ctx, colmax[i]), _p(ctx, d_stats[0][i]), _p(ctx, d_stats[1][i]),
-                                                   _p(ctx, d_stats[2][i]), _p(ctx, d_stats[3][i]), _p(ctx, d_stats[4][i]), _p(ctx, dx1[sl]),
-                                                   H, W, c, ctx._stream()), "spei_resblock_apply_bwd")
+        assert d_stats[0].shape == (B, H, c) and d_stats[2].shape == (B, W, c) and d_stats[4].shape == (B, c)
+        _lib.check(lib.spei_resblock_apply_bwd_batched(_p(ctx, dout), _p(ctx, x1), _p(ctx, s), _p(ctx, g1), _p(ctx, g2), _p(ctx, rowmax),
+                                                       _p(ctx, colmax), _p(ctx, d_stats[0]), _p(ctx, d_stats[1]), _p(ctx, d_stats[2]),
+                                                       _p(ctx, d_stats[3]), _p(ctx, d_stats[4]), _p(ctx, dx1), B, H, W, c, ctx._stream()),
+                   "spei_resblock_apply_bwd_batched")
         pg = iter(grads[5:])
         dparams = [next(pg) if t.requires_grad else None for t in prm]
         return (dout, dx1, None, None, None, None) + tuple(dparams)
