@@ -2,7 +2,10 @@
 """Headline benchmark: deblurred 720p frames/s of the SPEINet per-sequence forward pass on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU)
+  (N > 1: one rank per GPU over RCCL.  Either the caller starts the ranks — `python -m torch.distributed.run --nproc-per-node N ...
+  bench.py --gpus N ...`, as the driver does — or, with no RANK in the environment, bench.py starts them itself as child processes
+  of a parent that never touches the GPU (speinet_amd.dist.launch_ranks) and passes rank 0's line through.  --gpus must equal the
+  RCCL world size; a node with fewer GPUs than ranks is an error, never a 1-GPU line.)
 
 A "step" is one forward of one synthetic [1,5,3,720,1280] window (BASELINE.json configs[1]) per rank, inputs already
 resident in HBM.  Frames are independent, so ranks shard by frame with NO data-path collective (weak scaling);
@@ -147,6 +150,7 @@ def train_main(argv=None):
 
 def train_measure(argv=None):
     ap = argparse.ArgumentParser(prog="bench.py --train")
+    ap.add_argument("--gpus", type=int, default=1, help="ranks (one per GPU, gradients averaged over RCCL); > 1 without RANK in the env: starts them")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--patch", type=int, default=200)
     ap.add_argument("--steps", type=int, default=5)
@@ -160,6 +164,11 @@ def train_measure(argv=None):
                     help="swint: model/swint.py (trainer_swint.py, config 5); speinet: model/speinet.py (trainer_swint_hsa_nsf.py), every "
                          "4th crop without a sharp reference")
     a = ap.parse_args(argv)
+    if "RANK" not in os.environ and a.gpus > 1:
+        from speinet_amd.dist import launch_ranks
+        sys.exit(launch_ranks(os.path.abspath(__file__), ["--train", *(argv if argv is not None else sys.argv[1:])], a.gpus))
+    if a.gpus != int(os.environ.get("WORLD_SIZE", "1")):
+        raise SystemExit(f"bench.py --train: --gpus {a.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}")
     import numpy as np
     from speinet_amd.loss import Loss
     from speinet_amd.speinet import default_args
@@ -282,6 +291,12 @@ def main():
     ap.add_argument("--width", type=int, default=W)
     args = ap.parse_args()
 
+    if "RANK" not in os.environ and args.gpus > 1:
+        # one command for N GPUs: this parent never touches the GPU; it starts the N ranks (python -m torch.distributed.run ...
+        # bench.py <the same arguments>) as a child, passes rank 0's JSON line through and exits with the worst rank's code
+        from speinet_amd.dist import launch_ranks
+        sys.exit(launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -296,8 +311,9 @@ def main():
     else:
         local = 0
         torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run for N > 1", file=sys.stderr)
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the line's n_gpus must be the RCCL world size "
+                         "(`python bench.py --gpus N` starts its own ranks; under torch.distributed.run pass --gpus = --nproc-per-node)")
     dev = torch.device("cuda", local)
 
     from speinet_amd.speinet import SPEINet, default_args

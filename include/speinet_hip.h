@@ -126,6 +126,14 @@ int spei_conv_slab16_fa(int fmt, const float* x, int K, const void* x1, const fl
 int spei_mlp_fused16(int fmt, const float* x, float* out, const void* w1_frag, const float* b1, const void* w2_frag,
                      const float* b2, int64_t M, spei_stream_t stream);
 
+/* The same MLP branch (model/swinir.py:12-29, :279) as a two-role pipeline (round 4): the hidden dimension moves through the
+ * workgroup in four quarters; waves 0-3 compute fc1 + bias + GELU of quarter q into LDS while waves 4-7 accumulate fc2 over quarter
+ * q - 1, so each SIMD's matrix pipe and vector ALU work at the same time; the fc2 accumulators start from x + b2 (residual loaded
+ * straight into them) and are stored as they stand.  Arguments, layouts and aliasing rule as spei_mlp_fused16; the sums differ from
+ * it in fp32 rounding only (the residual enters the fc2 sum first instead of last). */
+int spei_mlp_ws16(int fmt, const float* x, float* out, const void* w1_frag, const float* b1, const void* w2_frag,
+                  const float* b2, int64_t M, spei_stream_t stream);
+
 /* The same MLP branch, token-stationary (round 3, csrc/swin_tok16.hip): a wave keeps its 32 tokens in registers from the
  * LayerNorm to the residual store, every GEMM is computed transposed with the weights as the A operand out of a 4-slot LDS ring
  * that a 512-thread workgroup fills by LDS-DMA once per 256 tokens.  wstream: the block's fc1 / fc2 weights as ONE linear

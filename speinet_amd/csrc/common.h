@@ -39,10 +39,16 @@ static inline long long* spei_stamp_buffer() { const char* v = getenv("SPEI_STAM
     do {                                                                                              \
         if ((buf) && threadIdx.x == 0) (buf)[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
+// the same from lane 0 of another wave (thread t): kernels whose waves take different roles
+#define SPEI_STAMP_AT(buf, i, t)                                                                      \
+    do {                                                                                              \
+        if ((buf) && threadIdx.x == (t)) (buf)[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 #else
 static constexpr int spei_knob(const char*, int dflt) { return dflt; }
 static inline long long* spei_stamp_buffer() { return nullptr; }
 #define SPEI_STAMP(buf, i) do { } while (0)
+#define SPEI_STAMP_AT(buf, i, t) do { } while (0)
 #endif
 
 // Raise a kernel's dynamic-LDS limit before its first launch with `lds` bytes ON THE CURRENT DEVICE.  The attribute is

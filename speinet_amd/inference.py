@@ -445,17 +445,29 @@ def build_args(argv=None):
                    help="recompute every encoder pass per window instead of reusing the per-frame results of overlapping windows")
     p.add_argument("--streams", type=int, default=2, help="HIP streams for the independent branches of a frame")
     p.add_argument("--no_graph", dest="graph", action="store_false", default=True, help="launch kernels eagerly (no hipGraph replay)")
+    p.add_argument("--n_GPUs", type=int, default=1,
+                   help="ranks, one per GPU, clips sharded over them (the reference's preset attribute n_GPUs, inference_SPEINet.py:626-697, "
+                        "there DataParallel); > 1 without RANK in the environment: this process starts the ranks and waits for them")
     a = p.parse_args(argv)
     for k, v in PRESETS.get(a.default_data, {}).items():
         if getattr(a, k) is None:
             setattr(a, k, v)
+    n_gpus = a.n_GPUs
     for k, v in vars(default_args()).items():
         setattr(a, k, v)
+    a.n_GPUs = n_gpus
     return a
 
 
 def main(argv=None):
     a = build_args(argv)
+    if "RANK" not in os.environ and a.n_GPUs > 1:
+        # one command for N GPUs: the parent (no GPU call) starts `python -m torch.distributed.run ... -m speinet_amd.inference <args>`
+        import sys
+        from .dist import launch_ranks
+        raise SystemExit(launch_ranks("speinet_amd.inference", list(sys.argv[1:] if argv is None else argv), a.n_GPUs, module=True))
+    if a.n_GPUs != int(os.environ.get("WORLD_SIZE", "1")):
+        raise SystemExit(f"--n_GPUs {a.n_GPUs} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}")
     if "RANK" in os.environ:
         import torch.distributed as dist
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))

@@ -179,6 +179,8 @@ class Ctx:
                       stages in ONE launch per layer (gridDim.y = pass; engine.enc_batched) instead of one launch per pass and layer:
                       bit-identical frames, ~1000 fewer launches per frame, and at H/4 a launch has 3150 workgroups instead of 450
                       (three resident rounds instead of half of one).  Off: round 2's per-pass launches on two streams
+      mlp_ws          (default OFF) 16-bit, with fuse_mlp: the fused MLP branch as a two-role pipeline (spei_mlp_ws16: fc1 + GELU producers
+                      and fc2 consumers sharing each SIMD).  Correct and tested; first measurement 66 vs 61.5 us per call at 720p
       corr_bf16       "f16" with corr "top2": the candidate pass of the correlation runs on bf16 operands (True, default) instead of
                       f16.  The fp32 re-score decides the winner and S either way (G14: 16 more of 57600 positions differ, dPSNR
                       +1e-6 dB); bf16 operands let the chip hold a ~7 % higher MFMA clock on the slab kernel (tools/bench_corr.py); on the diagonal
@@ -195,7 +197,7 @@ class Ctx:
     ACT_NONE, ACT_RELU, ACT_GELU = ACT_NONE, ACT_RELU, ACT_GELU
     CONV, CONV_T = CONV, CONV_T
     _FIELDS = ("precision", "corr_precision", "device", "use_slab", "bf16_storage", "x1_bf16", "fuse_mlp", "fuse_attn",
-               "fuse_block", "commute_upconv", "commute_any", "corr_bf16", "corr_diag", "fuse_apply", "split_decode", "batch_enc", "stage", "profile", "capture")
+               "fuse_block", "commute_upconv", "commute_any", "corr_bf16", "corr_diag", "fuse_apply", "split_decode", "batch_enc", "mlp_ws", "stage", "profile", "capture")
     # stages of an f16 frame that run in split (bf16x3) arithmetic by default, see `split_decode`
     SPLIT_STAGES = ("glue", "glue1", "dec2")
     __slots__ = _FIELDS
@@ -203,7 +205,7 @@ class Ctx:
     def __init__(self, precision: str = "f32", corr_precision: str = "bf16x3", device=None, use_slab: bool = True,
                  bf16_storage: bool = True, x1_bf16: bool = True, fuse_mlp: bool = True, fuse_attn: bool = True,
                  fuse_block: bool = False, commute_upconv: bool = True, commute_any: bool = False, corr_bf16: bool = True,
-                 corr_diag: bool = True, fuse_apply: bool = False, split_decode: bool = True, batch_enc: bool = True,
+                 corr_diag: bool = True, fuse_apply: bool = False, split_decode: bool = True, batch_enc: bool = True, mlp_ws: bool = False,
                  stage: Optional[dict] = None,
                  profile: Optional[dict] = None, capture: Optional[dict] = None):
         if precision not in PRECISIONS:
@@ -224,7 +226,7 @@ class Ctx:
         object.__setattr__(self, "device", device)
         for k, v in (("use_slab", use_slab), ("bf16_storage", bf16_storage), ("x1_bf16", x1_bf16), ("fuse_mlp", fuse_mlp),
                      ("fuse_attn", fuse_attn), ("fuse_block", fuse_block), ("commute_upconv", commute_upconv), ("commute_any", commute_any),
-                     ("corr_bf16", corr_bf16), ("corr_diag", corr_diag), ("fuse_apply", fuse_apply), ("split_decode", split_decode), ("batch_enc", batch_enc)):
+                     ("corr_bf16", corr_bf16), ("corr_diag", corr_diag), ("fuse_apply", fuse_apply), ("split_decode", split_decode), ("batch_enc", batch_enc), ("mlp_ws", mlp_ws)):
             object.__setattr__(self, k, bool(v))
         object.__setattr__(self, "stage", dict(stage) if stage else {})
         object.__setattr__(self, "profile", profile)
@@ -524,8 +526,8 @@ class Ctx:
         assert tuple(w1.shape) == (1, 512, 256) and tuple(w2.shape) == (1, 256, 512)
         tp = self._tp
         f = self.fmt
-        _lib.check(_lib.lib().spei_mlp_fused16(f, tp(x), tp(out), tp(w1.frag(f)), tp(b1), tp(w2.frag(f)), tp(b2), x.shape[0], self._stream()),
-                   "spei_mlp_fused16")
+        fn = _lib.lib().spei_mlp_ws16 if self.mlp_ws else _lib.lib().spei_mlp_fused16
+        _lib.check(fn(f, tp(x), tp(out), tp(w1.frag(f)), tp(b1), tp(w2.frag(f)), tp(b2), x.shape[0], self._stream()), "spei_mlp_fused16")
         return out
 
     def attn_tok(self, x: torch.Tensor, yhat: torch.Tensor, bk: dict, H: int, W: int, shift: int, out: torch.Tensor) -> torch.Tensor:

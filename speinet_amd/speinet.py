@@ -247,6 +247,8 @@ class SPEINet(nn.Module):
         self._graphs = {}
         self._graph_devices = set()
         self._generation += 1
+        from .train import drop_split_cache
+        drop_split_cache(self)           # the training graph's packed bf16 halves, kept on the parameters (train._split_frags)
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)

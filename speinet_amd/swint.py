@@ -66,6 +66,8 @@ class SPEINet(nn.Module):
         for key in list(self._packed):
             torch.cuda.synchronize(torch.device(key))
         self._packed = {}
+        from .train import drop_split_cache
+        drop_split_cache(self)           # the training graph's packed bf16 halves, kept on the parameters (train._split_frags)
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)

@@ -66,12 +66,16 @@ def _split_frags(ctx: "Ctx", owner):
     spei_pack_split16).  `owner` = (parameter tensor, tag): tag "fwd" = the forward weight [tap][N][K], "dgrad" = the stride-1
     data-gradient weight (taps reversed, channel axes swapped).  The pair is kept ON the parameter object together with the `_version`
     it was made from — the same weight is packed once per optimizer step however many encoder passes use it, and nothing can outlive
-    or be mistaken for another parameter (an address-keyed table can: a freed parameter's address is handed to the next model's)."""
+    or be mistaken for another parameter (an address-keyed table can: a freed parameter's address is handed to the next model's).
+    The stamp is (`_version`, storage address, device): `.to()` / `param.data = t` swap the storage without touching the counter.
+    Edits THROUGH `.data` (`p.data.mul_()`) change neither: the model's `invalidate_packed()` — run at the top of every autograd
+    forward — drops the cache of every parameter (`drop_split_cache`), so a pair lives for one forward + backward at most."""
     weight, tag = owner
+    stamp = (weight._version, weight.data_ptr(), str(weight.device))
     cache = getattr(weight, "_spei_split", None)
     if cache is not None:
         hit = cache.get(tag)
-        if hit is not None and hit[0] == weight._version:
+        if hit is not None and hit[0] == stamp:
             return hit[1]
     w = weight.detach()
     w = w if w.is_contiguous() else w.contiguous()
@@ -85,10 +89,17 @@ def _split_frags(ctx: "Ctx", owner):
     try:
         if cache is None:
             cache = weight._spei_split = {}
-        cache[tag] = (weight._version, out)
+        cache[tag] = (stamp, out)
     except AttributeError:
         pass
     return out
+
+
+def drop_split_cache(module) -> None:
+    """Forget the packed bf16 halves kept on the module's parameters (called by `invalidate_packed()`)."""
+    for p_ in module.parameters():
+        if getattr(p_, "_spei_split", None):
+            p_._spei_split = {}
 
 
 def _wkey(weight: torch.Tensor, tag: str):

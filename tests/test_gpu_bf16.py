@@ -196,14 +196,16 @@ def test_forward_16bit_golden(golden_dir, net, name, b, h, w, mode, corr, tol_er
         assert dps[i] <= tol_db, (i, dps[i])           # no per-branch slack (round 3): the north-star bound on `_forwardb` too
 
 
+@pytest.mark.parametrize("ws", [True, False])
 @pytest.mark.parametrize("mode", ["bf16", "f16"])
-def test_mlp_fused_vs_oracle(synth_sd, mode):
-    """Fused LN -> fc1 -> GELU -> fc2 -> +x kernel against the fp32 formula (tolerance of the mode, relative to the branch)."""
-    ops = Ctx(mode, device=DEV)
+def test_mlp_fused_vs_oracle(synth_sd, mode, ws):
+    """Fused LN -> fc1 -> GELU -> fc2 -> +x kernel against the fp32 formula (tolerance of the mode, relative to the branch); ws: the
+    two-role pipeline of round 4 (spei_mlp_ws16) / round 2's kernel."""
+    ops = Ctx(mode, device=DEV, mlp_ws=ws)
     p = "swin.layers.1.residual_group.blocks.2."
     bk = pack.swin_block(synth_sd, p, 8, 5)
     w1, w2 = pack.PackedW(bk["w1"].t, DEV), pack.PackedW(bk["w2"].t, DEV)
-    for m in (64, 1000, 2500, 57600):              # whole tile, ragged tail, many tiles, the 720p token count
+    for m in (1, 64, 127, 1000, 2500, 57600, 115200):   # one token, half a tile, a ragged tile, ragged tail, many tiles, the 720p token count, two calls' worth
         x = rnd(40 + m, m, 256, scale=1.5) + 0.3
         ref = x + F.linear(F.gelu(F.linear(F.layer_norm(x, (256,), synth_sd[p + "norm2.weight"], synth_sd[p + "norm2.bias"], 1e-5),
                                            synth_sd[p + "mlp.fc1.weight"], synth_sd[p + "mlp.fc1.bias"])),

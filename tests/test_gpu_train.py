@@ -667,3 +667,35 @@ def test_pack_split16_matches_the_torch_formulation(n, k, ks):
         _lib.check(_lib.lib().spei_pack_split16(ctx._tp(w.contiguous()), n, k, ks, mode, ctx._tp(fhi), ctx._tp(flo), ctx._stream()), "spei_pack_split16")
         assert torch.equal(fhi.view(torch.int16), pack._frag(hi).reshape(-1).view(torch.int16)), (mode, "hi")
         assert torch.equal(flo.view(torch.int16), pack._frag(lo).reshape(-1).view(torch.int16)), (mode, "lo")
+
+
+def test_inplace_data_edit_reaches_the_split_weights():
+    """ADVICE r3: the packed bf16 (hi, lo) halves of the bf16x3 training graph are cached on the parameters, stamped with `_version`;
+    `p.data.mul_()` / `p.data.copy_()` do not move that counter.  `invalidate_packed()` — run at the top of every autograd forward —
+    drops them: after an edit through `.data` the bf16x3 step must follow the f32 step, not the stale weights."""
+    from speinet_amd.speinet import default_args
+    from speinet_amd.swint import SPEINet
+    from speinet_amd.synth import synth_frames, synth_state_dict
+    from speinet_amd import train as T
+    args = default_args()
+    args.n_sequence = 3
+    net = SPEINet(n_sequence=3, args=args)
+    net.load_state_dict(synth_state_dict(net.state_dict(), seed=0), strict=True)
+    net = net.to(DEV).train()
+    x = synth_frames(2, 40, 40, seed=17)[:, :3].contiguous().to(DEV)
+    scales = T.drop_path_scales(net.cfg.depths, 2, 2, generator=torch.Generator().manual_seed(1))
+    net.train_precision = "bf16x3"
+    with torch.no_grad():
+        before = net(x, drop_path_scales=scales).clone()
+        assert any(getattr(p, "_spei_split", None) for p in net.parameters()), "the split cache is in use"
+        for name, p in net.named_parameters():
+            if name.endswith("weight") and p.dim() in (2, 4):
+                p.data.mul_(1.25)                                  # invisible to `_version`
+        after16 = net(x, drop_path_scales=scales).clone()
+        net.train_precision = "f32"
+        after32 = net(x, drop_path_scales=scales).clone()
+    scale = after32.abs().max().item()
+    moved = (after16 - before).abs().max().item() / scale
+    apart = (after16 - after32).abs().max().item() / scale
+    print(f"in-place edit: bf16x3 output moved by {moved:.2e}, bf16x3 vs f32 after the edit {apart:.1e}")
+    assert moved > 1e-2 and apart < 2e-4

@@ -41,11 +41,14 @@ for shift in (0, 2):
 out_b = torch.empty_like(x)
 for shift in (0, 2):
     timeit(f"attn_tok   shift={shift}", lambda: ops.attn_tok(x, yhat, bk, H, W, shift, out_b))
-timeit("mlp_fused", lambda: ops.mlp_fused(x, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out))
+old, ws = ops.replace(mlp_ws=False), ops.replace(mlp_ws=True)
+timeit("mlp_fused (round 2 kernel)", lambda: old.mlp_fused(x, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out))
+timeit("mlp_ws (two-role pipeline)", lambda: ws.mlp_fused(x, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out))
 timeit("mlp_tok", lambda: ops.mlp_tok(x, bk["mlp_stream"], bk["b1"], bk["b2"], out))
 x2 = torch.randn(2 * H * W, 256, device=dev)
 out2 = torch.empty_like(x2)
-timeit("mlp_fused 2x tokens", lambda: ops.mlp_fused(x2, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out2))
+timeit("mlp_fused 2x tokens", lambda: old.mlp_fused(x2, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out2))
+timeit("mlp_ws    2x tokens", lambda: ws.mlp_fused(x2, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out2))
 timeit("mlp_tok   2x tokens", lambda: ops.mlp_tok(x2, bk["mlp_stream"], bk["b1"], bk["b2"], out2))
 for shift in (0, 2):
     timeit(f"attn + mlp shift={shift}", lambda: ops.mlp_fused(ops.attn_fused(x, yhat, bk, H, W, shift, out), bk["w1"], bk["b1"], bk["w2"], bk["b2"], out))

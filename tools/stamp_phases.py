@@ -55,8 +55,10 @@ def run():
         ops.attn_tok(x, yhat, bk, H, W, 2, out)
     elif which == "mlptok":
         ops.mlp_tok(x, bk["mlp_stream"], bk["b1"], bk["b2"], out)
+    elif which == "mlpold":
+        ops.replace(mlp_ws=False).mlp_fused(x, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out)
     else:
-        ops.mlp_fused(x, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out)
+        ops.replace(mlp_ws=True).mlp_fused(x, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out)
 
 
 for _ in range(5):
@@ -84,6 +86,7 @@ for i in range(1, last + 1):
     j = max(k for k in range(i) if (s[:, k] > 0).any())
     d = (s[:, i] - s[:, j]).float() * tick_us
     print(f"  phase {j}->{i}: median {d.median():7.2f} us   p10 {d.quantile(0.1):7.2f}   p90 {d.quantile(0.9):7.2f}")
+print("  offsets from stamp 0 (median): " + ", ".join(f"{i}: {((s[:, i] - s[:, 0]).float() * tick_us).median():.2f}" for i in range(1, last + 1) if (s[:, i] > 0).any()))
 tot = (s[:, last] - s[:, 0]).float() * tick_us
 st = (s[:, 0] - t0).float() * tick_us
 print(f"  workgroup lifetime: median {tot.median():.2f} us (p10 {tot.quantile(0.1):.2f}, p90 {tot.quantile(0.9):.2f}); start times: "
