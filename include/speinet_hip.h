@@ -171,6 +171,26 @@ int spei_attn_fused16(int fmt, const float* x, float* out, const void* yhat, con
                       const void* wkv_frag, const float* bkv, const void* wproj_frag, const float* bproj,
                       const float* relbias, int H, int W, int shift, spei_stream_t stream);
 
+/* The same attention branch (model/swinir.py:238-278, :115-149) over a BATCH of equally sized maps that share the block's weights
+ * — the two Swin calls of a frame, model/speinet.py:84 — in one launch, four windows per 256-thread workgroup (round 4): every
+ * weight fragment fetched from L2 feeds four MFMAs instead of two, one 100-row token slab per workgroup (y-hat, then LayerNorm(x),
+ * then the attention output) so that two workgroups still share a CU.  x, out: [batch][H*W][256] fp32 (may alias), yhat
+ * [batch][H*W][256] `fmt`; weights, biases, relbias as spei_attn_fused16.  Per map the result differs from spei_attn_fused16 in
+ * fp32 rounding only (the residual enters the projection sum first instead of last). */
+int spei_attn_win4_16(int fmt, const float* x, float* out, const void* yhat, const void* wq_frag, const float* bq,
+                      const void* wkv_frag, const float* bkv, const void* wproj_frag, const float* bproj,
+                      const float* relbias, int batch, int H, int W, int shift, spei_stream_t stream);
+
+/* Harness post-processing of one deblurred frame (inference_SPEINet.py:477-482 tensor2numpy, :484-500 calc_PSNR, :502-543 calc_SSIM):
+ * out_chw [3][H][W] fp32 (the model's output, unclamped) -> out_hwc [H][W][3] uint8 = round(clamp(255 x, 0, 255)) (half to even), and
+ * result[0] = 1 if every value of out_chw was finite else 0, result[1] = PSNR, result[2] = SSIM of out_hwc against gt_hwc ([H][W][3]
+ * uint8) on the region cropped by `border` pixels on every side (the reference crops 4).  PSNR from the exact integer squared error
+ * (inf for identical frames); SSIM: 11x11 Gaussian window (sigma 1.5), valid region, float64 sums, mean over channels and positions.
+ * ws: spei_frame_post_ws_doubles(H, W, border) doubles (-1: the cropped frame is smaller than the window). */
+int64_t spei_frame_post_ws_doubles(int H, int W, int border);
+int spei_frame_post(const float* out_chw, const unsigned char* gt_hwc, unsigned char* out_hwc, int H, int W, int border,
+                    double* ws, double* result, spei_stream_t stream);
+
 /* One whole cross-window Swin block (model/swinir.py:238-281) in a single persistent launch: the attention branch of
  * spei_attn_fused16 followed by the MLP branch of spei_mlp_fused16 on the same rows, x read once and written once, the
  * intermediate x1 = x + proj(...) never leaves the registers; groups of three windows per 512-thread workgroup, one

@@ -34,6 +34,7 @@ SIGNATURES = {
     "spei_conv_slab16": (I, [I, P, I, I, P, I, I, I, P, P, P, P, I, I, P, I, P, I, I, I, I, I, I, I, I, I, I, P]),
     "spei_conv_slab16_fa": (I, [I, P, I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "spei_attn_fused16": (I, [I, P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
+    "spei_attn_win4_16": (I, [I, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "spei_swin_block16": (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
     "spei_conv5_out_slab16": (I, [I, P, I, I, P, P, P, I, I, P]),
     "spei_convt2_slab16": (I, [I, P, I, I, I, P, P, P, P, P, P, I, I, I, I, I, I, P]),
@@ -85,6 +86,8 @@ SIGNATURES = {
     "spei_search_bwd_ref": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "spei_upsample_bicubic_bwd": (I, [P, P, I, I, I, I, P]),
     "spei_rowdot": (I, [P, P, P, L, I, P]),
+    "spei_frame_post_ws_doubles": (L, [I, I, I]),
+    "spei_frame_post": (I, [P, P, P, I, I, I, P, P, P]),
     "spei_det_gray": (I, [P, P, I, I, I, P]),
     "spei_det_ws_floats": (L, [I, I, I, I]),
     "spei_det_features": (I, [P, P, P, I, I, I, I, P]),

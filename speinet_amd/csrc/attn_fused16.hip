@@ -19,6 +19,7 @@
 //      channels), + bias + residual (prefetched before the GEMM), 16-byte stores.
 // HBM traffic per block: x read (+ once more, mostly from L2, for the residual), y-hat read, x written.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -366,6 +367,396 @@ __global__ __launch_bounds__(256 * HV, HV == 1 ? 2 : 1) void attn_fused_kernel(c
     }
 }
 
+// ---- round 4: four windows per workgroup, one token slab, a batch of maps per launch -------------------------------------------------
+// `attn_fused_kernel` streams the block's 512 KB of weight fragments once per TWO windows, and a CU takes in only ~30 B/clk from L2: its
+// Q / K / V phase runs at the intake rate, not the matrix pipe's (stamps: 11.7 of a workgroup's 28.6 us; 1152 workgroups x 512 KB =
+// 590 MB of weight stream per call).  Here a 256-thread workgroup owns FOUR windows, so every fragment it fetches feeds four MFMAs
+// (256 B of intake per MFMA: the rate the pipe can take), and it still shares its CU with a second workgroup, because it keeps ONE
+// token slab of 100 unpadded rows (52.8 KB) instead of two padded ones:
+//   1. y-hat rows -> slab;  Q^T of the wave's two heads (weights as the A operand), kept as packed 16-bit MFMA operands (64 registers);
+//   2. x rows -> LayerNorm -> the SAME slab;  per head: K^T pass -> S^T = K Q^T -> softmax -> P^T packed;  V pass -> O^T = V^T P^T
+//      (accumulators feed the next MFMA as operands, as in attn_fused_kernel; Q, K, V passes are separate so that one 4-window
+//      accumulator set (64 registers) is live at a time);
+//   3. O -> the slab;  proj with accumulators that START from x + bias (the residual is loaded straight into them), 16-byte stores.
+// A window's 32-row MFMA tile reads the 7 rows that follow its 25 tokens from the next window (finite data; keys >= 25 are masked,
+// queries >= 25 are never stored), the last tile clamps to row 99.  Launch: gridDim.x = batch x ceil(windows / 4): the two Swin calls
+// of a frame (same weights, model/speinet.py:84) run as ONE launch over stacked maps — 1152 workgroups on 512 slots instead of
+// 2 x 576.
+constexpr int WPG = 4;                // windows per workgroup
+constexpr int TOK = WPG * NT;         // 100 slab rows
+
+// a value the compiler must treat as unknown until this point: keeps it from computing (and keeping alive through the whole kernel)
+// the per-lane addresses of every later phase's bias / relative-position loads right at the top (lessons)
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
+template <typename LP>
+struct Attn4Params {
+    const float* x;       // [batch][H*W][256]
+    float* out;
+    const LP* yhat;
+    const LP* wq; const float* bq; const LP* wkv; const float* bkv; const LP* wproj; const float* bproj; const float* relbias;
+    long long* stamps;
+    int H, W, shift, nwin, groups, batch;     // nwin: windows per map; groups = ceil(nwin / 4)
+};
+
+// Eight waves, one head each (two waves per SIMD), one workgroup per CU.  A first version with four waves (two heads each, two
+// workgroups per CU) needed 276 registers for the Q^T / O^T it carries across the slab's re-use and ran 168 us for two 720p maps; this
+// one needs 224 with eight weight fragments in flight per wave: 158 us, and 137 us with the loads of a phase issued one phase early.
+template <typename LP>
+__global__ __launch_bounds__(512, 2) void attn_win4_kernel(const Attn4Params<LP> p) {
+    typedef typename lpv<LP>::x8 lp8;
+    typedef typename lpv<LP>::x4 lp4;
+    constexpr int TPP = 32;                           // tokens per staging pass (16 lanes per token, 512 threads)
+    constexpr int NPASS = (TOK + TPP - 1) / TPP;      // 4
+    constexpr int RQ = 8;                             // weight fragments in flight per wave, Q / K / V passes
+    constexpr int RP = 6;                             // ... projection
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* slab = smem;                                           // [100][PA]: y-hat, then LN(x), then the attention output
+    int* tok_pix = reinterpret_cast<int*>(smem + TOK * PA);               // [100] pixel index within the map, or -1
+    int* tok_reg = tok_pix + TOK;                                         // [100] shift-mask region id
+    float* sbias = reinterpret_cast<float*>(tok_reg + TOK);               // [1024] bq | bk | bv | bproj
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fk = lane >> 5;
+    const int nwx = p.W / WS;
+    const int bmap = blockIdx.x / p.groups, grp = blockIdx.x - bmap * p.groups;
+    const size_t moff = (size_t)bmap * p.H * p.W * D;
+    const float* xg = p.x + moff;
+    float* og = p.out + moff;
+    const LP* yg = p.yhat + moff;
+
+    SPEI_STAMP(p.stamps, 0);
+    if (tid < TOK) {
+        const int wd = tid / NT, t = tid - wd * NT;
+        const int win = grp * WPG + wd;
+        int pix = -1, reg = 0;
+        if (win < p.nwin) {
+            const int wy = win / nwx, wx = win - wy * nwx;
+            const int ysf = wy * WS + t / WS, xsf = wx * WS + t % WS;      // shifted-frame coordinates
+            int yo = ysf + p.shift, xo = xsf + p.shift;                    // roll(-shift): shifted[y] = x[(y+shift) % H]
+            if (yo >= p.H) yo -= p.H;
+            if (xo >= p.W) xo -= p.W;
+            pix = yo * p.W + xo;
+            reg = p.shift > 0 ? 3 * mask_region(ysf, p.H, p.shift) + mask_region(xsf, p.W, p.shift) : 0;
+        }
+        tok_pix[tid] = pix;
+        tok_reg[tid] = reg;
+    }
+    // biases -> LDS: an accumulator's 16 bias values then come from 4 ds_read_b128 at the top of a pass instead of 16 dependent
+    // global loads (one exposed L2 round trip per pass)
+    sbias[tid] = tid < D ? p.bq[tid] : p.bkv[tid - D];
+    sbias[512 + tid] = tid < D ? p.bkv[D + tid] : p.bproj[tid - D];
+    lds_barrier();
+
+    const int l16 = tid & 15, rsub = tid >> 4;        // staging: 16 lanes per token, 32 tokens per pass
+    // Per-workgroup K rotation (spreads the L2 channel load of the weight stream; by group within the map, so that a map's result does
+    // not depend on its place in the batch): GEMM step i contracts k-step (rot + i) & 15.  The slab rows are STORED rotated by the same
+    // amount, so step i reads byte offset 32 i of a row — an immediate of the ds_read.  With the rotation in the read address instead,
+    // the 64 (window, step) addresses are common to all passes and the compiler keeps them in registers from the first pass to
+    // the last (64 VGPRs).
+    const int rot = grp & 15, rotb = rot * 32;
+    // ---- 1a. ALL of the workgroup's token loads are issued here: y-hat (consumed now) and x (consumed after the Q pass: its HBM round
+    // trip runs under the Q pass instead of after it; 64 registers that the Q pass can spare) -------------------------------------------
+    f32x4 xr[NPASS][4];
+    {
+        u32x4 yr[NPASS][2];
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int r = min(ps * TPP + rsub, TOK - 1);
+            const int pix = max(tok_pix[r], 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) yr[ps][j] = reinterpret_cast<const u32x4*>(yg + (size_t)pix * D)[l16 + 16 * j];
+        }
+        __builtin_amdgcn_sched_barrier(0);            // y first, then x: a y load sunk behind the x loads makes its vmcnt wait drain them all
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int r = min(ps * TPP + rsub, TOK - 1);
+            const int pix = max(tok_pix[r], 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xr[ps][j] = reinterpret_cast<const f32x4*>(xg + (size_t)pix * D)[l16 + 16 * j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int r = ps * TPP + rsub;
+            if (r < TOK) {
+                const bool ok = tok_pix[r] >= 0;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    *reinterpret_cast<u32x4*>(slab + r * PA + (((l16 + 16 * j) * 16 - rotb) & 511)) = ok ? yr[ps][j] : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+    }
+    lds_barrier();
+    SPEI_STAMP(p.stamps, 1);
+
+    // slab row of (window wd, tile row fr): the 7 rows past a window's 25 tokens are the next window's first tokens; clamp at the end
+    int rowoff[WPG];
+#pragma unroll
+    for (int wd = 0; wd < WPG; ++wd) rowoff[wd] = min(wd * NT + fr, TOK - 1) * PA + fk * 16;
+    const int h = wave;                               // the wave's head
+
+    // One pass of the wave's 4 windows over K = 256: 16 weight fragments from L2 (RQ in flight), token fragments from the slab one step
+    // ahead, 4 MFMAs per step; TOKENS_ON_COLUMNS: weights as the A operand (Q^T, K^T), else tokens as A (V).  Pinned with full
+    // scheduling barriers (left alone the scheduler sinks every load to right before its use).
+    auto pass = [&](const LP* wp, f32x16 (&acc)[WPG], auto tokens_on_columns) {
+        lp8 ring[RQ];
+#pragma unroll
+        for (int d = 0; d < RQ; ++d) ring[d] = *reinterpret_cast<const lp8*>(wp + ((rot + d) & 15) * 512);
+        lp8 tn[WPG];
+#pragma unroll
+        for (int wd = 0; wd < WPG; ++wd) tn[wd] = *reinterpret_cast<const lp8*>(slab + rowoff[wd]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            lp8 tc[WPG];
+#pragma unroll
+            for (int wd = 0; wd < WPG; ++wd) tc[wd] = tn[wd];
+            if (i + 1 < 16) {
+#pragma unroll
+                for (int wd = 0; wd < WPG; ++wd) tn[wd] = *reinterpret_cast<const lp8*>(slab + rowoff[wd] + (i + 1) * 32);
+            }
+            const lp8 wc = ring[i % RQ];
+            if (i + RQ < 16) ring[i % RQ] = *reinterpret_cast<const lp8*>(wp + ((rot + i + RQ) & 15) * 512);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int wd = 0; wd < WPG; ++wd) {
+                if constexpr (decltype(tokens_on_columns)::value) acc[wd] = mfma16(wc, tc[wd], acc[wd]);
+                else acc[wd] = mfma16(tc[wd], wc, acc[wd]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // accumulator rows d = 8 g + 4 fk + e of a head <- bias[h * 32 + d]   (Q^T, K^T: head dim on the rows)
+    auto init_rows = [&](f32x16 (&acc)[WPG], const float* b) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(b + h * HD + 8 * g + 4 * fk);
+#pragma unroll
+            for (int wd = 0; wd < WPG; ++wd)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[wd][4 * g + e] = bv[e];
+        }
+    };
+
+    // ---- 1b. Q^T of the wave's head, kept as packed MFMA operands ------------------------------------------------------------------------
+    lp8 qp[WPG][2];
+    {
+        f32x16 acc[WPG];
+        init_rows(acc, sbias);
+        pass(p.wq + (size_t)h * 16 * 512 + lane * 8, acc, std::true_type{});
+#pragma unroll
+        for (int wd = 0; wd < WPG; ++wd) {
+            qp[wd][0] = cvt8<0, LP>(acc[wd]);
+            qp[wd][1] = cvt8<1, LP>(acc[wd]);
+        }
+    }
+    // relative-position bias of (query = lane column, key = register row): fetched here, used after the K pass
+    float rb[16];
+    {
+        const int qi = fr < NT ? fr : 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = (r & 3) + 8 * (r >> 2) + 4 * fk;
+            rb[r] = p.relbias[(h * NT + qi) * NT + min(key, NT - 1)];
+        }
+    }
+    lds_barrier();                                  // every wave is done with the y rows
+    SPEI_STAMP(p.stamps, 2);
+
+    // ---- 2a. LayerNorm(x) (loaded at the top) -> the same slab ------------------------------------------------------------------------------
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int r = ps * TPP + rsub;
+        const bool ok = r < TOK && tok_pix[min(r, TOK - 1)] >= 0;
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sm += (xr[ps][j][0] + xr[ps][j][1]) + (xr[ps][j][2] + xr[ps][j][3]);
+        const float mean = sum16(sm) * (1.0f / 256.0f);
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xr[ps][j] -= mean;
+            ss += (xr[ps][j][0] * xr[ps][j][0] + xr[ps][j][1] * xr[ps][j][1]) + (xr[ps][j][2] * xr[ps][j][2] + xr[ps][j][3] * xr[ps][j][3]);
+        }
+        const float rstd = ok ? 1.0f / sqrtf(sum16(ss) * (1.0f / 256.0f) + 1e-5f) : 0.f;     // empty rows stage zeros
+        if (r < TOK) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lp4 hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hv[e] = to_lp<LP>(xr[ps][j][e] * rstd);
+                *reinterpret_cast<lp4*>(slab + r * PA + (((l16 + 16 * j) * 8 - rotb) & 511)) = hv;
+            }
+        }
+    }
+    // shift mask: bit r of mbits[wd] = key (register row r) lies in another region than the lane's query
+    unsigned mbits[WPG];
+#pragma unroll
+    for (int wd = 0; wd < WPG; ++wd) {
+        mbits[wd] = 0u;
+        if (p.shift > 0) {
+            const int qreg = tok_reg[wd * NT + (fr < NT ? fr : 0)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (tok_reg[wd * NT + min(key, NT - 1)] != qreg) mbits[wd] |= 1u << r;
+            }
+        }
+    }
+    lds_barrier();
+    SPEI_STAMP(p.stamps, 3);
+
+    // ---- 2b. K^T -> S^T -> softmax;  V -> O^T ------------------------------------------------------------------------------------------------
+    lp4 opk[WPG][4];                                  // O^T packed: [window][4 d-groups], written to the slab after the barrier
+    {
+        lp8 pp[WPG][2];                               // P^T packed
+        {
+            f32x16 acc[WPG];
+            init_rows(acc, sbias + D);
+            pass(p.wkv + (size_t)h * 16 * 512 + lane * 8, acc, std::true_type{});
+#pragma unroll
+            for (int wd = 0; wd < WPG; ++wd) {
+                f32x16 st;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[r] = 0.f;
+                // S^T[key][query] = sum_d K^T[d][key] Q^T[d][query]:  A = (K^T)^T from the accumulator, B = Q^T (packed)
+                st = mfma16(cvt8<0, LP>(acc[wd]), qp[wd][0], st);
+                st = mfma16(cvt8<1, LP>(acc[wd]), qp[wd][1], st);
+                float mx = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    float v = -INFINITY;
+                    if (key < NT) {
+                        v = st[r] + rb[r];
+                        if (mbits[wd] >> r & 1) v += -100.0f;
+                    }
+                    st[r] = v;
+                    mx = fmaxf(mx, v);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __expf(st[r] - mx);
+                    st[r] = e;
+                    sum += e;
+                }
+                sum += __shfl_xor(sum, 32, 64);
+                const float inv = 1.0f / sum;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[r] *= inv;
+                pp[wd][0] = cvt8<0, LP>(st);
+                pp[wd][1] = cvt8<1, LP>(st);
+            }
+        }
+        SPEI_STAMP(p.stamps, 4);
+        {
+            f32x16 acc[WPG];                          // V[token][d]: tokens on the accumulator rows, head dim on the columns
+            const float bv = sbias[512 + h * HD + fr];
+#pragma unroll
+            for (int wd = 0; wd < WPG; ++wd)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[wd][r] = bv;
+            pass(p.wkv + (size_t)(8 + h) * 16 * 512 + lane * 8, acc, std::false_type{});
+#pragma unroll
+            for (int wd = 0; wd < WPG; ++wd) {
+                // O^T[d][query] = sum_key V[key][d] P^T[key][query]:  A = V^T from the accumulator (X^T.B form), B = P^T (packed)
+                f32x16 ot;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[r] = 0.f;
+                ot = mfma16(cvt8<0, LP>(acc[wd]), pp[wd][0], ot);
+                ot = mfma16(cvt8<1, LP>(acc[wd]), pp[wd][1], ot);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) opk[wd][g][e] = to_lp<LP>(ot[4 * g + e]);
+            }
+        }
+        SPEI_STAMP(p.stamps, 5);
+    }
+    // ---- 3. proj: the wave's 32 output channels of the 100 rows (4 row tiles, the last one clamped); acc starts from x + bias.  The
+    // residual rows and the first projection fragments are requested BEFORE the barrier that ends the attention phase -----------------------
+    const int et = fr & 3, ecol = (fr >> 2) * 4;
+    f32x4 rv[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = i * 32 + 8 * k + 4 * fk + et;
+            const int pix = max(tok_pix[min(r, TOK - 1)], 0);
+            rv[i][k] = *reinterpret_cast<const f32x4*>(xg + (size_t)pix * D + wave * HD + ecol);
+        }
+    const int rot4 = (grp * 3) & 15;                  // the projection's own rotation; the attention output is stored rotated by it
+    const LP* wpp = p.wproj + (size_t)wave * 16 * 512 + lane * 8;
+    lp8 wf[RP];
+#pragma unroll
+    for (int d = 0; d < RP; ++d) wf[d] = *reinterpret_cast<const lp8*>(wpp + ((rot4 + d) & 15) * 512);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();                                  // every wave is done reading the x rows
+    // rows d = 8 g + 4 fk + e of head h, column = query token fr (< 25)  ->  slab[wd * 25 + fr][h * 32 + d]
+    if (fr < NT) {
+#pragma unroll
+        for (int wd = 0; wd < WPG; ++wd)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<lp4*>(slab + (wd * NT + fr) * PA + (((h * HD + 8 * g + 4 * fk) * 2 - rot4 * 32) & 511)) = opk[wd][g];
+    }
+    {
+        f32x16 acc[4];
+        const float bias = sbias[768 + wave * HD + fr];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float a[4] = {rv[i][k][0], rv[i][k][1], rv[i][k][2], rv[i][k][3]};
+                quad_transpose4(a[0], a[1], a[2], a[3], et);              // row chunks -> accumulator layout
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][4 * k + e] = a[e] + bias;
+            }
+        lds_barrier();                              // the attention output is in the slab
+        SPEI_STAMP(p.stamps, 8);
+        int aoff[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aoff[i] = min(i * 32 + fr, TOK - 1) * PA + fk * 16;
+        lp8 an[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) an[i] = *reinterpret_cast<const lp8*>(slab + aoff[i]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            lp8 ac[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ac[i] = an[i];
+            if (s + 1 < 16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) an[i] = *reinterpret_cast<const lp8*>(slab + aoff[i] + (s + 1) * 32);
+            }
+            const lp8 wc = wf[s % RP];
+            if (s + RP < 16) wf[s % RP] = *reinterpret_cast<const lp8*>(wpp + ((rot4 + s + RP) & 15) * 512);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = mfma16(ac[i], wc, acc[i]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        SPEI_STAMP(p.stamps, 9);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float a[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = acc[i][4 * k + e];
+                quad_transpose4(a[0], a[1], a[2], a[3], et);
+                const int r = i * 32 + 8 * k + 4 * fk + et;
+                const int pix = r < TOK ? tok_pix[r] : -1;
+                if (pix >= 0) *reinterpret_cast<f32x4*>(og + (size_t)pix * D + wave * HD + ecol) = f32x4{a[0], a[1], a[2], a[3]};
+            }
+        SPEI_STAMP(p.stamps, 10);
+    }
+}
+
 }  // namespace
 
 template <typename LP>
@@ -387,6 +778,36 @@ static int attn_launch(const float* x, float* out, const void* yhat, const void*
     }
     SPEI_CHECK_LAUNCH("spei_attn_fused16");
     return 0;
+}
+
+template <typename LP>
+static int attn4_launch(const float* x, float* out, const void* yhat, const void* wq, const float* bq, const void* wkv, const float* bkv,
+                        const void* wproj, const float* bproj, const float* relbias, int batch, int H, int W, int shift, hipStream_t st) {
+    Attn4Params<LP> p;
+    p.x = x; p.out = out; p.yhat = (const LP*)yhat; p.wq = (const LP*)wq; p.bq = bq; p.wkv = (const LP*)wkv;
+    p.bkv = bkv; p.wproj = (const LP*)wproj; p.bproj = bproj; p.relbias = relbias;
+    p.H = H; p.W = W; p.shift = shift; p.nwin = (H / WS) * (W / WS); p.groups = (p.nwin + WPG - 1) / WPG; p.batch = batch;
+    p.stamps = spei_stamp_buffer();
+    const size_t lds = (size_t)TOK * PA + 2 * TOK * sizeof(int) + 1024 * sizeof(float);
+    ensure_dyn_lds<&attn_win4_kernel<LP>>(lds);
+    hipLaunchKernelGGL((attn_win4_kernel<LP>), dim3(p.groups * batch), dim3(512), lds, st, p);
+    SPEI_CHECK_LAUNCH("spei_attn_win4_16");
+    return 0;
+}
+
+extern "C" int spei_attn_win4_16(int fmt, const float* x, float* out, const void* yhat, const void* wq_frag, const float* bq,
+                                 const void* wkv_frag, const float* bkv, const void* wproj_frag, const float* bproj,
+                                 const float* relbias, int batch, int H, int W, int shift, spei_stream_t stream) {
+    SPEI_REQUIRE(x && out && yhat && wq_frag && bq && wkv_frag && bkv && wproj_frag && bproj && relbias, "spei_attn_win4_16: null pointer");
+    SPEI_REQUIRE(fmt == SPEI_BF16 || fmt == SPEI_F16, "spei_attn_win4_16: fmt=%d", fmt);
+    SPEI_REQUIRE(H > 0 && W > 0 && H % WS == 0 && W % WS == 0, "spei_attn_win4_16: %dx%d is not a multiple of the 5x5 window", H, W);
+    SPEI_REQUIRE(shift >= 0 && shift < WS, "spei_attn_win4_16: shift=%d", shift);
+    SPEI_REQUIRE(batch >= 1 && (int64_t)batch * H * W < (1ll << 30), "spei_attn_win4_16: batch=%d of %dx%d", batch, H, W);
+    SPEI_REQUIRE(((uintptr_t)x | (uintptr_t)out | (uintptr_t)yhat | (uintptr_t)wq_frag | (uintptr_t)wkv_frag | (uintptr_t)wproj_frag) % 16 == 0,
+                 "spei_attn_win4_16: 16-byte alignment required");
+    hipStream_t st = (hipStream_t)stream;
+    if (fmt == SPEI_F16) return attn4_launch<_Float16>(x, out, yhat, wq_frag, bq, wkv_frag, bkv, wproj_frag, bproj, relbias, batch, H, W, shift, st);
+    return attn4_launch<__bf16>(x, out, yhat, wq_frag, bq, wkv_frag, bkv, wproj_frag, bproj, relbias, batch, H, W, shift, st);
 }
 
 extern "C" int spei_attn_fused16(int fmt, const float* x, float* out, const void* yhat, const void* wq_frag, const float* bq,

@@ -103,6 +103,12 @@ __device__ __forceinline__ float wave_allreduce(float v) {
 __device__ __forceinline__ float wave_sum(float v) { return wave_allreduce<OpSum>(v); }
 __device__ __forceinline__ float wave_max(float v) { return wave_allreduce<OpMax>(v); }
 
+// Workgroup barrier that orders LDS traffic only: waits for this wave's LDS operations (lgkmcnt), NOT for its global loads.
+// __syncthreads() carries a workgroup-scope fence, and on gfx950 (one vmcnt for loads and stores) that drains every global load
+// the wave has in flight before it reaches the barrier: nothing can be prefetched across it (stamps, round 4: a phase whose loads
+// were issued one barrier early was no shorter).  Use where the waves exchange data through LDS only.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -135,6 +135,43 @@ def swin(ctx: Ctx, sx: SwinX, feat: FMap, sw: dict, out: FMap) -> FMap:
     return ctx.igemm(res, sw["conv_last_w"], sw["conv_last_b"], 128, ksize=3, residual=sx.f_mid, out=out)
 
 
+def swin_multi(ctx: Ctx, sx: SwinX, feats: BMap, sw: dict, outs: list) -> None:
+    """Every Swin call of a frame — `self.swin(f_mid, features)` once per neighbour frame, model/speinet.py:84: the same weights, the
+    same x-side input, one y per call — as ONE batch: `feats` holds the calls' y maps stacked ([B*H*W, 128]), every kernel of the 36
+    blocks runs once over the stacked token maps (the attention kernel per map inside one launch, the MLP / LayerNorm row-wise, the
+    3x3 convolutions with gridDim.y = map).  Round 3 ran the calls side by side on two streams: every launch then filled the chip
+    with ITS OWN workgroups and the pair gained little (9.7 ms for 10.2 ms of kernels); batched, a launch has twice the workgroups
+    (4.5 rounds of the four-window attention kernel instead of 2.25) and the frame half the launches.  outs[b]: where call b's
+    [H*W, 128] result goes (views of the `fusion` input)."""
+    ctx = ctx.for_stage("swin")
+    B, h, w = feats.B, feats.H, feats.W
+    m = h * w
+    dev = feats.t.device
+    y_first = ctx.igemm_batched(feats, sw["conv_first_w"], sw["conv_first_b"], 256, 3)
+    yt = ctx.layernorm(y_first.t, sw["pe_g"], sw["pe_b"])
+    idt = ctx.inter_dtype()
+    yhat = ctx.layernorm(yt, out_dtype=idt)       # norm1(y) without affine; gamma/beta live in wq/bq (pack.py)
+    del y_first, yt
+    r = sx.xt0.repeat(B, 1)                       # RSTB input / running residual, per call
+    bufs = [torch.empty(B * m, 256, device=dev), torch.empty(B * m, 256, device=dev)]
+    for layer in sw["layers"]:
+        cur = r
+        for bi, bk in enumerate(layer["blocks"]):
+            shift = 0 if bi % 2 == 0 else 2
+            nxt = bufs[bi % 2]
+            ctx.attn_fused(cur, yhat, bk, h, w, shift, out=nxt)
+            ctx.mlp_fused(nxt, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out=nxt)
+            cur = nxt
+        # RSTB: conv3x3(blocks(x)) + x   (swinir.py:483-484), in place on the residual buffer
+        rb = BMap(r, B, h, w, 256)
+        ctx.igemm_batched(BMap(cur, B, h, w, 256), layer["conv_w"], layer["conv_b"], 256, 3, residual=rb, out=rb)
+    xt = ctx.layernorm(r, sw["norm_g"], sw["norm_b"])
+    x_first = BMap(sx.x_first.t.repeat(B, 1), B, h, w, 256)
+    res = ctx.igemm_batched(BMap(xt, B, h, w, 256), sw["cab_w"], sw["cab_b"], 256, 3, residual=x_first)
+    for b in range(B):                            # strided outputs (slices of the 384-channel fusion input): one launch per call
+        ctx.igemm(res.map(b), sw["conv_last_w"], sw["conv_last_b"], 128, ksize=3, residual=sx.f_mid, out=outs[b])
+
+
 # ---- SearchTransfer / SelfTransfer (reference model/SearchTransfer.py) ---------------------------------
 # Each is split around the correlation arg-max kernel (the dominant kernel of the path): `*_plan` prepares it, the caller
 # launches `plan` (engine._tail does; bench.py places that launch between two captured graph segments to time it live with
@@ -263,10 +300,23 @@ def forward_sample_steps(ctx: Ctx, x: torch.Tensor, P: dict, n_seq: int, has_ref
     mid = x[n_seq // 2]
     e0 = enc(ctx, mid, P)
     f_mid = enc(ctx, ctx.rl_prior(mid, 5, 0.01), P, extra=e0, out=cat.view(0, 128))
+    others = [i for i in range(n_seq) if i != n_seq // 2]
+    if ctx.for_stage("swin").swin_multi_available():
+        # the neighbour frames' encoder passes on the lanes, then ALL their swin calls as one batch (swin_multi)
+        fb = BMap.empty(len(others), h3, w3, 128, dev)
+        for k, i in enumerate(others):
+            with torch.cuda.stream(lanes[k % len(lanes)]):
+                e = enc(ctx, x[i], P)
+                enc(ctx, ctx.rl_prior(x[i], 1, 0.01), P, extra=e, out=fb.map(k))
+                del e
+        for s_ in lanes[1:]:
+            main.wait_stream(s_)                  # join
+        yield from _fuse_tail(ctx, f_mid, fb, cat, lv, P, out, lanes)
+        return
     sx = SwinX(ctx, f_mid, P["swin"])
     ready = torch.cuda.Event()
     ready.record(main)
-    for slot, i in enumerate([i for i in range(n_seq) if i != n_seq // 2], start=1):
+    for slot, i in enumerate(others, start=1):
         lane = lanes[(slot - 1) % len(lanes)]
         with torch.cuda.stream(lane):
             e = enc(ctx, x[i], P)                      # the neighbour frame's own passes need nothing from the middle frame:
@@ -318,22 +368,34 @@ def forward_batch_steps(ctx: Ctx, x: torch.Tensor, P: dict, n_seq: int, zero_ref
             cat = FMap(torch.empty(h3 * w3, 128 * n_seq, device=dev), h3, w3, 128 * n_seq)
             f_mid = FMap(ctx.add(lv3.map(m0 + 1).t, lv3.map(m0).t), h3, w3, 128)            # enc(RL5(mid)) + enc(mid)   (speinet.py:130-132)
             cat.t[:, :128].copy_(f_mid.t)
-            feats = [FMap(ctx.add(lv3.map(m0 + 3 + 2 * k).t, lv3.map(m0 + 2 + 2 * k).t), h3, w3, 128) for k in range(len(others))]
+            fb = BMap.empty(len(others), h3, w3, 128, dev)                                   # enc(RL1(x_i)) + enc(x_i), the calls' y maps stacked
+            for k in range(len(others)):
+                ctx.add(lv3.map(m0 + 3 + 2 * k).t, lv3.map(m0 + 2 + 2 * k).t, out=fb.map(k).t)
             mr = m0 + 2 + 2 * len(others)
             lv = None if zero_ref[b] else (lv1.map(mr), lv2.map(mr), lv3.map(mr))
-            sx = SwinX(ctx, f_mid, P["swin"])
-            ready = torch.cuda.Event()
-            ready.record(main)
-            for slot, feat in enumerate(feats, start=1):
-                lane = lanes[(slot - 1) % len(lanes)]
-                if lane is not main:
-                    lane.wait_event(ready)
-                with torch.cuda.stream(lane):
-                    swin(ctx, sx, feat, P["swin"], out=cat.view(128 * slot, 128))
-            for s_ in lanes[1:]:
-                main.wait_stream(s_)                  # join
-            yield from _tail(ctx, cat, lv, P, out[b])
+            yield from _fuse_tail(ctx, f_mid, fb, cat, lv, P, out[b], lanes)
         b0 += len(group)
+
+
+def _fuse_tail(ctx: Ctx, f_mid: FMap, fb: BMap, cat: FMap, lv, P: dict, out: torch.Tensor, lanes: list):
+    """The neighbour-frame fusions into `cat` (its first 128 channels already hold f_mid), then `_tail`.  One batched pass over the
+    stacked y maps where the mode has the batched kernels (swin_multi), else one swin call per neighbour frame on the side lanes."""
+    main = lanes[0]
+    sx = SwinX(ctx, f_mid, P["swin"])
+    if ctx.for_stage("swin").swin_multi_available():
+        swin_multi(ctx, sx, fb, P["swin"], [cat.view(128 * slot, 128) for slot in range(1, fb.B + 1)])
+    else:
+        ready = torch.cuda.Event()
+        ready.record(main)
+        for slot in range(1, fb.B + 1):
+            lane = lanes[(slot - 1) % len(lanes)]
+            if lane is not main:
+                lane.wait_event(ready)
+            with torch.cuda.stream(lane):
+                swin(ctx, sx, fb.map(slot - 1), P["swin"], out=cat.view(128 * slot, 128))
+        for s_ in lanes[1:]:
+            main.wait_stream(s_)                  # join
+    yield from _tail(ctx, cat, lv, P, out)
 
 
 def _tail(ctx: Ctx, cat: FMap, lv, P: dict, out: torch.Tensor):
@@ -382,18 +444,8 @@ def fuse_and_decode_steps(ctx: Ctx, f_mid: FMap, feats: list, lv, P: dict, n_seq
     main = lanes[0]
     cat = FMap(torch.empty(h3 * w3, 128 * n_seq, device=dev), h3, w3, 128 * n_seq)
     cat.t[:, :128].copy_(f_mid.t)
-    sx = SwinX(ctx, f_mid, P["swin"])
-    ready = torch.cuda.Event()
-    ready.record(main)
-    for slot, feat in enumerate(feats, start=1):
-        lane = lanes[(slot - 1) % len(lanes)]
-        if lane is not main:
-            lane.wait_event(ready)
-        with torch.cuda.stream(lane):
-            swin(ctx, sx, feat, P["swin"], out=cat.view(128 * slot, 128))
-    for s_ in lanes[1:]:
-        main.wait_stream(s_)
-    yield from _tail(ctx, cat, lv, P, out)
+    fb = BMap(torch.cat([f.t for f in feats]), len(feats), h3, w3, 128)
+    yield from _fuse_tail(ctx, f_mid, fb, cat, lv, P, out, lanes)
 
 
 # ---- the `swint` variant (reference model/swint.py:51-67) ---------------------------------------------------------------------

@@ -24,7 +24,7 @@ from concurrent.futures import Future, ThreadPoolExecutor
 import numpy as np
 import torch
 
-from . import checkpoint, detector, selection
+from . import checkpoint, detector, ops, selection
 from .dist import gather_metrics, shard_clips_by_length
 from .speinet import EncoderCache, SPEINet, default_args
 
@@ -340,13 +340,13 @@ class Inference:
                         out = self.net.forward_window(x, keys, enc_cache, zero_ref=bool(w["zero_pre"]))
                     else:
                         out = self.net(x, routing=[bool(w["zero_pre"])])
-                    finite = torch.isfinite(out).all()               # checked by the worker: half operands do not saturate (ops.py)
-                    out_u8 = out.mul(255.0).clamp(0, 255).round()[0].to(torch.uint8).permute(1, 2, 0).contiguous()   # = tensor2numpy, on the GPU
-                    gt_u8 = gt[:nh, :nw]
-                    psnr, ssim = metrics_gpu(out_u8[4:-4, 4:-4], gt_u8[4:-4, 4:-4])     # border crop: inference_SPEINet.py:405-410
+                    # tensor2numpy, the finite check (half operands do not saturate: the worker looks at it), PSNR and SSIM on the
+                    # 4-pixel-cropped frame (inference_SPEINet.py:405-410): three HIP launches (csrc/metrics.hip)
+                    gt_u8 = gt[:nh, :nw].contiguous()
+                    out_u8, met = ops.frame_post(out[0], gt_u8, 4)
                     slot = self._result_slot(out_u8.shape)
                     slot["out"].copy_(out_u8, non_blocking=True)
-                    slot["met"].copy_(torch.stack([finite.to(torch.float64), psnr, ssim]), non_blocking=True)
+                    slot["met"].copy_(met, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record()
                     inflight.append(ev)

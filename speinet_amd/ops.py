@@ -127,6 +127,28 @@ class _timed:
         return False
 
 
+def frame_post(out_chw: torch.Tensor, gt_hwc: torch.Tensor, border: int = 4):
+    """Harness post-processing of one frame on the device (csrc/metrics.hip; reference inference_SPEINet.py:477-543): out_chw [3,H,W]
+    fp32 -> (uint8 [H,W,3] frame, float64 [finite, PSNR, SSIM] against gt_hwc on the border-cropped region), three launches on the
+    current stream of the tensors' device, no host sync."""
+    assert out_chw.is_cuda and out_chw.dtype == torch.float32 and out_chw.dim() == 3 and out_chw.shape[0] == 3 and out_chw.is_contiguous()
+    h, w = out_chw.shape[1:]
+    assert gt_hwc.shape == (h, w, 3) and gt_hwc.dtype == torch.uint8 and gt_hwc.device == out_chw.device and gt_hwc.is_contiguous()
+    lib = _lib.lib()
+    n = lib.spei_frame_post_ws_doubles(h, w, border)
+    if n < 0:
+        raise ValueError(f"frame {w}x{h} with border {border} is smaller than the 11x11 SSIM window")
+    dev = out_chw.device
+    u8 = torch.empty(h, w, 3, dtype=torch.uint8, device=dev)
+    ws = torch.empty(n, dtype=torch.float64, device=dev)
+    res = torch.empty(3, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.spei_frame_post(_vp(out_chw.data_ptr()), _vp(gt_hwc.data_ptr()), _vp(u8.data_ptr()), h, w, border, _vp(ws.data_ptr()),
+                                       _vp(res.data_ptr()), st), "spei_frame_post")
+    return u8, res
+
+
 class CorrPlan:
     """A prepared K11 launch (see Ctx.corr_plan): `launch()` runs the arg-max kernel — bracketed by the profile events — and
     whatever must follow it on the same stream (the exact re-score of the "top2" form)."""
@@ -181,6 +203,8 @@ class Ctx:
                       (three resident rounds instead of half of one).  Off: round 2's per-pass launches on two streams
       mlp_ws          (default OFF) 16-bit, with fuse_mlp: the fused MLP branch as a two-role pipeline (spei_mlp_ws16: fc1 + GELU producers
                       and fc2 consumers sharing each SIMD).  Correct and tested; first measurement 66 vs 61.5 us per call at 720p
+      attn_win4       16-bit, with fuse_attn: the fused attention branch with four windows per workgroup and a batch of maps per launch
+                      (spei_attn_win4_16).  Off: round 2's two-window kernel, one map per launch (spei_attn_fused16)
       corr_bf16       "f16" with corr "top2": the candidate pass of the correlation runs on bf16 operands (True, default) instead of
                       f16.  The fp32 re-score decides the winner and S either way (G14: 16 more of 57600 positions differ, dPSNR
                       +1e-6 dB); bf16 operands let the chip hold a ~7 % higher MFMA clock on the slab kernel (tools/bench_corr.py); on the diagonal
@@ -197,7 +221,7 @@ class Ctx:
     ACT_NONE, ACT_RELU, ACT_GELU = ACT_NONE, ACT_RELU, ACT_GELU
     CONV, CONV_T = CONV, CONV_T
     _FIELDS = ("precision", "corr_precision", "device", "use_slab", "bf16_storage", "x1_bf16", "fuse_mlp", "fuse_attn",
-               "fuse_block", "commute_upconv", "commute_any", "corr_bf16", "corr_diag", "fuse_apply", "split_decode", "batch_enc", "mlp_ws", "stage", "profile", "capture")
+               "fuse_block", "commute_upconv", "commute_any", "corr_bf16", "corr_diag", "fuse_apply", "split_decode", "batch_enc", "mlp_ws", "attn_win4", "stage", "profile", "capture")
     # stages of an f16 frame that run in split (bf16x3) arithmetic by default, see `split_decode`
     SPLIT_STAGES = ("glue", "glue1", "dec2")
     __slots__ = _FIELDS
@@ -206,7 +230,7 @@ class Ctx:
                  bf16_storage: bool = True, x1_bf16: bool = True, fuse_mlp: bool = True, fuse_attn: bool = True,
                  fuse_block: bool = False, commute_upconv: bool = True, commute_any: bool = False, corr_bf16: bool = True,
                  corr_diag: bool = True, fuse_apply: bool = False, split_decode: bool = True, batch_enc: bool = True, mlp_ws: bool = False,
-                 stage: Optional[dict] = None,
+                 attn_win4: bool = True, stage: Optional[dict] = None,
                  profile: Optional[dict] = None, capture: Optional[dict] = None):
         if precision not in PRECISIONS:
             raise ValueError(f"unknown precision {precision!r}")
@@ -226,7 +250,7 @@ class Ctx:
         object.__setattr__(self, "device", device)
         for k, v in (("use_slab", use_slab), ("bf16_storage", bf16_storage), ("x1_bf16", x1_bf16), ("fuse_mlp", fuse_mlp),
                      ("fuse_attn", fuse_attn), ("fuse_block", fuse_block), ("commute_upconv", commute_upconv), ("commute_any", commute_any),
-                     ("corr_bf16", corr_bf16), ("corr_diag", corr_diag), ("fuse_apply", fuse_apply), ("split_decode", split_decode), ("batch_enc", batch_enc), ("mlp_ws", mlp_ws)):
+                     ("corr_bf16", corr_bf16), ("corr_diag", corr_diag), ("fuse_apply", fuse_apply), ("split_decode", split_decode), ("batch_enc", batch_enc), ("mlp_ws", mlp_ws), ("attn_win4", attn_win4)):
             object.__setattr__(self, k, bool(v))
         object.__setattr__(self, "stage", dict(stage) if stage else {})
         object.__setattr__(self, "profile", profile)
@@ -446,19 +470,31 @@ class Ctx:
 
     # ---- the same stacks on several maps per launch (the frame's encoder passes) -------------------------------------------------
     def batched_available(self) -> bool:
-        """One launch per layer for all maps of a BMap: the single-product 16-bit modes on the slab kernel."""
-        return self.lp16 and self.use_slab and self.x1_bf16 and self.bf16_storage and not self.fuse_apply and self.batch_enc
+        """One launch per layer for all maps of a BMap (the frame's encoder passes): the single-product 16-bit modes on the slab kernel."""
+        return self.batched_kernels() and self.x1_bf16 and self.bf16_storage and not self.fuse_apply and self.batch_enc
+
+    def batched_kernels(self) -> bool:
+        """`igemm_batched` can run (what the batched Swin calls need; `batch_enc` only decides about the encoder passes)."""
+        return self.lp16 and self.use_slab
 
     def igemm_batched(self, a: BMap, w, bias: torch.Tensor, N: int, ksize: int, stride: int = 1, act: int = ACT_NONE,
-                      out_dtype=torch.float32) -> BMap:
-        assert self.batched_available() and not torch.is_tensor(w) and w.fhi is not None
+                      out_dtype=torch.float32, residual: Optional[BMap] = None, out: Optional[BMap] = None) -> BMap:
+        """One conv layer on every map of `a` in one launch (gridDim.y = map).  residual: fp32 maps of the output shape added in the
+        epilogue; it may be `out` itself (each workgroup reads the residual of its own pixels before it writes them), never `a`."""
+        assert self.batched_kernels() and not torch.is_tensor(w) and w.fhi is not None
         pad = ksize // 2
         ho, wo = (a.H + 2 * pad - ksize) // stride + 1, (a.W + 2 * pad - ksize) // stride + 1
         assert tuple(w.shape) == (ksize * ksize, N, a.C) and a.t.dtype in (torch.float32, LP_DTYPE[self.fmt])
-        out = BMap.empty(a.B, ho, wo, N, a.t.device, out_dtype)
+        if out is None:
+            out = BMap.empty(a.B, ho, wo, N, a.t.device, out_dtype)
+        assert (out.B, out.H, out.W, out.C) == (a.B, ho, wo, N) and out.t.data_ptr() != a.t.data_ptr()
+        if residual is not None:
+            assert (residual.B, residual.H, residual.W, residual.C) == (a.B, ho, wo, N) and residual.t.dtype == torch.float32
+            assert residual.t.data_ptr() != a.t.data_ptr()
         tp = self._tp
         _lib.check(_lib.lib().spei_conv_slab16_batched(self.fmt, tp(a.t), a.C, a.fmt, tp(w.frag(self.fmt)), _vp(0), tp(bias), tp(out.t), out.fmt,
-                                                       _vp(0), a.B, a.H, a.W, ho, wo, N, ksize, stride, pad, act, self._stream()),
+                                                       tp(residual.t) if residual is not None else _vp(0), a.B, a.H, a.W, ho, wo, N, ksize,
+                                                       stride, pad, act, self._stream()),
                    "spei_conv_slab16_batched")
         return out
 
@@ -494,6 +530,10 @@ class Ctx:
     def mlp_fused_available(self) -> bool:
         return self.lp16 and self.use_slab and self.fuse_mlp
 
+    def swin_multi_available(self) -> bool:
+        """The Swin calls of a frame as one batch over stacked maps (engine.swin_multi): needs the batched attention kernel."""
+        return self.attn_fused_available() and self.attn_win4 and self.mlp_fused_available() and self.batched_kernels() and not self.fuse_block
+
     def block_fused_available(self) -> bool:
         return self.attn_fused_available() and self.mlp_fused_available() and self.fuse_block
 
@@ -510,11 +550,20 @@ class Ctx:
         return out
 
     def attn_fused(self, x: torch.Tensor, yhat: torch.Tensor, bk: dict, H: int, W: int, shift: int, out: torch.Tensor) -> torch.Tensor:
-        """out = x + proj(window_attention(...))  (reference model/swinir.py:238-278); in place when out is x."""
-        assert x.shape == (H * W, 256) and x.dtype == torch.float32 and out.shape == x.shape and out.dtype == torch.float32
+        """out = x + proj(window_attention(...))  (reference model/swinir.py:238-278); in place when out is x.  x, yhat, out:
+        [B * H * W, 256], B >= 1 equally sized maps stacked (the Swin calls of a frame share the block's weights); B > 1 needs the
+        batched four-window kernel (`attn_win4`)."""
+        assert x.shape[0] % (H * W) == 0 and x.shape[1] == 256 and x.dtype == torch.float32 and out.shape == x.shape and out.dtype == torch.float32
         f = self.fmt
         assert yhat.shape == x.shape and yhat.dtype == LP_DTYPE[f]
         tp = self._tp
+        batch = x.shape[0] // (H * W)
+        if self.attn_win4:
+            _lib.check(_lib.lib().spei_attn_win4_16(f, tp(x), tp(out), tp(yhat), tp(bk["wq"].frag(f)), tp(bk["bq"]), tp(bk["wkv"].frag(f)),
+                                                    tp(bk["bkv"]), tp(bk["wproj"].frag(f)), tp(bk["bproj"]), tp(bk["relbias"]), batch, H, W,
+                                                    shift, self._stream()), "spei_attn_win4_16")
+            return out
+        assert batch == 1, "the two-window kernel takes one map per launch"
         _lib.check(_lib.lib().spei_attn_fused16(f, tp(x), tp(out), tp(yhat), tp(bk["wq"].frag(f)), tp(bk["bq"]), tp(bk["wkv"].frag(f)),
                                                 tp(bk["bkv"]), tp(bk["wproj"].frag(f)), tp(bk["bproj"]), tp(bk["relbias"]), H, W, shift,
                                                 self._stream()), "spei_attn_fused16")
@@ -660,7 +709,9 @@ class Ctx:
             return self.upsample(self.igemm(f, w, b, n), s, act=ACT_RELU)
         return self.igemm(self.upsample(f, s), w, b, n, act=ACT_RELU)
 
-    def add(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-        out = torch.empty_like(a)
+    def add(self, a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if out is None:
+            out = torch.empty_like(a)
+        assert out.shape == a.shape == b.shape and out.dtype == a.dtype == torch.float32
         _lib.check(_lib.lib().spei_add(self._tp(a), self._tp(b), self._tp(out), a.numel(), self._stream()), "spei_add")
         return out

@@ -247,11 +247,14 @@ def test_mlp_tok_vs_oracle(synth_sd, mode):
 
 @pytest.mark.parametrize("h,w,shift", [(5, 5, 0), (5, 5, 2), (10, 15, 0), (10, 15, 2), (15, 25, 2), (20, 35, 0), (20, 35, 2),
                                        (180, 320, 2)])       # last: the 720p token map (2304 windows), oracle on the CPU
+@pytest.mark.parametrize("win4", [True, False])
 @pytest.mark.parametrize("mode", ["bf16", "f16"])
-def test_attn_fused_vs_oracle(synth_sd, h, w, shift, mode):
+def test_attn_fused_vs_oracle(synth_sd, h, w, shift, mode, win4):
     """Fused LN -> q/kv -> shifted-window attention -> proj -> +x kernel against the oracle's attention branch
-    (model/swinir.py:238-278); odd window counts leave the second window slot of the last workgroup empty."""
-    ops = Ctx(mode, device=DEV)
+    (model/swinir.py:238-278); window counts that are not a multiple of a workgroup's windows leave its last slots empty.  win4: the
+    four-window kernel of round 4 (spei_attn_win4_16, the default; also run on TWO stacked maps, as the engine calls it for the two Swin
+    calls of a frame: each map must come out as it does alone) / round 2's two-window kernel."""
+    ops = Ctx(mode, device=DEV, attn_win4=win4)
     p = "swin.layers.2.residual_group.blocks.1."
     bk = pack._to_device(pack.swin_block(synth_sd, p, 8, 5), DEV)
     m = h * w
@@ -272,6 +275,14 @@ def test_attn_fused_vs_oracle(synth_sd, h, w, shift, mode):
     out = ops.attn_fused(xd, yhat, bk, h, w, shift, out=torch.empty_like(xd))
     e = ((out.cpu() - x[0] - branch).abs().max() / branch.abs().max()).item()
     assert torch.isfinite(out).all() and e < TOL[mode], f"{h}x{w} shift {shift}: rel err {e:.2e}"
+    if win4:
+        # two maps in one launch: map 0 = this case, map 1 = other tokens; map 0's rows must be bit-identical to the single-map launch
+        x2 = torch.cat((xd, xd.flip(0) * 0.7 + 0.1))
+        y2 = torch.cat((yhat, yhat.flip(0)))
+        both = ops.attn_fused(x2, y2, bk, h, w, shift, out=torch.empty_like(x2))
+        assert torch.equal(both[:m], out) and torch.isfinite(both).all()
+        alone = ops.attn_fused(x2[m:].contiguous(), y2[m:].contiguous(), bk, h, w, shift, out=torch.empty_like(xd))
+        assert torch.equal(both[m:], alone)
     inplace = ops.attn_fused(xd, yhat, bk, h, w, shift, out=xd)
     assert torch.equal(inplace, out)
 

@@ -134,3 +134,32 @@ def test_forward_window_reuse_bit_identical(graph):
             assert torch.equal(out_w, ref), f"window {t}"
     # 8 raw + 6 RL-5 + 8 RL-1 encoder passes and 2 reference pyramids were computed, instead of 36 + 5 without the cache
     assert cache.misses == 24 and cache.hits >= 10, (cache.hits, cache.misses)
+
+
+@pytest.mark.parametrize("h,w", [(720, 1280), (60, 100), (45, 77), (19, 51)])
+def test_frame_post_vs_numpy(h, w):
+    """csrc/metrics.hip (uint8 conversion + finite flag + PSNR + SSIM in three launches) against the host restatements of the
+    reference's functions: `selection.tensor2numpy` (inference_SPEINet.py:477-482), `selection.calc_psnr` (:484-500) and
+    `inference.calc_ssim` (:502-543, numpy float64; SSIM itself is parity-unpinned: cv2 is absent) on the 4-pixel-cropped frames."""
+    from speinet_amd import ops
+    g = torch.Generator().manual_seed(h * 1000 + w)
+    gt = (torch.rand(h, w, 3, generator=g) * 255).round().to(torch.uint8)
+    out = (gt.permute(2, 0, 1).float() / 255 + 0.08 * torch.randn(3, h, w, generator=g)).contiguous()     # leaves [0, 1] in places
+    out[0, 5, 7] = 0.5 / 255                                                                               # a tie: rounds to even (0)
+    out[1, 6, 8] = 1.5 / 255                                                                               # ... (2)
+    u8, res = ops.frame_post(out.to("cuda:0"), gt.to("cuda:0"), 4)
+    ref_u8 = selection.tensor2numpy(out[None])
+    assert np.array_equal(u8.cpu().numpy(), ref_u8)
+    fin, psnr, ssim = res.tolist()
+    assert fin == 1.0
+    a, b = ref_u8[4:-4, 4:-4], gt.numpy()[4:-4, 4:-4]
+    assert abs(psnr - selection.calc_psnr(a, b)) < 1e-9
+    assert abs(ssim - inference.calc_ssim(a, b)) < 1e-10
+    # identical frames: PSNR inf, SSIM 1; a non-finite value is reported and does not poison the uint8 frame
+    same = (gt.permute(2, 0, 1).float() / 255).contiguous()
+    _, res = ops.frame_post(same.to("cuda:0"), gt.to("cuda:0"), 4)
+    assert res[0].item() == 1.0 and res[1].item() == float("inf") and abs(res[2].item() - 1.0) < 1e-12
+    same[2, 3, 3] = float("nan")
+    same[0, 9, 9] = float("inf")
+    u8, res = ops.frame_post(same.to("cuda:0"), gt.to("cuda:0"), 4)
+    assert res[0].item() == 0.0 and u8.cpu()[3, 3, 2] == 0

@@ -36,8 +36,13 @@ def timeit(name, fn, n=30):
     print(f"{name:28s} {e0.elapsed_time(e1) / n * 1e3:7.1f} us")
 
 
+a2 = ops.replace(attn_win4=False)
+xx, yy = torch.randn(2 * H * W, 256, device=dev), torch.randn(2 * H * W, 256, device=dev).to(LP)
+oo = torch.empty_like(xx)
 for shift in (0, 2):
-    timeit(f"attn_fused shift={shift}", lambda: ops.attn_fused(x, yhat, bk, H, W, shift, out))
+    timeit(f"attn_fused (2 windows) shift={shift}", lambda: a2.attn_fused(x, yhat, bk, H, W, shift, out))
+    timeit(f"attn_win4 1 map        shift={shift}", lambda: ops.attn_fused(x, yhat, bk, H, W, shift, out))
+    timeit(f"attn_win4 2 maps       shift={shift}", lambda: ops.attn_fused(xx, yy, bk, H, W, shift, oo))
 out_b = torch.empty_like(x)
 for shift in (0, 2):
     timeit(f"attn_tok   shift={shift}", lambda: ops.attn_tok(x, yhat, bk, H, W, shift, out_b))
@@ -51,5 +56,5 @@ timeit("mlp_fused 2x tokens", lambda: old.mlp_fused(x2, bk["w1"], bk["b1"], bk["
 timeit("mlp_ws    2x tokens", lambda: ws.mlp_fused(x2, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out2))
 timeit("mlp_tok   2x tokens", lambda: ops.mlp_tok(x2, bk["mlp_stream"], bk["b1"], bk["b2"], out2))
 for shift in (0, 2):
-    timeit(f"attn + mlp shift={shift}", lambda: ops.mlp_fused(ops.attn_fused(x, yhat, bk, H, W, shift, out), bk["w1"], bk["b1"], bk["w2"], bk["b2"], out))
+    timeit(f"attn + mlp shift={shift}", lambda: a2.mlp_fused(a2.attn_fused(x, yhat, bk, H, W, shift, out), bk["w1"], bk["b1"], bk["w2"], bk["b2"], out))
     timeit(f"swin_block shift={shift}", lambda: ops.swin_block(x, yhat, bk, H, W, shift, out))

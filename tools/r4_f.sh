@@ -1,0 +1,9 @@
+set -e
+O=gpurun_out/r4f
+mkdir -p $O
+timeout -k 10 600 python -m pytest tests/test_gpu_bf16.py -x -q -k "attn_fused_vs_oracle" > $O/tests.txt 2>&1 || true
+tail -5 $O/tests.txt
+python -m speinet_amd.build --tuning > $O/build.txt 2>&1
+python tools/stamp_phases.py attn4 > $O/stamp_attn4.txt 2>&1 || true
+python tools/stamp_phases.py attn > $O/stamp_attn.txt 2>&1 || true
+cat $O/stamp_attn4.txt $O/stamp_attn.txt

@@ -33,6 +33,8 @@ bk = pack._to_device(pack.swin_block(sd, p, 8, 5), dev)
 x = torch.randn(H * W, 256, device=dev)
 yhat = torch.randn(H * W, 256, device=dev).half()
 out = torch.empty_like(x)
+x2, yhat2 = torch.randn(2 * H * W, 256, device=dev), torch.randn(2 * H * W, 256, device=dev).half()
+out2 = torch.empty_like(x2)
 
 
 if which.startswith("conv"):
@@ -48,7 +50,9 @@ def run():
     if which.startswith("conv"):
         ops.igemm(cx, cw, cb, ch, ksize=5, out=cout)
     elif which == "attn":
-        ops.attn_fused(x, yhat, bk, H, W, 2, out)
+        ops.replace(attn_win4=False).attn_fused(x, yhat, bk, H, W, 2, out)
+    elif which == "attn4":
+        ops.attn_fused(x2, yhat2, bk, H, W, 2, out2)
     elif which == "block":
         ops.swin_block(x, yhat, bk, H, W, 2, out)
     elif which == "attntok":
