@@ -39,9 +39,11 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   harness        (N = 1, unless --no-harness) end-to-end frames/s of the inference harness (speinet_amd.inference, the counterpart of
                  inference_SPEINet.py) on a synthetic 720p clip ON DISK: PNG decode, selection, upload, forward with cross-window
                  encoder reuse, uint8, PSNR / SSIM, PNG encode — what a user of the reference's script gets per frame.
-  cpu_baseline   the oracle (CPU restatement of the reference, PyTorch fp32) timed on this host's cores, rank 0, N = 1:
-                 ONE 720p frame, no warm-up (about a minute).  If a 360x640 probe predicts more than --cpu-budget seconds
-                 the probe itself is reported, scaled by the FLOP formula of BASELINE.md §2 and labelled "extrapolated".
+  cpu_baseline   the oracle (CPU restatement of the reference, PyTorch fp32) timed on this host's cores, rank 0, N = 1: one untimed
+                 and two timed 360x640 frames (threads, allocator, oneDNN primitives warm), then ONE 720p frame (the value).  Threads =
+                 the physical cores of one socket, capped by the CPUs the process may use (affinity / cgroup quota); both numbers are
+                 in the record.  If the probe predicts more than --cpu-budget seconds for the 720p frame the probe itself is
+                 reported, scaled by the FLOP formula of BASELINE.md §2 and labelled "extrapolated".
 """
 from __future__ import annotations
 
@@ -61,7 +63,7 @@ sys.path.insert(0, ROOT)
 H, W = 720, 1280
 # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters: dense matrix peaks (never the 2:1-sparsity figures)
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0, "f16": 2500.0}
-TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
+TRAFFIC_FILES = ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
 
 
 def path_flops(h: int, w: int) -> float:
@@ -84,8 +86,9 @@ def traffic_bytes(precision: str, corr_precision: str):
             continue
         e = d.get(f"{precision}/{corr_precision if precision != 'f32' else 'f32'}")
         if e:
-            return e.get("hbm_bytes_per_launch"), e.get("path_hbm_bytes_per_frame"), f"profiles/{name} (offline rocprofv3 --pmc, {d.get('commit', 'n/a')})"
-    return None, None, None
+            return (e.get("hbm_bytes_per_launch"), e.get("path_hbm_bytes_per_frame"), f"profiles/{name} (offline rocprofv3 --pmc, {d.get('commit', 'n/a')})",
+                    e.get("families_hbm_bytes_per_frame") or {})
+    return None, None, None, {}
 
 
 def physical_cores() -> int:
@@ -106,6 +109,39 @@ def physical_cores() -> int:
         return os.cpu_count() or 1
 
 
+def socket_cores() -> int:
+    """Physical cores of ONE socket (unique core ids under the first `physical id` of /proc/cpuinfo)."""
+    try:
+        per, cur = {}, {}
+        for line in list(open("/proc/cpuinfo")) + ["\n"]:
+            if ":" in line:
+                k, v = (t.strip() for t in line.split(":", 1))
+                cur[k] = v
+            elif cur:
+                per.setdefault(cur.get("physical id", "0"), set()).add(cur.get("core id", cur.get("processor", "0")))
+                cur = {}
+        return max(1, len(per[sorted(per)[0]])) if per else (os.cpu_count() or 1)
+    except OSError:
+        return os.cpu_count() or 1
+
+
+def usable_cpus() -> int:
+    """CPUs this process may run on: its affinity mask, capped by the cgroup CPU quota (cpu.max, v2; cpu.cfs_quota_us, v1)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:
+            q, per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(seed: int, mode: str, budget_s: float) -> dict:
     """The oracle (CPU restatement of the reference, PyTorch fp32) on this host: one untimed warm-up + two timed frames at 360x640
     (threads, allocator and oneDNN primitives warm; their spread is reported), then ONE timed frame at the bench size 1280x720 — the
@@ -113,7 +149,10 @@ def cpu_baseline(seed: int, mode: str, budget_s: float) -> dict:
     from oracle import speinet_oracle as O
     from speinet_amd.synth import state_dict_template, synth_frames, synth_state_dict
     phys, logical = physical_cores(), os.cpu_count() or 1
-    threads = min(phys, 16)
+    socket, usable = socket_cores(), usable_cpus()
+    # the physical cores of ONE socket — capped by what this process may actually use (CPU affinity / cgroup quota: a
+    # 1-GPU box of the pool shares its host; more threads than usable CPUs time-slice and measure the scheduler)
+    threads = max(1, min(socket, usable))
     torch.set_num_threads(threads)
     sd = synth_state_dict(state_dict_template(), seed=0)
 
@@ -129,16 +168,55 @@ def cpu_baseline(seed: int, mode: str, budget_s: float) -> dict:
     probes = [run(sh, sw) for _ in range(2)]
     dt = min(probes)
     scale = path_flops(H, W) / path_flops(sh, sw)
-    host = f"{threads} threads on {phys} physical / {logical} logical cores visible"
+    host = (f"{threads} threads = min(physical cores of one socket {socket}, CPUs this process may use {usable}); {phys} physical / {logical} "
+            "logical cores visible")
     if mode == "720p" and dt * scale * 2.5 <= budget_s:       # measured: the quadratic term makes 720p ~2x the FLOP-scaled probe
         dt720 = run(H, W)
-        return {"value": 1.0 / dt720, "unit": "frames/s", "cores": threads, "physical_cores": phys, "kind": "port",
+        return {"value": 1.0 / dt720, "unit": "frames/s", "cores": threads, "physical_cores": phys, "socket_physical_cores": socket,
+                "usable_cpus": usable, "kind": "port",
                 "sample": f"oracle (PyTorch fp32 CPU restatement), {host}: ONE {W}x{H} _forwardbs frame in {dt720:.1f} s after a warm-up "
                           f"and two timed {sw}x{sh} frames ({probes[0]:.2f} s, {probes[1]:.2f} s)"}
-    return {"value": 1.0 / (dt * scale), "unit": "frames/s", "cores": threads, "physical_cores": phys, "kind": "port",
+    return {"value": 1.0 / (dt * scale), "unit": "frames/s", "cores": threads, "physical_cores": phys, "socket_physical_cores": socket,
+            "usable_cpus": usable, "kind": "port",
             "sample": f"EXTRAPOLATED: oracle, {host}: best of two timed {sw}x{sh} _forwardbs frames after a warm-up ({probes[0]:.2f} s, "
                       f"{probes[1]:.2f} s), scaled x{scale:.2f} to 720p by F(HW) of BASELINE.md (optimistic: the 57600^2 correlation does "
                       "not scale like FLOPs)"}
+
+
+def family_records(fam_events: dict, n_frames: int, h: int, w: int, has_ref: bool, peak: float, fam_hbm: dict, diag: bool) -> dict:
+    """Per kernel family: kernel ms per frame (HIP events around every launch, exclusive), launches, the ALGORITHMIC work per frame
+    (conv 8.536 T, Swin linears + attention 4.455 T — both linear in H W —, correlation 2 x 1152 x (HW/16)^2; the
+    streaming family = ResBlock gate statistics + gated sums: one read of x1 for the statistics, x + x1 read and x' written by the
+    apply pass: 12 B per element of each of the frame's 72 (66 without a sharp reference) ResBlock maps) and what that makes of the
+    roofline that bounds it."""
+    if not n_frames:
+        return {}
+    hw = h * w
+    scale = hw / float(H * W)
+    blocks_per_level = (7 if has_ref else 6) * 3 + 3                  # encoder passes x 3 ResBlocks + the decoder's 3, per level
+    work = {"conv": ("mfma", 8.536e12 * scale, "conv_slab / igemm / conv5 (every Conv2d, ConvTranspose2d; Swin's 3x3 convs)"),
+            "swin": ("mfma", 4.455e12 * scale, "attn_win4 + mlp_fused (72 Swin blocks: LayerNorm, q/kv/proj, W-MSA, MLP)"),
+            "correlation": ("mfma", corr_flops(h, w), "corr_diag / corr_slab + reduce + re-score (SearchTransfer's bmm + max)"),
+            "streaming": ("hbm", blocks_per_level * 56.0 * hw * 12.0, "gate_stats / gate_maps / resblock_apply (SE + triplet gates, gated residual sum)")}
+    out = {}
+    for fam, (bound, alg, kernels) in work.items():
+        ev = fam_events.get(fam, [])
+        if not ev:
+            continue
+        ms = sum(s_.elapsed_time(e_) for s_, e_ in ev) / n_frames
+        rec = {"ms_per_frame": ms, "launches_per_frame": len(ev) / n_frames, "kernels": kernels, "bound": bound,
+               "hbm_bytes_per_frame": fam_hbm.get(fam)}
+        if bound == "mfma":
+            rec.update(algorithmic_flops_per_frame=alg, achieved=alg / (ms * 1e-3) / 1e12, peak=peak, unit="TFLOP/s")
+            if fam == "correlation" and diag:
+                rec.update(executed_flops_per_frame=alg / 3.0, executed_tflops=alg / 3.0 / (ms * 1e-3) / 1e12,
+                           note="the diagonal kernel executes a third of the bmm's flops (each row-against-row term once): frac prices the "
+                                "algorithmic count and can exceed 1; executed_tflops / peak is the matrix-pipe utilisation")
+        else:
+            rec.update(algorithmic_bytes_per_frame=alg, achieved=alg / (ms * 1e-3) / 1e9, peak=8000.0, unit="GB/s")
+        rec["frac"] = rec["achieved"] / rec["peak"]
+        out[fam] = rec
+    return out
 
 
 def train_main(argv=None):
@@ -284,6 +362,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=2,
                     help="frames in flight: consecutive steps alternate over this many launch streams; step i + 1 starts when step i's "
                          "correlation kernel has finished, so its encoder passes run beside step i's decoder (1: one frame at a time)")
+    ap.add_argument("--no-families", action="store_true", help="skip the per-family kernel-time pass (3 eager frames with HIP events around every launch)")
     ap.add_argument("--no-extras", action="store_true", help="skip the bf16-to-the-letter and training sub-records of the default line")
     ap.add_argument("--free-overlap", action="store_true", help="with --inflight > 1: let the frames overlap freely instead of gating frame i + 1 on frame i's correlation kernel")
     ap.add_argument("--knobs", default="", help='experiments: JSON of extra speinet_amd.ops.Ctx fields, e.g. \'{"stage": {"glue": {"precision": "bf16x3"}}}\'')
@@ -382,6 +461,19 @@ def main():
         run_steps(args.steps)
         barrier()
         dt_ref_call = time.perf_counter() - t1
+        # ---- per-family kernel time: the same frames once more, eager on ONE stream with a HIP event pair around every launch of the
+        # conv / swin / correlation / streaming kernels (exclusive times: nothing overlaps; not part of the timed region) ----------------
+        fam_prof, fam_frames = {"families": {}}, 0
+        if rank == 0 and not args.no_families:
+            keep = (net.use_graph, net.streams)
+            net.use_graph, net.streams = False, 1
+            net(frames[0], routing=routing)                       # eager warm-up (allocator)
+            torch.cuda.synchronize()
+            for i in range(3):
+                net(frames[i % 2], routing=routing, profile=fam_prof)
+                fam_frames += nb
+            torch.cuda.synchronize()
+            net.use_graph, net.streams = keep
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)] if nfl == 1 else \
               [marks[i].elapsed_time(marks[i + nfl]) / nfl for i in range(1, args.steps + 1 - nfl)]   # same-stream neighbours
     pairs = prof["corr_argmax"]
@@ -406,8 +498,10 @@ def main():
         ach_alg = corr_flops(h, w) / (corr_ms * 1e-3) / 1e12 if corr_ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.precision]
         dtype = args.precision if args.precision == "f32" else f"{args.precision} (correlation {args.corr_precision})"
-        k_bytes, path_hbm, tsrc = traffic_bytes(args.precision, args.corr_precision) if (h, w) == (H, W) else (None, None, None)
+        k_bytes, path_hbm, tsrc, fam_hbm = traffic_bytes(args.precision, args.corr_precision) if (h, w) == (H, W) else (None, None, None, {})
         qs = statistics.quantiles(step_ms, n=10) if len(step_ms) >= 2 else [step_ms[0]] * 9
+        families = family_records(fam_prof["families"], fam_frames, h, w, args.branch == "bs", peak, fam_hbm, kname.startswith("corr_diag"))
+        top = max(families, key=lambda k: families[k]["ms_per_frame"]) if families else None
         line = {
             "metric": "deblurred 720p frames/sec", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * tmax / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -421,15 +515,26 @@ def main():
             "step_ms": {"median": statistics.median(step_ms), "p10": qs[0], "p90": qs[8], "min": min(step_ms), "max": max(step_ms)},
             "reference_call": {"value": world * args.steps * nb / tmax_ref, "unit": "frames/s", "ms_per_step": 1e3 * tmax_ref / args.steps,
                                "note": "forward(x) without the routing hint: the frame-3 test runs on the device, one host sync per call"},
-            "roofline": {"bound": "mfma", "kernel": prof.get("corr_kernel"), "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                         "frac": ach / peak, "traffic": k_bytes, "traffic_source": tsrc, "launch_ms": corr_ms,
-                         "launch_ms_source": "HIP events around the direct launch between the two graph segments, every timed step",
-                         "algorithmic_flops_per_launch": corr_flops(h, w),
-                         "executed_flops_per_launch": exec_flops,
-                         "algorithmic_equivalent_tflops": ach_alg,
-                         "note": ("achieved = executed flops / launch time; the kernel shares each row-against-row term among the three patch rows "
-                                  "that use it, so it executes a third of the algorithmic (bmm) count: the bmm-equivalent rate exceeds the MFMA peak")
-                                 if exec_flops != corr_flops(h, w) else "achieved = algorithmic flops / launch time",
+            # the family with the most kernel time per frame; every family is in `families`, the correlation kernel —
+            # the one launch per frame that can be bracketed live inside the timed region — keeps its own record
+            "roofline": {**({"bound": families[top]["bound"], "kernel": f"{top} family: {families[top]['kernels']}",
+                             "achieved": families[top]["achieved"], "peak": families[top]["peak"], "unit": families[top]["unit"],
+                             "frac": families[top]["frac"], "traffic": families[top]["hbm_bytes_per_frame"],
+                             "ms_per_frame": families[top]["ms_per_frame"],
+                             "what": "achieved = the family's ALGORITHMIC flops (bytes) per frame / its kernel time per frame; kernel time = sum of "
+                                     "HIP-event pairs around every launch of the family over 3 eager single-stream frames run right after the timed "
+                                     "region (exclusive: nothing overlaps); traffic = the family's HBM bytes per frame from the offline PMC passes"}
+                            if top else {"bound": "mfma", "kernel": None, "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None}),
+                         "families": families, "traffic_source": tsrc,
+                         "correlation_kernel": {
+                             "kernel": prof.get("corr_kernel"), "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                             "traffic": k_bytes, "launch_ms": corr_ms,
+                             "launch_ms_source": "HIP events around the direct launch between the two graph segments, every timed step",
+                             "algorithmic_flops_per_launch": corr_flops(h, w), "executed_flops_per_launch": exec_flops,
+                             "algorithmic_equivalent_tflops": ach_alg,
+                             "note": ("achieved = executed flops / launch time; the kernel shares each row-against-row term among the three patch rows "
+                                      "that use it, so it executes a third of the algorithmic (bmm) count: the bmm-equivalent rate exceeds the MFMA peak")
+                                     if exec_flops != corr_flops(h, w) else "achieved = algorithmic flops / launch time"},
                          "path_flops_per_frame": path_flops(h, w),
                          "path_frac": path_flops(h, w) * fps / world / 1e12 / peak,
                          "path_hbm_bytes_per_frame": path_hbm,
@@ -453,7 +558,22 @@ def main():
                                    "dtype": f"bf16 (correlation {args.corr_precision})", "corr_kernel": prof_b.get("corr_kernel"),
                                    "corr_launch_ms": sum(s_.elapsed_time(e_) for s_, e_ in pb) / max(1, len(pb)),
                                    "parity": "|dPSNR| vs the reference 3e-3 dB (tests/test_gpu_bf16.py bound 1e-2)"}
-            net.precision = args.precision
+            # BASELINE.json configs[2] ("fp32, PSNR-matched"): the f32-grade arithmetic — split bf16x3 products on the 16-bit matrix pipe
+            # (2^-16 per operand, fp32 accumulation; every kernel <= 2e-4 relative, frames within 1e-3 dB of the reference with the
+            # correlation in the same arithmetic: tests/test_gpu_bf16.py, test_gpu_parity.py) — same frames, fewer steps (3x the time)
+            net.precision, net.corr_precision = "bf16x3", "bf16x3"
+            k32 = max(4, args.steps // 4)
+            with torch.no_grad():
+                run_steps(nfl + 1, routing=routing)
+                barrier()
+                t3 = time.perf_counter()
+                run_steps(k32, routing=routing)
+                barrier()
+                dt3 = time.perf_counter() - t3
+            line["f32_grade"] = {"value": k32 / dt3, "unit": "frames/s", "ms_per_step": 1e3 * dt3 / k32, "steps": k32,
+                                 "dtype": "bf16x3 (split products, f32-grade; correlation bf16x3)",
+                                 "parity": "|dPSNR| vs the reference <= 1e-3 dB, max |err| < 1e-3 (tests/test_gpu_parity.py, test_gpu_bf16.py)"}
+            net.precision, net.corr_precision = args.precision, args.corr_precision
         if world == 1 and not args.no_harness and (h, w) == (H, W) and args.precision != "f32" and nb == 1:
             from speinet_amd.inference import harness_throughput
             del net, frames

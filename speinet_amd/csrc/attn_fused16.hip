@@ -499,10 +499,11 @@ __global__ __launch_bounds__(512, 2) void attn_win4_kernel(const Attn4Params<LP>
     // One pass of the wave's 4 windows over K = 256: 16 weight fragments from L2 (RQ in flight), token fragments from the slab one step
     // ahead, 4 MFMAs per step; TOKENS_ON_COLUMNS: weights as the A operand (Q^T, K^T), else tokens as A (V).  Pinned with full
     // scheduling barriers (left alone the scheduler sinks every load to right before its use).
-    auto pass = [&](const LP* wp, f32x16 (&acc)[WPG], auto tokens_on_columns) {
+    auto pass = [&](const LP* wp, f32x16 (&acc)[WPG], auto tokens_on_columns, auto&& behind_prologue) {
         lp8 ring[RQ];
 #pragma unroll
         for (int d = 0; d < RQ; ++d) ring[d] = *reinterpret_cast<const lp8*>(wp + ((rot + d) & 15) * 512);
+        behind_prologue();                            // loads that a LATER phase consumes: behind the first RQ fragments in the (in-order) vmcnt queue
         lp8 tn[WPG];
 #pragma unroll
         for (int wd = 0; wd < WPG; ++wd) tn[wd] = *reinterpret_cast<const lp8*>(slab + rowoff[wd]);
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(512, 2) void attn_win4_kernel(const Attn4Params<LP>
     {
         f32x16 acc[WPG];
         init_rows(acc, sbias);
-        pass(p.wq + (size_t)h * 16 * 512 + lane * 8, acc, std::true_type{});
+        pass(p.wq + (size_t)h * 16 * 512 + lane * 8, acc, std::true_type{}, [] {});
 #pragma unroll
         for (int wd = 0; wd < WPG; ++wd) {
             qp[wd][0] = cvt8<0, LP>(acc[wd]);
@@ -609,12 +610,14 @@ __global__ __launch_bounds__(512, 2) void attn_win4_kernel(const Attn4Params<LP>
 
     // ---- 2b. K^T -> S^T -> softmax;  V -> O^T ------------------------------------------------------------------------------------------------
     lp4 opk[WPG][4];                                  // O^T packed: [window][4 d-groups], written to the slab after the barrier
+    const int et = fr & 3, ecol = (fr >> 2) * 4;
+    f32x4 rv[4][4];                                   // residual rows of the projection's accumulators: requested under the V pass
     {
         lp8 pp[WPG][2];                               // P^T packed
         {
             f32x16 acc[WPG];
             init_rows(acc, sbias + D);
-            pass(p.wkv + (size_t)h * 16 * 512 + lane * 8, acc, std::true_type{});
+            pass(p.wkv + (size_t)h * 16 * 512 + lane * 8, acc, std::true_type{}, [] {});
 #pragma unroll
             for (int wd = 0; wd < WPG; ++wd) {
                 f32x16 st;
@@ -659,7 +662,16 @@ __global__ __launch_bounds__(512, 2) void attn_win4_kernel(const Attn4Params<LP>
             for (int wd = 0; wd < WPG; ++wd)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[wd][r] = bv;
-            pass(p.wkv + (size_t)(8 + h) * 16 * 512 + lane * 8, acc, std::false_type{});
+            pass(p.wkv + (size_t)(8 + h) * 16 * 512 + lane * 8, acc, std::false_type{}, [&] {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int r = i * 32 + 8 * k + 4 * fk + et;
+                        const int pix = max(tok_pix[min(r, TOK - 1)], 0);
+                        rv[i][k] = *reinterpret_cast<const f32x4*>(xg + (size_t)pix * D + wave * HD + ecol);
+                    }
+            });
 #pragma unroll
             for (int wd = 0; wd < WPG; ++wd) {
                 // O^T[d][query] = sum_key V[key][d] P^T[key][query]:  A = V^T from the accumulator (X^T.B form), B = P^T (packed)
@@ -677,17 +689,7 @@ __global__ __launch_bounds__(512, 2) void attn_win4_kernel(const Attn4Params<LP>
         SPEI_STAMP(p.stamps, 5);
     }
     // ---- 3. proj: the wave's 32 output channels of the 100 rows (4 row tiles, the last one clamped); acc starts from x + bias.  The
-    // residual rows and the first projection fragments are requested BEFORE the barrier that ends the attention phase -----------------------
-    const int et = fr & 3, ecol = (fr >> 2) * 4;
-    f32x4 rv[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int r = i * 32 + 8 * k + 4 * fk + et;
-            const int pix = max(tok_pix[min(r, TOK - 1)], 0);
-            rv[i][k] = *reinterpret_cast<const f32x4*>(xg + (size_t)pix * D + wave * HD + ecol);
-        }
+    // residual rows were requested under the V pass, the first projection fragments are BEFORE the barrier that ends the attention phase -----
     const int rot4 = (grp * 3) & 15;                  // the projection's own rotation; the attention output is stored rotated by it
     const LP* wpp = p.wproj + (size_t)wave * 16 * 512 + lane * 8;
     lp8 wf[RP];

@@ -127,6 +127,26 @@ class _timed:
         return False
 
 
+def _family(name: str):
+    """Time every call of a leaf launch method when the caller asked for it: `profile["families"]` = {family: [(start, end), ...]} gets
+    one HIP event pair per call on the launch stream (eager, single-stream passes only: bench.py's per-family roofline record)."""
+    def deco(fn):
+        def wrapper(self, *a, **k):
+            pr = self.profile
+            if pr is None or "families" not in pr:
+                return fn(self, *a, **k)
+            st = torch.cuda.current_stream(self.device)
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record(st)
+            out = fn(self, *a, **k)
+            e_.record(st)
+            pr["families"].setdefault(name, []).append((s_, e_))
+            return out
+        wrapper.__name__, wrapper.__doc__ = fn.__name__, fn.__doc__
+        return wrapper
+    return deco
+
+
 def frame_post(out_chw: torch.Tensor, gt_hwc: torch.Tensor, border: int = 4):
     """Harness post-processing of one frame on the device (csrc/metrics.hip; reference inference_SPEINet.py:477-543): out_chw [3,H,W]
     fp32 -> (uint8 [H,W,3] frame, float64 [finite, PSNR, SSIM] against gt_hwc on the border-cropped region), three launches on the
@@ -162,11 +182,18 @@ class CorrPlan:
         st = ctx._stream()
         if ctx.profile is not None:
             ctx.profile["corr_kernel"] = self.kernel
+        fam = ctx.profile is not None and "families" in ctx.profile
+        if fam:
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            f0.record(torch.cuda.current_stream(ctx.device))
         with _timed(ctx, "corr_argmax"):
             for fn, name, args in self.main:
                 _lib.check(fn(*args, st), name)
         for fn, name, args in self.post:
             _lib.check(fn(*args, st), name)
+        if fam:
+            f1.record(torch.cuda.current_stream(ctx.device))
+            ctx.profile["families"].setdefault("correlation", []).append((f0, f1))
 
 
 class Ctx:
@@ -318,6 +345,7 @@ class Ctx:
                    "spei_rl_prior")
         return out
 
+    @_family("conv")
     def conv5_in(self, img: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: Optional[FMap] = None) -> FMap:
         c, h, wd = img.shape
         assert c == 3
@@ -328,6 +356,7 @@ class Ctx:
                    "spei_conv5_in")
         return out
 
+    @_family("conv")
     def conv5_out(self, f: FMap, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, w32=None,
                   b32: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Last conv, NHWC 32 channels -> three NCHW planes.  w32 / b32 (weights zero-padded to 32 output channels,
@@ -344,6 +373,7 @@ class Ctx:
         return out
 
     # ---- the GEMM family ---------------------------------------------------------------------------------------
+    @_family("conv")
     def igemm(self, a0: FMap, w, bias: Optional[torch.Tensor], N: int, ksize: int = 1, stride: int = 1,
               mode: int = CONV, act: int = ACT_NONE, a1: Optional[FMap] = None, residual: Optional[FMap] = None,
               rowscale: Optional[torch.Tensor] = None, out: Optional[FMap] = None, out_dtype=torch.float32,
@@ -415,6 +445,7 @@ class Ctx:
         return out
 
     # ---- ResBlock (K3) -----------------------------------------------------------------------------------------
+    @_family("streaming")
     def resblock_gates(self, x1: FMap, pk: dict):
         dev = x1.t.device
         lib = _lib.lib()
@@ -463,10 +494,14 @@ class Ctx:
             out = FMap.empty(x.H, x.W, c, x.t.device)
         if extra is not None:
             assert extra.off == 0 and extra.ld == c
+        self._apply(x, x1, s, g1, g2, extra, out, c)
+        return out
+
+    @_family("streaming")
+    def _apply(self, x, x1, s, g1, g2, extra, out, c):
         _lib.check(_lib.lib().spei_resblock_apply(self._fp(x), self._fp(x1), x1.fmt, self._tp(s), self._tp(g1), self._tp(g2),
                                                   self._fp(extra), self._fp(out), out.ld, x.H, x.W, c, self._stream()),
                    "spei_resblock_apply")
-        return out
 
     # ---- the same stacks on several maps per launch (the frame's encoder passes) -------------------------------------------------
     def batched_available(self) -> bool:
@@ -477,6 +512,7 @@ class Ctx:
         """`igemm_batched` can run (what the batched Swin calls need; `batch_enc` only decides about the encoder passes)."""
         return self.lp16 and self.use_slab
 
+    @_family("conv")
     def igemm_batched(self, a: BMap, w, bias: torch.Tensor, N: int, ksize: int, stride: int = 1, act: int = ACT_NONE,
                       out_dtype=torch.float32, residual: Optional[BMap] = None, out: Optional[BMap] = None) -> BMap:
         """One conv layer on every map of `a` in one launch (gridDim.y = map).  residual: fp32 maps of the output shape added in the
@@ -507,6 +543,13 @@ class Ctx:
         t = self.igemm_batched(x, pk["w1"], pk["b1"], c, 5, act=ACT_RELU, out_dtype=idt)
         x1 = self.igemm_batched(t, pk["w2"], pk["b2"], c, 5, out_dtype=idt)
         del t
+        return self._gates_apply_batched(x, x1, pk)
+
+    @_family("streaming")
+    def _gates_apply_batched(self, x: BMap, x1: BMap, pk: dict) -> BMap:
+        c, dev = x.C, x.t.device
+        lib = _lib.lib()
+        tp = self._tp
         s = torch.empty(x.B, c, device=dev)
         g1 = torch.empty(x.B, x.H, c, device=dev)
         g2 = torch.empty(x.B, x.W, c, device=dev)
@@ -537,6 +580,7 @@ class Ctx:
     def block_fused_available(self) -> bool:
         return self.attn_fused_available() and self.mlp_fused_available() and self.fuse_block
 
+    @_family("swin")
     def swin_block(self, x: torch.Tensor, yhat: torch.Tensor, bk: dict, H: int, W: int, shift: int, out: torch.Tensor) -> torch.Tensor:
         """out = x1 + mlp(norm2(x1)), x1 = x + attention(norm1(x), yhat)  (reference model/swinir.py:238-281); in place when out is x."""
         f = self.fmt
@@ -549,6 +593,7 @@ class Ctx:
                                                 self._stream()), "spei_swin_block16")
         return out
 
+    @_family("swin")
     def attn_fused(self, x: torch.Tensor, yhat: torch.Tensor, bk: dict, H: int, W: int, shift: int, out: torch.Tensor) -> torch.Tensor:
         """out = x + proj(window_attention(...))  (reference model/swinir.py:238-278); in place when out is x.  x, yhat, out:
         [B * H * W, 256], B >= 1 equally sized maps stacked (the Swin calls of a frame share the block's weights); B > 1 needs the
@@ -569,6 +614,7 @@ class Ctx:
                                                 self._stream()), "spei_attn_fused16")
         return out
 
+    @_family("swin")
     def mlp_fused(self, x: torch.Tensor, w1, b1: torch.Tensor, w2, b2: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         """out = x + fc2(gelu(fc1(LN(x))))  (reference model/swinir.py:279); in place when out is x."""
         assert x.shape[1] == 256 and x.dtype == torch.float32 and out.shape == x.shape and out.dtype == torch.float32

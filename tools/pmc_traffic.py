@@ -40,6 +40,20 @@ out = {"commit": sys.argv[6] if len(sys.argv) > 6 else "n/a", KEY: {"kernel": kn
                      "note": sys.argv[4] + "; FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md "
                              "HBM section); algorithmic compulsory bytes = 2 maps x 14.7 MB (16-bit) + 0.9 MB outputs; the diagonal kernel also writes one "
                              "key pair per (query, diagonal, reference tile): 415 MB at 720p, read back once by its reduce kernel"}}
+# per kernel family (bench.py's roofline.families): the same sums restricted to the family's kernels
+FAMILIES = {"swin": r"attn_fused_kernel|attn_win4_kernel|mlp_fused_kernel|mlp_ws_kernel|swin_block_kernel",
+            "conv": r"conv_slab_kernel|igemm_bf16_kernel|igemm_f32_kernel|conv5_in_kernel|conv5_out_kernel",
+            "correlation": r"corr_(slab|diag)_kernel|corr_diag_reduce|corr_diag_final|corr_rescore|corr_argmax",
+            "streaming": r"resblock_apply|gate_stats|gate_maps"}
+
+
+def fam_total(d, name, rx):
+    f = (glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True))[0]
+    return sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == name and re.search(rx, r["Kernel_Name"]))
+
+
+out[KEY]["families_hbm_bytes_per_frame"] = {k: (2.0 * fam_total(sys.argv[1], "FETCH_SIZE", rx) + fam_total(sys.argv[2], "WRITE_SIZE", rx)) * 1024.0 / n
+                                            for k, rx in FAMILIES.items()}
 # whole frame: every dispatch of the run (n frames = n launches of the correlation kernel; the one-off weight packing of
 # the first call is included, < 1 %), same corrections
 out[KEY]["path_hbm_bytes_per_frame"] = (2.0 * total(sys.argv[1], "FETCH_SIZE") + total(sys.argv[2], "WRITE_SIZE")) * 1024.0 / n

@@ -1,5 +1,5 @@
 set -e
-O=gpurun_out/r4j
+O=gpurun_out/r4q
 mkdir -p $O
 timeout -k 10 600 python -m pytest tests/test_gpu_bf16.py -x -q -k "attn_fused_vs_oracle" > $O/tests.txt 2>&1 || true
 tail -5 $O/tests.txt
