@@ -359,12 +359,17 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="HIP streams for the independent neighbour-frame / reference branches of a frame")
     ap.add_argument("--branch", choices=["bs", "b"], default="bs", help="bs: with sharp reference (SearchTransfer); b: SelfTransfer")
     ap.add_argument("--batch", type=int, default=1, help="windows per forward call (BASELINE configs[1] is batch 1; B > 1 batches the encoder passes of all samples per layer)")
-    ap.add_argument("--inflight", type=int, default=2,
-                    help="frames in flight: consecutive steps alternate over this many launch streams; step i + 1 starts when step i's "
-                         "correlation kernel has finished, so its encoder passes run beside step i's decoder (1: one frame at a time)")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="frames in flight: consecutive steps alternate over this many launch streams (each its own captured graph instance), "
+                         "so that the kernels of one frame fill the tails and launch gaps of the others (1: one frame at a time).  Round 4: three, "
+                         "ungated (--gate none) — with the frame's Swin calls batched on one stream there is no second in-frame stream to fill the "
+                         "chip any more, and three free-running frames measured +2.8 % over round 3's two gated ones (same box)")
     ap.add_argument("--no-families", action="store_true", help="skip the per-family kernel-time pass (3 eager frames with HIP events around every launch)")
     ap.add_argument("--no-extras", action="store_true", help="skip the bf16-to-the-letter and training sub-records of the default line")
-    ap.add_argument("--free-overlap", action="store_true", help="with --inflight > 1: let the frames overlap freely instead of gating frame i + 1 on frame i's correlation kernel")
+    ap.add_argument("--free-overlap", action="store_true", help="(= --gate none, the default since round 4)")
+    ap.add_argument("--gate", choices=["corr_end", "corr_start", "none"], default=None,
+                    help="with --inflight > 1, when step i + 1 may start: after step i's correlation kernel (corr_end, round 3), when it starts "
+                         "(corr_start), or at once (none)")
     ap.add_argument("--knobs", default="", help='experiments: JSON of extra speinet_amd.ops.Ctx fields, e.g. \'{"stage": {"glue": {"precision": "bf16x3"}}}\'')
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
@@ -418,6 +423,7 @@ def main():
         torch.cuda.synchronize()
 
     nfl = max(1, args.inflight)
+    gate_mode = args.gate or "none"
     checksums = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(nfl)]
     prof = {"corr_argmax": []}
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -429,15 +435,14 @@ def main():
         gate = None
         for i in range(n):
             with torch.cuda.stream(lanes[i % nfl]):
-                if gate is not None and nfl > 1 and not args.free_overlap:
-                    # the next frame starts once this frame's correlation kernel (a full-chip MFMA kernel: nothing overlaps it
-                    # productively) is done: its encoder passes then run beside THIS frame's decoder, whose small launches leave most of
-                    # the chip idle
+                if gate is not None and nfl > 1 and gate_mode != "none":
+                    # (round 3's policy, --gate corr_end: the next frame starts once this frame's correlation kernel — a full-chip MFMA
+                    # kernel — is done, so that its encoder passes run beside THIS frame's decoder)
                     torch.cuda.current_stream().wait_event(gate)
                 pr = kw.get("profile")
                 local = pr if pr is not None else {"corr_argmax": []}
                 out = net(frames[i % 2], **dict(kw, profile=local))
-                gate = local["corr_argmax"][-1][1]            # (B > 1: the last sample's)
+                gate = local["corr_argmax"][-1][1 if gate_mode == "corr_end" else 0]            # (B > 1: the last sample's)
                 checksums[i % nfl].add_(out.double().sum())
                 if pr is not None:
                     marks[i + 1].record()
@@ -511,7 +516,9 @@ def main():
                                    "synthetic name-keyed weights seed 0", "frames_per_step_per_gpu": nb,
                        "sharding": "frames by rank, no data-path collective",
                        "launch": ("2 hipGraph segments + the correlation kernel per frame" if net.use_graph else "eager") + f", {args.streams} HIP streams"
-                                 + (f"; {nfl} frames in flight (step i + 1 starts when step i's correlation kernel is done)" if nfl > 1 else "")},
+                                 + (f"; {nfl} frames in flight" + {"corr_end": " (step i + 1 starts when step i's correlation kernel is done)",
+                                                                     "corr_start": " (step i + 1 starts with step i's correlation kernel)",
+                                                                     "none": " on their own streams, ungated"}[gate_mode] if nfl > 1 else "")},
             "step_ms": {"median": statistics.median(step_ms), "p10": qs[0], "p90": qs[8], "min": min(step_ms), "max": max(step_ms)},
             "reference_call": {"value": world * args.steps * nb / tmax_ref, "unit": "frames/s", "ms_per_step": 1e3 * tmax_ref / args.steps,
                                "note": "forward(x) without the routing hint: the frame-3 test runs on the device, one host sync per call"},

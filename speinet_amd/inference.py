@@ -192,7 +192,7 @@ class Inference:
         self.net.precision = args.precision
         self.net.corr_precision = {"f32": "bf16x3", "bf16x3": "bf16x3", "bf16": "top2", "f16": "top2"}[args.precision]
         self.net.use_graph = bool(getattr(args, "graph", True))      # one hipGraph per frame shape / routing
-        self.net.streams = int(getattr(args, "streams", 2))
+        self.net.streams = int(getattr(args, "streams", 1))
         workers = max(2, min(8, (os.cpu_count() or 4) // max(1, self.world)))
         self.io_pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="speinet-io")
         self.post_pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="speinet-post")
@@ -300,6 +300,13 @@ class Inference:
                                               .format(clip, name, psnr, ssim, t_pre, t_fwd, t_post, t_pre + t_fwd + t_post))
 
                 inflight = collections.deque()                  # one event per enqueued window
+                # windows alternate over a few launch streams (each replays its own captured instance of the fuse-and-decode graph): the
+                # kernels of window k + 1 fill the tails and launch gaps of window k's, as bench.py's frames in flight do
+                home = torch.cuda.current_stream(self.device)
+                # (the home stream — where the inputs are assembled — is a lane only when it is the ONLY one: a lane waits for the home
+                # stream before every window, and would wait for the window graphs queued there)
+                nl = max(1, int(getattr(a, "lanes", 2)))
+                lanes = [home] if nl == 1 else [torch.cuda.Stream(device=self.device) for _ in range(nl)]
                 t_loop = time.time()
                 def prepare(k):
                     """Inputs of window k on the device: (x, keys, gt, nh, nw, window, seconds spent)."""
@@ -326,7 +333,7 @@ class Inference:
                     # keep the host at most two windows ahead of the GPU: enough slack to hide its own work, and a worker that
                     # fetches a finished frame waits ~2 windows, not the whole queue (the post pool would otherwise spend its
                     # time blocked on results instead of encoding PNGs)
-                    if len(inflight) >= 2:
+                    if len(inflight) >= max(2, len(lanes)):
                         inflight.popleft().synchronize()
                     x, keys, gt, nh, nw, w, t_prep = nxt
                     t0 = time.time()
@@ -334,21 +341,28 @@ class Inference:
                     # model's prefetch stream before this window's fuse-and-decode graph is queued, so they run underneath it
                     nxt = prepare(k + 1) if k + 1 < len(wins) else None
                     t1 = time.time()
-                    if a.reuse and nxt is not None:
-                        self.net.prefetch_window(nxt[0], nxt[1], enc_cache, zero_ref=bool(nxt[5]["zero_pre"]))
-                    if a.reuse:
-                        out = self.net.forward_window(x, keys, enc_cache, zero_ref=bool(w["zero_pre"]))
-                    else:
-                        out = self.net(x, routing=[bool(w["zero_pre"])])
-                    # tensor2numpy, the finite check (half operands do not saturate: the worker looks at it), PSNR and SSIM on the
-                    # 4-pixel-cropped frame (inference_SPEINet.py:405-410): three HIP launches (csrc/metrics.hip)
                     gt_u8 = gt[:nh, :nw].contiguous()
-                    out_u8, met = ops.frame_post(out[0], gt_u8, 4)
-                    slot = self._result_slot(out_u8.shape)
-                    slot["out"].copy_(out_u8, non_blocking=True)
-                    slot["met"].copy_(met, non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record()
+                    lane = lanes[k % len(lanes)]
+                    if lane is not home:
+                        lane.wait_stream(home)                 # the window's inputs were assembled on the home stream
+                    with torch.cuda.stream(lane):
+                        for t_ in (x, gt_u8):
+                            t_.record_stream(lane)
+                        if a.reuse and nxt is not None:
+                            nxt[0].record_stream(lane)
+                            self.net.prefetch_window(nxt[0], nxt[1], enc_cache, zero_ref=bool(nxt[5]["zero_pre"]))
+                        if a.reuse:
+                            out = self.net.forward_window(x, keys, enc_cache, zero_ref=bool(w["zero_pre"]))
+                        else:
+                            out = self.net(x, routing=[bool(w["zero_pre"])])
+                        # tensor2numpy, the finite check (half operands do not saturate: the worker looks at it), PSNR and SSIM on the
+                        # 4-pixel-cropped frame (inference_SPEINet.py:405-410): three HIP launches (csrc/metrics.hip)
+                        out_u8, met = ops.frame_post(out[0], gt_u8, 4)
+                        slot = self._result_slot(out_u8.shape)
+                        slot["out"].copy_(out_u8, non_blocking=True)
+                        slot["met"].copy_(met, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record()
                     inflight.append(ev)
                     t2 = time.time()
                     save_to = os.path.join(a.result_path, clip, w["name"] + ".png") if a.save_image else ""
@@ -388,7 +402,7 @@ def synth_clip(root: str, n: int = 40, h: int = 720, w: int = 1280, seed: int = 
     return os.path.join(root, "data")
 
 
-def harness_throughput(frames: int = 100, precision: str = "f16", h: int = 720, w: int = 1280) -> dict:
+def harness_throughput(frames: int = 100, precision: str = "f16", h: int = 720, w: int = 1280, extra_args=()) -> dict:
     """End-to-end frames/s of this harness on a synthetic clip ON DISK: PNG decode -> selection -> upload -> forward (with
     cross-window encoder reuse) -> uint8 -> PSNR / SSIM -> PNG encode, everything the reference's loop does per frame
     (inference_SPEINet.py:364-429).  One untimed pass first (graph capture, page cache), then one timed pass."""
@@ -398,7 +412,8 @@ def harness_throughput(frames: int = 100, precision: str = "f16", h: int = 720, 
     root = tempfile.mkdtemp(prefix="speinet_clip_")
     try:
         data = synth_clip(root, frames, h, w)
-        a = build_args(["--data_path", data, "--model_path", "synthetic", "--result_path", os.path.join(root, "res"), "--precision", precision])
+        a = build_args(["--data_path", data, "--model_path", "synthetic", "--result_path", os.path.join(root, "res"), "--precision", precision,
+                        *extra_args])
         inf = Inference(a)
         inf.logger.echo = False
         inf.infer()
@@ -443,7 +458,13 @@ def build_args(argv=None):
     p.add_argument("--prefetch", type=int, default=4, help="windows decoded ahead of the GPU")
     p.add_argument("--no_reuse", dest="reuse", action="store_false", default=True,
                    help="recompute every encoder pass per window instead of reusing the per-frame results of overlapping windows")
-    p.add_argument("--streams", type=int, default=2, help="HIP streams for the independent branches of a frame")
+    p.add_argument("--streams", type=int, default=1,
+                   help="HIP streams for the independent branches of a frame (round 4: 1 — the frame's Swin calls run as one batch, the "
+                        "second in-frame stream has nothing left to carry, and every extra stream competes for the 4 hardware queues)")
+    p.add_argument("--lanes", type=int, default=2,
+                   help="windows in flight: consecutive windows of a clip alternate over this many launch streams (2: +4.6 %% over 1 on a "
+                        "100-frame 720p clip; 3 and 4 measured 8-25 %% SLOWER — three window graphs, the prefetch stream's encoder "
+                        "passes and two correlation kernels at a time leave every kernel a third of the chip)")
     p.add_argument("--no_graph", dest="graph", action="store_false", default=True, help="launch kernels eagerly (no hipGraph replay)")
     p.add_argument("--n_GPUs", type=int, default=1,
                    help="ranks, one per GPU, clips sharded over them (the reference's preset attribute n_GPUs, inference_SPEINet.py:626-697, "

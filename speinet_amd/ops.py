@@ -250,7 +250,7 @@ class Ctx:
     _FIELDS = ("precision", "corr_precision", "device", "use_slab", "bf16_storage", "x1_bf16", "fuse_mlp", "fuse_attn",
                "fuse_block", "commute_upconv", "commute_any", "corr_bf16", "corr_diag", "fuse_apply", "split_decode", "batch_enc", "mlp_ws", "attn_win4", "stage", "profile", "capture")
     # stages of an f16 frame that run in split (bf16x3) arithmetic by default, see `split_decode`
-    SPLIT_STAGES = ("glue", "glue1", "dec2")
+    SPLIT_STAGES = ("glue", "dec2")
     __slots__ = _FIELDS
 
     def __init__(self, precision: str = "f32", corr_precision: str = "bf16x3", device=None, use_slab: bool = True,

@@ -407,12 +407,15 @@ class SPEINet(nn.Module):
                          lambda: G(("sum", iters, h, w), [x[0, i], raw(i)], lambda fr, e: [engine.encode_sum(ctx, fr, iters, e, P)])[0])
 
         with torch.cuda.stream(pf):
-            f_mid = summed(mid, 5)
-            feats = [summed(i, 1) for i in range(n) if i != mid]
-            lv = None
-            if not zero_ref:
-                lv = piece((tag, keys[n + 1], "ref"),
-                           lambda: tuple(G(("pyr", h, w), [x[0, n + 1]], lambda fr: list(engine.reference_pyramid(ctx, fr, P)))))
+            if ctx.for_stage("enc").batched_available():
+                f_mid, feats, lv = self._window_pieces_batched(ctx, x, keys, cache, zero_ref, P, tag, G, pf, used)
+            else:
+                f_mid = summed(mid, 5)
+                feats = [summed(i, 1) for i in range(n) if i != mid]
+                lv = None
+                if not zero_ref:
+                    lv = piece((tag, keys[n + 1], "ref"),
+                               lambda: tuple(G(("pyr", h, w), [x[0, n + 1]], lambda fr: list(engine.reference_pyramid(ctx, fr, P)))))
         for f in [f_mid] + feats + list(lv or ()):   # produced on `pf`, consumed (and possibly freed by the cache) under `main`
             f.t.record_stream(main)
         if pieces_only:
@@ -423,7 +426,9 @@ class SPEINet(nn.Module):
         if not self.use_graph:
             engine.fuse_and_decode(ctx, f_mid, feats, lv, P, n, out[0], sides)
             return out
-        gkey = ("window", h, w, bool(zero_ref)) + self._mode_key(x.device)
+        # one captured instance per launch stream: a caller that keeps several windows in flight (inference.py) replays from several
+        # streams, and each needs its own static buffers
+        gkey = ("window", h, w, bool(zero_ref), torch.cuda.current_stream(x.device).cuda_stream) + self._mode_key(x.device)
         g = self._graphs.get(gkey)
         if g is None:
             from .ops import FMap
@@ -460,7 +465,71 @@ class SPEINet(nn.Module):
         g2.replay()
         return s_out.clone()
 
-    def _trim_graphs(self, limit: int = 12) -> None:
+    def _window_pieces_batched(self, ctx, x, keys, cache, zero_ref, P, tag, G, pf, used):
+        """The encoder passes a window still misses — enc(frame), enc(RL_1(frame)), enc(RL_5(frame)), the sharp frame's pyramid — as ONE
+        batched pass (engine.enc_batched: one launch per layer for all of them; per map bit-identical to a pass of its own and to the
+        passes `forward` batches), then the sums enc(RL(frame)) + enc(frame).  Steady state of a clip: three maps per window (the new
+        frame raw and RL-1, the new middle frame RL-5), four when a new sharp frame arrives.  Cache keys, hit / miss accounting and the
+        results are those of the one-pass-at-a-time form."""
+        from .ops import FMap
+        h, w = x.shape[-2:]
+        h3, w3 = h // 4, w // 4
+        n, mid = self.n_sequence, self.n_sequence // 2
+        plan, have = [], {}          # plan: (cache key, frame index, RL iterations or 0, keep the three levels)
+
+        def lookup(key):
+            if key in have:
+                return have[key]
+            hit = cache.get(key)
+            if hit is not None:
+                used.append(hit)
+                have[key] = hit[0]
+            return have.get(key)
+
+        sums = [(mid, 5)] + [(i, 1) for i in range(n) if i != mid]
+        for i, it in sums:
+            if lookup((tag, keys[i], it)) is None:
+                if lookup((tag, keys[i], "raw")) is None and not any(pk == (tag, keys[i], "raw") for pk, *_ in plan):
+                    plan.append(((tag, keys[i], "raw"), i, 0, False))
+                if not any(pk == (tag, keys[i], ("rl", it)) for pk, *_ in plan):
+                    plan.append(((tag, keys[i], ("rl", it)), i, it, False))
+        if not zero_ref and lookup((tag, keys[n + 1], "ref")) is None:
+            plan.append(((tag, keys[n + 1], "ref"), n + 1, 0, True))
+        if plan:
+            sig = tuple((it, lv_) for _, _, it, lv_ in plan)
+
+            def run(*fr):
+                maps = [ctx.rl_prior(f, it, 0.01) if it else f for f, (_, _, it, _) in zip(fr, plan)]
+                lv1, lv2, lv3 = engine.enc_batched(ctx, maps, P)
+                outs = []
+                for j, (_, _, _, levels) in enumerate(plan):
+                    outs += [lv1.map(j), lv2.map(j), lv3.map(j)] if levels else [lv3.map(j)]
+                return outs
+
+            outs = iter(G(("pieces", sig, h, w), [x[0, i] for _, i, _, _ in plan], run))
+            ev = torch.cuda.Event()
+            made = {}
+            for pk, _, _, levels in plan:
+                made[pk] = tuple(next(outs) for _ in range(3)) if levels else next(outs)
+            for i, it in sums:                         # enc(RL_it(frame)) + enc(frame): the operand order of engine.forward_batch_steps
+                ks = (tag, keys[i], it)
+                if ks not in have:
+                    rl = made[(tag, keys[i], ("rl", it))]
+                    raw = made.get((tag, keys[i], "raw"))
+                    raw = raw if raw is not None else have[(tag, keys[i], "raw")]
+                    made[ks] = FMap(ctx.add(rl.t, raw.t), h3, w3, 128)
+            ev.record(pf)
+            for pk, v in made.items():
+                if not (isinstance(pk[2], tuple) and pk[2][0] == "rl"):      # the bare enc(RL(frame)) maps are not reused
+                    hit = cache.put(pk, (v, ev))
+                    used.append(hit)
+                    have[pk] = v
+        f_mid = have[(tag, keys[mid], 5)]
+        feats = [have[(tag, keys[i], 1)] for i in range(n) if i != mid]
+        lv = None if zero_ref else have[(tag, keys[n + 1], "ref")]
+        return f_mid, feats, lv
+
+    def _trim_graphs(self, limit: int = 24) -> None:
         if len(self._graphs) >= limit:
             torch.cuda.synchronize()           # a replay of one of them may still be running (other stream, earlier window)
             self._graphs.clear()

@@ -299,11 +299,13 @@ def test_forward_golden(golden_dir, net, name, b, h, w):
         assert dp <= 1e-3, f"PSNR delta {dp:.2e} dB"
 
 
-@pytest.mark.parametrize("h,w", [(60, 40), (100, 60), (60, 140)])
+@pytest.mark.parametrize("h,w", [(200, 120), (120, 200), (100, 300)])
 def test_forward_portrait_and_wide_vs_oracle(net, synth_sd, h, w):
     """Frame shapes the goldens do not hold — portrait (SelfTransfer's rotated reference map is LOWER than the query map there: the
     diagonal correlation kernel hands over to the slab kernel) and a wide strip — mixed batch (one sample per routing branch), against
-    the oracle run here on the CPU; the f16 / top2 throughput mode against the same output with its PSNR bound."""
+    the oracle run here on the CPU; the f16 / top2 throughput mode against the same output at the north-star bound of 1e-3 dB on BOTH
+    routing branches (round 3 allowed 2e-3 on 60x40 ... 60x140 frames, where one uint8 step moves the PSNR by that much; these frames
+    are large enough to carry the bound)."""
     x = synth_frames(2, h, w, seed=100 + h, zero_ref=(1,))
     ref = O.forward(x, synth_sd, O.Cfg())
     with torch.no_grad():
@@ -320,7 +322,7 @@ def test_forward_portrait_and_wide_vs_oracle(net, synth_sd, h, w):
     for i in range(2):
         tgt = O.to_uint8(x[i:i + 1, 1])
         dp = abs(O.psnr_uint8(O.to_uint8(out16[i:i + 1]), tgt) - O.psnr_uint8(O.to_uint8(ref[i:i + 1]), tgt))
-        assert dp <= 2e-3, f"sample {i}: PSNR delta {dp:.2e} dB"          # tiny frames: a handful of uint8 steps move the PSNR more than at 720p
+        assert dp <= 1e-3, f"sample {i}: PSNR delta {dp:.2e} dB"
 
 
 def test_forward_routing_argument(net):
