@@ -126,30 +126,6 @@ int spei_conv_slab16_fa(int fmt, const float* x, int K, const void* x1, const fl
 int spei_mlp_fused16(int fmt, const float* x, float* out, const void* w1_frag, const float* b1, const void* w2_frag,
                      const float* b2, int64_t M, spei_stream_t stream);
 
-/* The same MLP branch (model/swinir.py:12-29, :279) as a two-role pipeline (round 4): the hidden dimension moves through the
- * workgroup in four quarters; waves 0-3 compute fc1 + bias + GELU of quarter q into LDS while waves 4-7 accumulate fc2 over quarter
- * q - 1, so each SIMD's matrix pipe and vector ALU work at the same time; the fc2 accumulators start from x + b2 (residual loaded
- * straight into them) and are stored as they stand.  Arguments, layouts and aliasing rule as spei_mlp_fused16; the sums differ from
- * it in fp32 rounding only (the residual enters the fc2 sum first instead of last). */
-int spei_mlp_ws16(int fmt, const float* x, float* out, const void* w1_frag, const float* b1, const void* w2_frag,
-                  const float* b2, int64_t M, spei_stream_t stream);
-
-/* The same MLP branch, token-stationary (round 3, csrc/swin_tok16.hip): a wave keeps its 32 tokens in registers from the
- * LayerNorm to the residual store, every GEMM is computed transposed with the weights as the A operand out of a 4-slot LDS ring
- * that a 512-thread workgroup fills by LDS-DMA once per 256 tokens.  wstream: the block's fc1 / fc2 weights as ONE linear
- * stream of 1 KiB MFMA fragments in consumption order (speinet_amd/pack.py MlpStreamW: 16 chunks of [fc1 tile c: 16 k-steps |
- * fc2 n-tiles 0..7 x k-steps 2c, 2c+1], fc2's input channels in the order an accumulator tile presents them as an operand).
- * x, out: [M][256] fp32, may alias. */
-int spei_mlp_tok16(int fmt, const float* x, float* out, const void* wstream, const float* b1, const float* b2, int64_t M,
-                   spei_stream_t stream);
-
-/* The attention branch of spei_attn_fused16, token-stationary (round 3, csrc/swin_tok16.hip): a wave owns one 5x5 window from the
- * first load to the last store; Q^T, K^T, V, S^T, O^T and the projection's B operand never leave its registers; the weights arrive
- * through the LDS ring (wstream: speinet_amd/pack.py AttnStreamW, 16 chunks of 32 fragments).  relb28: [8][25][28] relative position
- * bias, key axis padded.  x, out: [H*W][256] fp32, must NOT alias; yhat as for spei_attn_fused16. */
-int spei_attn_tok16(int fmt, const float* x, float* out, const void* yhat, const void* wstream, const float* bq, const float* bkv,
-                    const float* bproj, const float* relb28, int H, int W, int shift, spei_stream_t stream);
-
 /* ConvTranspose2d(k = 3, stride 2, padding 1, output_padding 1) on the slab kernel (reference model/recons_video_ori.py:58-71,
  * the tails of decoder_second / decoder_first): the four output-parity classes are stride-1 convolutions over the input
  * grid with 1 / 2 / 2 / 4 taps, written with pixel stride 2.  wfrag<py><px>: fragment-ordered 16-bit weights of class
@@ -190,15 +166,6 @@ int spei_attn_win4_16(int fmt, const float* x, float* out, const void* yhat, con
 int64_t spei_frame_post_ws_doubles(int H, int W, int border);
 int spei_frame_post(const float* out_chw, const unsigned char* gt_hwc, unsigned char* out_hwc, int H, int W, int border,
                     double* ws, double* result, spei_stream_t stream);
-
-/* One whole cross-window Swin block (model/swinir.py:238-281) in a single persistent launch: the attention branch of
- * spei_attn_fused16 followed by the MLP branch of spei_mlp_fused16 on the same rows, x read once and written once, the
- * intermediate x1 = x + proj(...) never leaves the registers; groups of three windows per 512-thread workgroup, one
- * workgroup per CU.  Arguments as for the two kernels it replaces; x and out may alias. */
-int spei_swin_block16(int fmt, const float* x, float* out, const void* yhat, const void* wq_frag, const float* bq,
-                      const void* wkv_frag, const float* bkv, const void* wproj_frag, const float* bproj,
-                      const float* relbias, const void* w1_frag, const float* b1, const void* w2_frag, const float* b2,
-                      int H, int W, int shift, spei_stream_t stream);
 
 /* K3 — ResBlock gates (model/block.py:8-24 SE, 71-96 ZPool+AttentionGate1/2, 108-124 TripletAttention).
  * x1: conv2 output [H][W][C] stored as x1_fmt (SPEI_F32 / SPEI_BF16 / SPEI_F16).  Workspace `ws` floats: spei_gate_ws_floats(H,W,C).

@@ -35,13 +35,9 @@ SIGNATURES = {
     "spei_conv_slab16_fa": (I, [I, P, I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "spei_attn_fused16": (I, [I, P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
     "spei_attn_win4_16": (I, [I, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
-    "spei_swin_block16": (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
     "spei_conv5_out_slab16": (I, [I, P, I, I, P, P, P, I, I, P]),
     "spei_convt2_slab16": (I, [I, P, I, I, I, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "spei_mlp_fused16": (I, [I, P, P, P, P, P, P, L, P]),
-    "spei_mlp_ws16": (I, [I, P, P, P, P, P, P, L, P]),
-    "spei_mlp_tok16": (I, [I, P, P, P, P, P, L, P]),
-    "spei_attn_tok16": (I, [I, P, P, P, P, P, P, P, P, I, I, I, P]),
     "spei_split16": (I, [I, P, I, P, P, L, I, P]),
     "spei_corr_slab16": (I, [I, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P]),
     "spei_corr_slab_top2_16": (I, [I, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P]),

@@ -274,218 +274,6 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const MlpParams<LP> p) {
     SPEI_STAMP(p.stamps, 8);
 }
 
-// ---- round 4: the same branch as a two-role pipeline -------------------------------------------------------------------------------
-// In `mlp_fused_kernel` the eight waves walk the phases together: fc1 (matrix pipe), GELU (vector ALU), barrier, fc2 (matrix pipe) —
-// a CU's matrix pipe idles through every GELU and its vector ALUs through every GEMM (stamps: GEMMs 10.4 us, GELU 7.6 + the residual wait,
-// of a 27.6 us workgroup; 27 % MFMA busy).  Here the two waves of each SIMD take different ROLES and the hidden dimension moves through
-// them in four quarters of 128 channels:
-//     waves 0-3 (producers):  fc1^T of quarter q (32 hidden channels x 128 tokens each) -> bias (accumulator init) -> GELU -> LDS
-//     waves 4-7 (consumers):  fc2 partial product over quarter q-1 (64 output channels x 128 tokens each, K = 128)
-// one barrier per stage, the quarter buffers double-buffered: while a producer's GELU occupies a SIMD's vector ALU, its partner wave's
-// MFMAs occupy the matrix pipe, and the other way round.  The consumers start from acc = x + b2 (the residual is loaded straight into
-// the accumulators, in row chunks + a quad transpose, while the producers run stage 0) and store their accumulators as they stand:
-// no residual registers, no residual wait.  Weight traffic is unchanged (every fragment is fetched once per workgroup and feeds four
-// MFMAs); HBM traffic is unchanged.
-constexpr int HQ = 128;                             // hidden channels per stage
-constexpr int NQ = HID / HQ;                        // 4 stages
-constexpr int PH = 2 * HQ + 16;                     // row pitch of a quarter buffer (bytes)
-constexpr int RING2 = 3;                            // fc2 fragment pairs in flight per consumer wave
-
-template <typename LP>
-__global__ __launch_bounds__(512) void mlp_ws_kernel(const MlpParams<LP> p) {
-    typedef typename lpv<LP>::x8 lp8;
-    typedef typename lpv<LP>::x4 lp4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* sa = smem;                                       // [MT][PA]      normalised tokens
-    unsigned char* hb = smem + MT * PA;                             // [2][MT][PH]   hidden quarters (GELU output), double-buffered
-    float* bias1 = reinterpret_cast<float*>(smem + MT * PA + 2 * MT * PH);   // [512]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 31, fk = lane >> 5;
-    const int m0 = blockIdx.x * MT;
-    const int et = fr & 3, ecol = (fr >> 2) * 4;
-
-    SPEI_STAMP(p.stamps, 0);
-    bias1[tid] = p.b1[tid];
-
-    // ---- LayerNorm(256) of the 128 tokens -> sa (all eight waves; as mlp_fused_kernel) ------------------------------------------------
-    {
-        const int l16 = tid & 15, rsub = tid >> 4;
-        f32x4 xr[MT / 32][4];
-#pragma unroll
-        for (int b = 0; b < MT / 32; ++b) {
-            const int m = min(m0 + b * 32 + rsub, p.M - 1);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xr[b][j] = reinterpret_cast<const f32x4*>(p.x + (size_t)m * D)[l16 + 16 * j];
-        }
-#pragma unroll
-        for (int b = 0; b < MT / 32; ++b) {
-            const int r = b * 32 + rsub;
-            float s = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) s += (xr[b][j][0] + xr[b][j][1]) + (xr[b][j][2] + xr[b][j][3]);
-            const float mean = sum16(s) * (1.0f / 256.0f);
-            float ss = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                xr[b][j] -= mean;
-                ss += (xr[b][j][0] * xr[b][j][0] + xr[b][j][1] * xr[b][j][1]) + (xr[b][j][2] * xr[b][j][2] + xr[b][j][3] * xr[b][j][3]);
-            }
-            const float rstd = 1.0f / sqrtf(sum16(ss) * (1.0f / 256.0f) + 1e-5f);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                lp4 hv;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) hv[e] = to_lp<LP>(xr[b][j][e] * rstd);
-                *reinterpret_cast<lp4*>(sa + r * PA + (l16 + 16 * j) * 8) = hv;
-            }
-        }
-    }
-    const int rot = blockIdx.x & 15;                 // per-workgroup K rotation: spreads the L2 channel load of the weight stream
-
-    if (wave < 4) {
-        // ================================ producers: fc1^T -> GELU -> quarter buffer ================================
-        __builtin_amdgcn_s_setprio(1);               // the longer chain of a stage (64 MFMAs + the GELU) goes first on its SIMD
-        lp8 ring[RING];
-        const LP* wptr = p.w1 + (size_t)wave * 16 * 512 + lane * 8;          // hidden tile 4 q + wave, q = 0
-#pragma unroll
-        for (int d = 0; d < RING; ++d) ring[d] = *reinterpret_cast<const lp8*>(wptr + ((rot + d) & 15) * 512);
-        __syncthreads();                             // #0: token slab and bias1 complete
-        SPEI_STAMP(p.stamps, 1);
-        const unsigned char* abase = sa + fr * PA + fk * 16;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            f32x16 acc1[RT];                         // rows c = 8 g + 4 fk + e of the wave's 32 hidden channels, column = token fr
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias1 + q * HQ + wave * 32 + 8 * g + 4 * fk);
-#pragma unroll
-                for (int i = 0; i < RT; ++i)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc1[i][4 * g + e] = bv[e];
-            }
-            lp8 tn[RT];
-#pragma unroll
-            for (int i = 0; i < RT; ++i) tn[i] = *reinterpret_cast<const lp8*>(abase + i * 32 * PA + rot * 32);
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                lp8 tc[RT];
-#pragma unroll
-                for (int i = 0; i < RT; ++i) tc[i] = tn[i];
-                if (s + 1 < 16) {
-#pragma unroll
-                    for (int i = 0; i < RT; ++i) tn[i] = *reinterpret_cast<const lp8*>(abase + i * 32 * PA + ((rot + s + 1) & 15) * 32);
-                }
-                const lp8 w = ring[s % RING];
-                if (s + RING < 16) ring[s % RING] = *reinterpret_cast<const lp8*>(wptr + ((rot + s + RING) & 15) * 512);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < RT; ++i) acc1[i] = mfma16(w, tc[i], acc1[i]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (q + 1 < NQ) {                        // the next quarter's first fragments arrive under the GELU
-                wptr = p.w1 + (size_t)((q + 1) * 4 + wave) * 16 * 512 + lane * 8;
-#pragma unroll
-                for (int d = 0; d < RING; ++d) ring[d] = *reinterpret_cast<const lp8*>(wptr + ((rot + d) & 15) * 512);
-            }
-            unsigned char* hq = hb + (q & 1) * MT * PH;
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int i = 0; i < RT; ++i) {
-                    const f32x2 g01 = gelu2c(f32x2{acc1[i][4 * g], acc1[i][4 * g + 1]});
-                    const f32x2 g23 = gelu2c(f32x2{acc1[i][4 * g + 2], acc1[i][4 * g + 3]});
-                    lp4 hv;
-                    hv[0] = to_lp<LP>(g01[0]); hv[1] = to_lp<LP>(g01[1]); hv[2] = to_lp<LP>(g23[0]); hv[3] = to_lp<LP>(g23[1]);
-                    *reinterpret_cast<lp4*>(hq + (i * 32 + fr) * PH + (wave * 32 + 8 * g + 4 * fk) * 2) = hv;
-                }
-            SPEI_STAMP(p.stamps, 2 + q);
-            __syncthreads();                         // #(q + 1): quarter q is in hb[q & 1]
-        }
-    } else {
-        // ================================ consumers: acc = x + b2, then fc2 over the quarters ================================
-        const int u = wave - 4;                      // output channels [64 u, 64 u + 64)
-        f32x16 acc2[RT][2];
-#pragma unroll
-        for (int nn = 0; nn < 2; ++nn) {
-            const float bias = p.b2[u * 64 + nn * 32 + fr];
-#pragma unroll
-            for (int i = 0; i < RT; ++i)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int m = min(m0 + i * 32 + 8 * k + 4 * fk + et, p.M - 1);
-                    const f32x4 rv = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * D + u * 64 + nn * 32 + ecol);
-                    float a[4] = {rv[0], rv[1], rv[2], rv[3]};
-                    quad_transpose4(a[0], a[1], a[2], a[3], et);          // row chunks -> accumulator layout (the transpose is its own inverse)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc2[i][nn][4 * k + e] = a[e] + bias;
-                }
-        }
-        SPEI_STAMP_AT(p.stamps, 7, 256);
-        const int rot8 = rot & 7;
-        // fc2 fragment pairs: ONE ring over the 32 k-steps of the four quarters (slot = step % RING2; 8 is not a multiple of the ring
-        // depth), step t = 8 j + s reads k-step 8 j + ((rot8 + s) & 7); refills run RING2 steps ahead, across quarter boundaries —
-        // the weights depend on nothing
-        lp8 ring2[RING2][2];
-        const LP* wp2 = p.w2 + (size_t)(2 * u) * 32 * 512 + lane * 8;        // column tiles 2 u, 2 u + 1
-#pragma unroll
-        for (int d = 0; d < RING2; ++d)
-#pragma unroll
-            for (int nn = 0; nn < 2; ++nn) ring2[d][nn] = *reinterpret_cast<const lp8*>(wp2 + ((size_t)nn * 32 + ((rot8 + d) & 7)) * 512);
-        __syncthreads();                             // #0
-        __syncthreads();                             // #1: quarter 0 is in hb[0]
-        SPEI_STAMP_AT(p.stamps, 8, 256);
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) {
-            const unsigned char* hbase = hb + (j & 1) * MT * PH + fr * PH + fk * 16;
-            lp8 tn[RT];
-#pragma unroll
-            for (int i = 0; i < RT; ++i) tn[i] = *reinterpret_cast<const lp8*>(hbase + i * 32 * PH + rot8 * 32);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const int t = 8 * j + s, slot = t % RING2;
-                lp8 tc[RT];
-#pragma unroll
-                for (int i = 0; i < RT; ++i) tc[i] = tn[i];
-                if (s + 1 < 8) {
-#pragma unroll
-                    for (int i = 0; i < RT; ++i) tn[i] = *reinterpret_cast<const lp8*>(hbase + i * 32 * PH + ((rot8 + s + 1) & 7) * 32);
-                }
-                const lp8 w0 = ring2[slot][0], w1 = ring2[slot][1];
-                if (t + RING2 < 8 * NQ) {
-                    const int tn_ = t + RING2, ks = 8 * (tn_ / 8) + ((rot8 + (tn_ & 7)) & 7);
-#pragma unroll
-                    for (int nn = 0; nn < 2; ++nn) ring2[slot][nn] = *reinterpret_cast<const lp8*>(wp2 + ((size_t)nn * 32 + ks) * 512);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < RT; ++i) {
-                    acc2[i][0] = mfma16(tc[i], w0, acc2[i][0]);
-                    acc2[i][1] = mfma16(tc[i], w1, acc2[i][1]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            SPEI_STAMP_AT(p.stamps, 9 + j, 256);
-            if (j + 1 < NQ) __syncthreads();         // #(j + 2): quarter j + 1 is in hb[(j + 1) & 1]; the producers may overwrite hb[j & 1]
-        }
-        // ---- the accumulators hold x + b2 + fc2(...): quad transpose, 16-byte stores ----
-#pragma unroll
-        for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-            for (int i = 0; i < RT; ++i)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float a[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) a[e] = acc2[i][nn][4 * k + e];
-                    quad_transpose4(a[0], a[1], a[2], a[3], et);
-                    const int m = m0 + i * 32 + 8 * k + 4 * fk + et;
-                    if (m < p.M) *reinterpret_cast<f32x4*>(p.out + (size_t)m * D + u * 64 + nn * 32 + ecol) = f32x4{a[0], a[1], a[2], a[3]};
-                }
-        SPEI_STAMP_AT(p.stamps, 13, 256);
-    }
-}
-
 }  // namespace
 
 template <typename LP>
@@ -498,29 +286,6 @@ static int mlp_launch(const float* x, float* out, const void* w1, const float* b
     hipLaunchKernelGGL(mlp_fused_kernel<LP>, dim3(cdiv(M, MT)), dim3(512), lds, st, p);
     SPEI_CHECK_LAUNCH("spei_mlp_fused16");
     return 0;
-}
-
-template <typename LP>
-static int mlp_ws_launch(const float* x, float* out, const void* w1, const float* b1, const void* w2, const float* b2, int64_t M, hipStream_t st) {
-    MlpParams<LP> p;
-    p.x = x; p.out = out; p.w1 = (const LP*)w1; p.b1 = b1; p.w2 = (const LP*)w2; p.b2 = b2; p.M = (int)M;
-    p.stamps = spei_stamp_buffer();
-    const size_t lds = (size_t)MT * PA + (size_t)2 * MT * PH + HID * sizeof(float);
-    ensure_dyn_lds<&mlp_ws_kernel<LP>>(lds);
-    hipLaunchKernelGGL(mlp_ws_kernel<LP>, dim3(cdiv(M, MT)), dim3(512), lds, st, p);
-    SPEI_CHECK_LAUNCH("spei_mlp_ws16");
-    return 0;
-}
-
-extern "C" int spei_mlp_ws16(int fmt, const float* x, float* out, const void* w1_frag, const float* b1, const void* w2_frag,
-                             const float* b2, int64_t M, spei_stream_t stream) {
-    SPEI_REQUIRE(x && out && w1_frag && b1 && w2_frag && b2 && M > 0, "spei_mlp_ws16: bad arguments");
-    SPEI_REQUIRE(fmt == SPEI_BF16 || fmt == SPEI_F16, "spei_mlp_ws16: fmt=%d", fmt);
-    SPEI_REQUIRE(M < (1ll << 31), "spei_mlp_ws16: too many tokens");
-    SPEI_REQUIRE(((uintptr_t)x | (uintptr_t)out | (uintptr_t)w1_frag | (uintptr_t)w2_frag) % 16 == 0, "spei_mlp_ws16: 16-byte alignment required");
-    hipStream_t st = (hipStream_t)stream;
-    if (fmt == SPEI_F16) return mlp_ws_launch<_Float16>(x, out, w1_frag, b1, w2_frag, b2, M, st);
-    return mlp_ws_launch<__bf16>(x, out, w1_frag, b1, w2_frag, b2, M, st);
 }
 
 extern "C" int spei_mlp_fused16(int fmt, const float* x, float* out, const void* w1_frag, const float* b1, const void* w2_frag,

@@ -102,10 +102,6 @@ def swin(ctx: Ctx, sx: SwinX, feat: FMap, sw: dict, out: FMap) -> FMap:
         for bi, bk in enumerate(layer["blocks"]):
             shift = 0 if bi % 2 == 0 else 2
             nxt = bufs[bi % 2]
-            if ctx.block_fused_available():
-                ctx.swin_block(cur, yhat, bk, h, w, shift, out=nxt)               # the whole block, one persistent kernel
-                cur = nxt
-                continue
             if ctx.attn_fused_available():
                 ctx.attn_fused(cur, yhat, bk, h, w, shift, out=nxt)               # whole attention branch, one kernel
             else:

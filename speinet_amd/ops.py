@@ -209,10 +209,6 @@ class Ctx:
       x1_bf16         16-bit: the ResBlock's conv2 output (read by the gate statistics and the apply pass) is 16-bit
       fuse_mlp        16-bit: LayerNorm -> fc1 -> GELU -> fc2 -> +x in one kernel (mlp_fused16.hip)
       fuse_attn       16-bit: LayerNorm -> q/kv GEMMs -> window attention -> proj -> +x in one kernel (attn_fused16.hip)
-      fuse_block      (default OFF) 16-bit, with fuse_mlp and fuse_attn: the whole Swin block as ONE persistent launch
-                      (swin_block16.hip).  Correct and tested, but measured slower than the two launches it replaces (150 vs
-                      133-142 us per block at 720p, and as a 1-workgroup-per-CU kernel it shuts out the other stream's
-                      kernels: 32.9 vs 30.7 ms per frame) — kept as the base for cross-group prefetching, DESIGN.md §6
       commute_upconv  16-bit: relu(conv1x1(bicubic_up(x))) evaluated as relu(bicubic_up(conv1x1(x)))
       commute_any     (default OFF) the same in every arithmetic mode: set by stage overrides that run single layers of a 16-bit
                       frame in split arithmetic (the f32-grade MODES keep the reference's order of operations)
@@ -228,8 +224,6 @@ class Ctx:
                       stages in ONE launch per layer (gridDim.y = pass; engine.enc_batched) instead of one launch per pass and layer:
                       bit-identical frames, ~1000 fewer launches per frame, and at H/4 a launch has 3150 workgroups instead of 450
                       (three resident rounds instead of half of one).  Off: round 2's per-pass launches on two streams
-      mlp_ws          (default OFF) 16-bit, with fuse_mlp: the fused MLP branch as a two-role pipeline (spei_mlp_ws16: fc1 + GELU producers
-                      and fc2 consumers sharing each SIMD).  Correct and tested; first measurement 66 vs 61.5 us per call at 720p
       attn_win4       16-bit, with fuse_attn: the fused attention branch with four windows per workgroup and a batch of maps per launch
                       (spei_attn_win4_16).  Off: round 2's two-window kernel, one map per launch (spei_attn_fused16)
       corr_bf16       "f16" with corr "top2": the candidate pass of the correlation runs on bf16 operands (True, default) instead of
@@ -248,15 +242,15 @@ class Ctx:
     ACT_NONE, ACT_RELU, ACT_GELU = ACT_NONE, ACT_RELU, ACT_GELU
     CONV, CONV_T = CONV, CONV_T
     _FIELDS = ("precision", "corr_precision", "device", "use_slab", "bf16_storage", "x1_bf16", "fuse_mlp", "fuse_attn",
-               "fuse_block", "commute_upconv", "commute_any", "corr_bf16", "corr_diag", "fuse_apply", "split_decode", "batch_enc", "mlp_ws", "attn_win4", "stage", "profile", "capture")
+               "commute_upconv", "commute_any", "corr_bf16", "corr_diag", "fuse_apply", "split_decode", "batch_enc", "attn_win4", "stage", "profile", "capture")
     # stages of an f16 frame that run in split (bf16x3) arithmetic by default, see `split_decode`
     SPLIT_STAGES = ("glue", "dec2")
     __slots__ = _FIELDS
 
     def __init__(self, precision: str = "f32", corr_precision: str = "bf16x3", device=None, use_slab: bool = True,
                  bf16_storage: bool = True, x1_bf16: bool = True, fuse_mlp: bool = True, fuse_attn: bool = True,
-                 fuse_block: bool = False, commute_upconv: bool = True, commute_any: bool = False, corr_bf16: bool = True,
-                 corr_diag: bool = True, fuse_apply: bool = False, split_decode: bool = True, batch_enc: bool = True, mlp_ws: bool = False,
+                 commute_upconv: bool = True, commute_any: bool = False, corr_bf16: bool = True,
+                 corr_diag: bool = True, fuse_apply: bool = False, split_decode: bool = True, batch_enc: bool = True,
                  attn_win4: bool = True, stage: Optional[dict] = None,
                  profile: Optional[dict] = None, capture: Optional[dict] = None):
         if precision not in PRECISIONS:
@@ -276,8 +270,8 @@ class Ctx:
         object.__setattr__(self, "corr_precision", corr_precision)
         object.__setattr__(self, "device", device)
         for k, v in (("use_slab", use_slab), ("bf16_storage", bf16_storage), ("x1_bf16", x1_bf16), ("fuse_mlp", fuse_mlp),
-                     ("fuse_attn", fuse_attn), ("fuse_block", fuse_block), ("commute_upconv", commute_upconv), ("commute_any", commute_any),
-                     ("corr_bf16", corr_bf16), ("corr_diag", corr_diag), ("fuse_apply", fuse_apply), ("split_decode", split_decode), ("batch_enc", batch_enc), ("mlp_ws", mlp_ws), ("attn_win4", attn_win4)):
+                     ("fuse_attn", fuse_attn), ("commute_upconv", commute_upconv), ("commute_any", commute_any),
+                     ("corr_bf16", corr_bf16), ("corr_diag", corr_diag), ("fuse_apply", fuse_apply), ("split_decode", split_decode), ("batch_enc", batch_enc), ("attn_win4", attn_win4)):
             object.__setattr__(self, k, bool(v))
         object.__setattr__(self, "stage", dict(stage) if stage else {})
         object.__setattr__(self, "profile", profile)
@@ -575,23 +569,7 @@ class Ctx:
 
     def swin_multi_available(self) -> bool:
         """The Swin calls of a frame as one batch over stacked maps (engine.swin_multi): needs the batched attention kernel."""
-        return self.attn_fused_available() and self.attn_win4 and self.mlp_fused_available() and self.batched_kernels() and not self.fuse_block
-
-    def block_fused_available(self) -> bool:
-        return self.attn_fused_available() and self.mlp_fused_available() and self.fuse_block
-
-    @_family("swin")
-    def swin_block(self, x: torch.Tensor, yhat: torch.Tensor, bk: dict, H: int, W: int, shift: int, out: torch.Tensor) -> torch.Tensor:
-        """out = x1 + mlp(norm2(x1)), x1 = x + attention(norm1(x), yhat)  (reference model/swinir.py:238-281); in place when out is x."""
-        f = self.fmt
-        assert x.shape == (H * W, 256) and x.dtype == torch.float32 and out.shape == x.shape and out.dtype == torch.float32
-        assert yhat.shape == x.shape and yhat.dtype == LP_DTYPE[f]
-        tp = self._tp
-        _lib.check(_lib.lib().spei_swin_block16(f, tp(x), tp(out), tp(yhat), tp(bk["wq"].frag(f)), tp(bk["bq"]), tp(bk["wkv"].frag(f)),
-                                                tp(bk["bkv"]), tp(bk["wproj"].frag(f)), tp(bk["bproj"]), tp(bk["relbias"]),
-                                                tp(bk["w1"].frag(f)), tp(bk["b1"]), tp(bk["w2"].frag(f)), tp(bk["b2"]), H, W, shift,
-                                                self._stream()), "spei_swin_block16")
-        return out
+        return self.attn_fused_available() and self.attn_win4 and self.mlp_fused_available() and self.batched_kernels()
 
     @_family("swin")
     def attn_fused(self, x: torch.Tensor, yhat: torch.Tensor, bk: dict, H: int, W: int, shift: int, out: torch.Tensor) -> torch.Tensor:
@@ -621,28 +599,8 @@ class Ctx:
         assert tuple(w1.shape) == (1, 512, 256) and tuple(w2.shape) == (1, 256, 512)
         tp = self._tp
         f = self.fmt
-        fn = _lib.lib().spei_mlp_ws16 if self.mlp_ws else _lib.lib().spei_mlp_fused16
-        _lib.check(fn(f, tp(x), tp(out), tp(w1.frag(f)), tp(b1), tp(w2.frag(f)), tp(b2), x.shape[0], self._stream()), "spei_mlp_fused16")
-        return out
-
-    def attn_tok(self, x: torch.Tensor, yhat: torch.Tensor, bk: dict, H: int, W: int, shift: int, out: torch.Tensor) -> torch.Tensor:
-        """out = x + proj(window_attention(...)), token-stationary kernel (csrc/swin_tok16.hip); out must not be x."""
-        assert x.shape == (H * W, 256) and x.dtype == torch.float32 and out.shape == x.shape and out.dtype == torch.float32
-        assert out.data_ptr() != x.data_ptr()
-        f = self.fmt
-        assert yhat.shape == x.shape and yhat.dtype == LP_DTYPE[f]
-        tp = self._tp
-        ws = bk["attn_stream"]
-        _lib.check(_lib.lib().spei_attn_tok16(f, tp(x), tp(out), tp(yhat), tp(ws.stream(f)), tp(bk["bq"]), tp(bk["bkv"]), tp(bk["bproj"]),
-                                              tp(ws.relb28), H, W, shift, self._stream()), "spei_attn_tok16")
-        return out
-
-    def mlp_tok(self, x: torch.Tensor, ws, b1: torch.Tensor, b2: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-        """out = x + fc2(gelu(fc1(LN(x)))), token-stationary kernel (csrc/swin_tok16.hip); ws: pack.MlpStreamW; in place when out is x."""
-        assert x.shape[1] == 256 and x.dtype == torch.float32 and x.is_contiguous() and out.shape == x.shape and out.dtype == torch.float32
-        tp = self._tp
-        f = self.fmt
-        _lib.check(_lib.lib().spei_mlp_tok16(f, tp(x), tp(out), tp(ws.stream(f)), tp(b1), tp(b2), x.shape[0], self._stream()), "spei_mlp_tok16")
+        _lib.check(_lib.lib().spei_mlp_fused16(f, tp(x), tp(out), tp(w1.frag(f)), tp(b1), tp(w2.frag(f)), tp(b2), x.shape[0], self._stream()),
+                   "spei_mlp_fused16")
         return out
 
     def layernorm(self, x: torch.Tensor, g: Optional[torch.Tensor] = None, b: Optional[torch.Tensor] = None,

@@ -78,81 +78,6 @@ class PackedW:
         return self._ct[fmt]
 
 
-# A 32x32 f32 accumulator tile handed to the next MFMA as an operand (registers 8s..8s+7 -> k-step s) presents its rows in the
-# order  k = 16 s + 8 (j >> 2) + 4 h + (j & 3)  for element j of lane half h, where a natural operand holds k = 16 s + 8 h + j
-# (MI355X guide, "An accumulator tile as the next MFMA's operand").  A weight that multiplies such a tile is stored with its
-# input channels permuted to match: position 8 h + j of every 16-group takes channel ACC_K_ORDER[8 h + j].
-ACC_K_ORDER = [0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15]
-
-
-def acc_k_order(w: torch.Tensor) -> torch.Tensor:
-    """[..., K] -> the same weight with K re-ordered inside every group of 16 (see ACC_K_ORDER)."""
-    k = w.shape[-1]
-    idx = torch.arange(k, device=w.device)
-    return w[..., (idx // 16) * 16 + torch.tensor(ACC_K_ORDER, device=w.device)[idx % 16]]
-
-
-class MlpStreamW:
-    """fc1 [512][256] and fc2 [256][512] of one Swin block as the fragment stream spei_mlp_tok16 consumes: 16 chunks of 32
-    fragments (1 KiB each) = [fc1 hidden tile c: k-steps 0..15 | fc2 output tiles j = 0..7 x k-steps 2c, 2c+1 (accumulator k
-    order)]."""
-    __slots__ = ("w1", "w2", "_s")
-
-    def __init__(self, w1: torch.Tensor, w2: torch.Tensor, device):
-        self.w1 = w1.detach().to(device=device, dtype=torch.float32).reshape(512, 256).contiguous()
-        self.w2 = w2.detach().to(device=device, dtype=torch.float32).reshape(256, 512).contiguous()
-        self._s = {}
-
-    def stream(self, fmt: int) -> torch.Tensor:
-        if fmt not in self._s:
-            lp = LP_DTYPE[fmt]
-            f1 = _frag(self.w1.to(lp)[None]).reshape(16, 16, 512)                 # [hidden tile][k-step][lane x 8]
-            f2 = _frag(acc_k_order(self.w2).to(lp)[None]).reshape(8, 16, 2, 512)  # [out tile j][chunk c][s][lane x 8]
-            self._s[fmt] = torch.cat((f1, f2.permute(1, 0, 2, 3).reshape(16, 16, 512)), dim=1).contiguous()
-        return self._s[fmt]
-
-
-class AttnStreamW:
-    """The attention weights of one Swin block as the fragment stream spei_attn_tok16 consumes (16 chunks of 32 fragments): chunks
-    0-3 Wq (two heads each, 16 k-steps per head), 4-11 head h: Wk_h then Wv_h, 12-15 Wproj (two 32-channel output tiles each; its
-    input channels in accumulator order: it multiplies O^T tiles handed over from the accumulators).  `relb28`: the relative
-    position bias [8][25][25] with the key axis padded to 28 (16-byte rows for the lanes' 4-key groups)."""
-    __slots__ = ("wq", "wkv", "wp", "relb28", "_s")
-
-    def __init__(self, wq, wkv, wp, relbias, device):
-        f = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
-        self.wq, self.wkv, self.wp = f(wq).reshape(256, 256), f(wkv).reshape(512, 256), f(wp).reshape(256, 256)
-        rb = f(relbias).reshape(8, 25, 25)
-        self.relb28 = torch.cat((rb, torch.zeros(8, 25, 3, device=device)), dim=2).contiguous()
-        self._s = {}
-
-    def stream(self, fmt: int) -> torch.Tensor:
-        if fmt not in self._s:
-            lp = LP_DTYPE[fmt]
-            fq = _frag(self.wq.to(lp)[None]).reshape(8, 16, 512)                      # [head][k-step][lane x 8]
-            fkv = _frag(self.wkv.to(lp)[None]).reshape(16, 16, 512)                    # tiles 0-7 K heads, 8-15 V heads
-            fp = _frag(acc_k_order(self.wp).to(lp)[None]).reshape(8, 16, 512)          # [out tile][k-step = 2 head + s]
-            kv = torch.stack((fkv[:8], fkv[8:]), dim=1)                                # [head][K | V][16][512]
-            self._s[fmt] = torch.cat((fq.reshape(4, 32, 512), kv.reshape(8, 32, 512), fp.reshape(4, 32, 512)), dim=0).contiguous()
-        return self._s[fmt]
-
-
-class AttnStreamHost:
-    """Marker (host side of packing) -> AttnStreamW on the device."""
-    __slots__ = ("wq", "wkv", "wp", "relbias")
-
-    def __init__(self, wq, wkv, wp, relbias):
-        self.wq, self.wkv, self.wp, self.relbias = wq, wkv, wp, relbias
-
-
-class MlpStreamHost:
-    """Marker (host side of packing) -> MlpStreamW on the device."""
-    __slots__ = ("w1", "w2")
-
-    def __init__(self, w1, w2):
-        self.w1, self.w2 = w1, w2
-
-
 def conv_w(w: torch.Tensor) -> torch.Tensor:
     co, ci, kh, kw = w.shape
     return w.permute(2, 3, 0, 1).reshape(kh * kw, co, ci).contiguous()
@@ -210,9 +135,6 @@ def swin_block(sd: SD, p: str, heads: int, ws: int) -> dict:
         "wproj": G(sd[p + "attn.proj.weight"].contiguous()), "bproj": sd[p + "attn.proj.bias"],
         "w1": G((w1 * g2[None, :]).float().contiguous()), "b1": (w1 @ b2 + bb1).float(),
         "w2": G(sd[p + "mlp.fc2.weight"].contiguous()), "b2": sd[p + "mlp.fc2.bias"],
-        "attn_stream": AttnStreamHost((scale * wq * g1[None, :]).float().contiguous(), (wkv * g1[None, :]).float().contiguous(),
-                                      sd[p + "attn.proj.weight"].contiguous(), relb.float()),
-        "mlp_stream": MlpStreamHost((w1 * g2[None, :]).float().contiguous(), sd[p + "mlp.fc2.weight"].contiguous()),
         "relbias": relb.float(),
     }
 
@@ -220,10 +142,6 @@ def swin_block(sd: SD, p: str, heads: int, ws: int) -> dict:
 def _to_device(o, device):
     if isinstance(o, GemmW):
         return PackedW(o.t, device)
-    if isinstance(o, MlpStreamHost):
-        return MlpStreamW(o.w1, o.w2, device)
-    if isinstance(o, AttnStreamHost):
-        return AttnStreamW(o.wq, o.wkv, o.wp, o.relbias, device)
     if torch.is_tensor(o):
         return o.detach().to(device=device, dtype=torch.float32).contiguous()
     if isinstance(o, dict):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Time the Swin-block kernels alone at the 720p lv3 size (180x320 tokens): the fused attention branch, the fused MLP
-branch, and the whole block as one persistent kernel.  PREC=bf16|f16 (default f16)."""
+"""Time the Swin-block kernels alone at the 720p lv3 size (180x320 tokens): the fused attention branch (round 2's two-window kernel,
+one map; round 4's four-window kernel on one map and on the two stacked maps of a frame) and the fused MLP branch.  PREC=bf16|f16."""
 import os
 import sys
 
@@ -43,18 +43,9 @@ for shift in (0, 2):
     timeit(f"attn_fused (2 windows) shift={shift}", lambda: a2.attn_fused(x, yhat, bk, H, W, shift, out))
     timeit(f"attn_win4 1 map        shift={shift}", lambda: ops.attn_fused(x, yhat, bk, H, W, shift, out))
     timeit(f"attn_win4 2 maps       shift={shift}", lambda: ops.attn_fused(xx, yy, bk, H, W, shift, oo))
-out_b = torch.empty_like(x)
-for shift in (0, 2):
-    timeit(f"attn_tok   shift={shift}", lambda: ops.attn_tok(x, yhat, bk, H, W, shift, out_b))
-old, ws = ops.replace(mlp_ws=False), ops.replace(mlp_ws=True)
-timeit("mlp_fused (round 2 kernel)", lambda: old.mlp_fused(x, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out))
-timeit("mlp_ws (two-role pipeline)", lambda: ws.mlp_fused(x, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out))
-timeit("mlp_tok", lambda: ops.mlp_tok(x, bk["mlp_stream"], bk["b1"], bk["b2"], out))
+timeit("mlp_fused", lambda: ops.mlp_fused(x, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out))
 x2 = torch.randn(2 * H * W, 256, device=dev)
 out2 = torch.empty_like(x2)
-timeit("mlp_fused 2x tokens", lambda: old.mlp_fused(x2, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out2))
-timeit("mlp_ws    2x tokens", lambda: ws.mlp_fused(x2, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out2))
-timeit("mlp_tok   2x tokens", lambda: ops.mlp_tok(x2, bk["mlp_stream"], bk["b1"], bk["b2"], out2))
+timeit("mlp_fused 2x tokens", lambda: ops.mlp_fused(x2, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out2))
 for shift in (0, 2):
     timeit(f"attn + mlp shift={shift}", lambda: a2.mlp_fused(a2.attn_fused(x, yhat, bk, H, W, shift, out), bk["w1"], bk["b1"], bk["w2"], bk["b2"], out))
-    timeit(f"swin_block shift={shift}", lambda: ops.swin_block(x, yhat, bk, H, W, shift, out))

@@ -4,7 +4,7 @@ every workgroup stamps s_memtime (100 MHz-independent shader clock ticks) at pha
 passed through SPEI_STAMP_PTR.  Prints the median per-phase durations in microseconds (at the measured clock) and the spread
 of workgroup start / end times across the launch.
 
-    python tools/stamp_phases.py attn|mlp|mlptok|block      (block: the first of the three groups of every workgroup)
+    python tools/stamp_phases.py attn|attn4|mlp      (attn: round 2's two-window kernel; attn4: the four-window kernel on two stacked maps)
     python tools/stamp_phases.py conv1|conv2|conv3   (conv_slab: the 5x5 ResBlock conv at 720p level 1 / 2 / 3, f16 in and out;
                                                       stamps: 0 start, 1 slab staged, 2 barrier passed, 3 main loop done, 4 stored)
 """
@@ -53,16 +53,8 @@ def run():
         ops.replace(attn_win4=False).attn_fused(x, yhat, bk, H, W, 2, out)
     elif which == "attn4":
         ops.attn_fused(x2, yhat2, bk, H, W, 2, out2)
-    elif which == "block":
-        ops.swin_block(x, yhat, bk, H, W, 2, out)
-    elif which == "attntok":
-        ops.attn_tok(x, yhat, bk, H, W, 2, out)
-    elif which == "mlptok":
-        ops.mlp_tok(x, bk["mlp_stream"], bk["b1"], bk["b2"], out)
-    elif which == "mlpold":
-        ops.replace(mlp_ws=False).mlp_fused(x, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out)
     else:
-        ops.replace(mlp_ws=True).mlp_fused(x, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out)
+        ops.mlp_fused(x, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out)
 
 
 for _ in range(5):
