@@ -120,6 +120,15 @@ int spei_conv_slab16_fa(int fmt, const float* x, int K, const void* x1, const fl
                         float* x_out, const void* wfrag, const float* bias, void* out, int ldo, int out_fmt, int H, int W, int N,
                         int ksize, int act, spei_stream_t stream);
 
+/* 32 -> 32 channel 5x5 convolution (stride 1, zero padding 2), weight-stationary (round 4, csrc/conv32_ws16.hip): the two convs of a
+ * ResBlock at full resolution (model/block.py:26-47,127-131 in model/recons_video_ori.py:26-43 inBlock and :72-75 outBlock) — every wave
+ * keeps the layer's 50 weight fragments in registers for the whole launch, one persistent workgroup per CU walks over 16 x 32 pixel
+ * tiles of all `batch` maps and double-buffers the tiles' slabs in LDS.  a: [batch][H*W][32] fp32 or `fmt`; wfrag: the layer's weights
+ * in fragment order (as spei_conv_slab16 takes them); bias [32] or NULL; out: [batch][H*W][32] `fmt` or fp32, must not be `a`;
+ * act: SPEI_ACT_NONE / SPEI_ACT_RELU.  Same operand rounding as spei_conv_slab16, fp32 sums in (tap, channel) order. */
+int spei_conv32_ws16(int fmt, const void* a, int a_fmt, const void* wfrag, const float* bias, void* out, int out_fmt, int batch,
+                     int H, int W, int act, spei_stream_t stream);
+
 /* Fused Swin MLP branch (model/swinir.py:12-29 Mlp.forward + the `x + mlp(norm2(x))` tail of :279), 16-bit matrix pipe:
  * out = x + fc2(GELU(fc1(LayerNorm256(x)))), LayerNorm affine folded into w1/b1 (pack.py); w*_frag in MFMA fragment
  * order; the normalised tokens and the 512-wide hidden activations live only in LDS.  x, out: [M][256] fp32, may alias. */

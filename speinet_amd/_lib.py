@@ -32,6 +32,7 @@ SIGNATURES = {
     "spei_igemm_f32_batched": (I, [P, I, I, P, I, I, P, P, P, I, P, I, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "spei_igemm_bf16": (I, [P, I, I, P, I, I, P, P, P, P, I, P, I, P, I, I, I, I, I, I, I, I, I, I, P]),
     "spei_conv_slab16": (I, [I, P, I, I, P, I, I, I, P, P, P, P, I, I, P, I, P, I, I, I, I, I, I, I, I, I, I, P]),
+    "spei_conv32_ws16": (I, [I, P, I, P, P, P, I, I, I, I, I, P]),
     "spei_conv_slab16_fa": (I, [I, P, I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "spei_attn_fused16": (I, [I, P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
     "spei_attn_win4_16": (I, [I, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),

@@ -67,6 +67,20 @@ inline void ensure_dyn_lds(size_t lds) {
     }
 }
 
+// Compute units of the current device (cached per device): grid size of the persistent kernels.
+inline int spei_num_cus() {
+    static int have[32] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 32) return 256;
+    if (have[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        have[dev] = n;
+    }
+    return have[dev];
+}
+
 // ---- cross-lane reductions on the VALU (DPP + gfx950 permlane swaps): no LDS-pipe traffic, unlike __shfl_xor -------
 // (ds_bpermute; 12 of them per wave_sum made the LayerNorm / gate-statistics kernels LDS-instruction-bound)
 template <int CTRL>

@@ -226,6 +226,9 @@ class Ctx:
                       (three resident rounds instead of half of one).  Off: round 2's per-pass launches on two streams
       attn_win4       16-bit, with fuse_attn: the fused attention branch with four windows per workgroup and a batch of maps per launch
                       (spei_attn_win4_16).  Off: round 2's two-window kernel, one map per launch (spei_attn_fused16)
+      conv32_ws       16-bit: the 32 -> 32 channel 5x5 convolutions (the ResBlock convs at full resolution: inBlock, outBlock) on the
+                      weight-stationary persistent kernel (spei_conv32_ws16: the layer's 51 KB of weights live in each wave's registers, nothing
+                      streams from L2 in the main loop).  Off: the slab kernel, which runs these layers at its weight intake
       corr_bf16       "f16" with corr "top2": the candidate pass of the correlation runs on bf16 operands (True, default) instead of
                       f16.  The fp32 re-score decides the winner and S either way (G14: 16 more of 57600 positions differ, dPSNR
                       +1e-6 dB); bf16 operands let the chip hold a ~7 % higher MFMA clock on the slab kernel (tools/bench_corr.py); on the diagonal
@@ -242,7 +245,7 @@ class Ctx:
     ACT_NONE, ACT_RELU, ACT_GELU = ACT_NONE, ACT_RELU, ACT_GELU
     CONV, CONV_T = CONV, CONV_T
     _FIELDS = ("precision", "corr_precision", "device", "use_slab", "bf16_storage", "x1_bf16", "fuse_mlp", "fuse_attn",
-               "commute_upconv", "commute_any", "corr_bf16", "corr_diag", "fuse_apply", "split_decode", "batch_enc", "attn_win4", "stage", "profile", "capture")
+               "commute_upconv", "commute_any", "corr_bf16", "corr_diag", "fuse_apply", "split_decode", "batch_enc", "attn_win4", "conv32_ws", "stage", "profile", "capture")
     # stages of an f16 frame that run in split (bf16x3) arithmetic by default, see `split_decode`
     SPLIT_STAGES = ("glue", "dec2")
     __slots__ = _FIELDS
@@ -251,7 +254,7 @@ class Ctx:
                  bf16_storage: bool = True, x1_bf16: bool = True, fuse_mlp: bool = True, fuse_attn: bool = True,
                  commute_upconv: bool = True, commute_any: bool = False, corr_bf16: bool = True,
                  corr_diag: bool = True, fuse_apply: bool = False, split_decode: bool = True, batch_enc: bool = True,
-                 attn_win4: bool = True, stage: Optional[dict] = None,
+                 attn_win4: bool = True, conv32_ws: bool = True, stage: Optional[dict] = None,
                  profile: Optional[dict] = None, capture: Optional[dict] = None):
         if precision not in PRECISIONS:
             raise ValueError(f"unknown precision {precision!r}")
@@ -271,7 +274,7 @@ class Ctx:
         object.__setattr__(self, "device", device)
         for k, v in (("use_slab", use_slab), ("bf16_storage", bf16_storage), ("x1_bf16", x1_bf16), ("fuse_mlp", fuse_mlp),
                      ("fuse_attn", fuse_attn), ("commute_upconv", commute_upconv), ("commute_any", commute_any),
-                     ("corr_bf16", corr_bf16), ("corr_diag", corr_diag), ("fuse_apply", fuse_apply), ("split_decode", split_decode), ("batch_enc", batch_enc), ("attn_win4", attn_win4)):
+                     ("corr_bf16", corr_bf16), ("corr_diag", corr_diag), ("fuse_apply", fuse_apply), ("split_decode", split_decode), ("batch_enc", batch_enc), ("attn_win4", attn_win4), ("conv32_ws", conv32_ws)):
             object.__setattr__(self, k, bool(v))
         object.__setattr__(self, "stage", dict(stage) if stage else {})
         object.__setattr__(self, "profile", profile)
@@ -403,7 +406,13 @@ class Ctx:
                   ksize, stride, pad, mode, act, self._stream())
         srcs = (fp(a0), a0.ld, k0, fp(a1), a1.ld if a1 is not None else 0, k1)
         lib = _lib.lib()
-        if (mode == CONV_T and self.lp16 and self.use_slab and ksize == 3 and stride == 2 and a1 is None and residual is None
+        if (self.conv32_ws_available() and mode == CONV and ksize == 5 and stride == 1 and k0 == 32 and N == 32 and a1 is None
+                and residual is None and rowscale is None and not ln_input and act in (ACT_NONE, ACT_RELU) and w.fhi is not None
+                and (a0.ld, a0.off, out.ld, out.off) == (32, 0, 32, 0) and a0.t.data_ptr() != out.t.data_ptr()):
+            # the 32-channel 5x5 layers: weight-stationary persistent kernel (csrc/conv32_ws16.hip)
+            _lib.check(lib.spei_conv32_ws16(self.fmt, fp(a0), a0.fmt, tp(w.frag(self.fmt)), tp(bias), fp(out), out.fmt, 1, a0.H, a0.W, act,
+                                            self._stream()), "spei_conv32_ws16")
+        elif (mode == CONV_T and self.lp16 and self.use_slab and ksize == 3 and stride == 2 and a1 is None and residual is None
                 and rowscale is None and N % 32 == 0 and k0 % 32 == 0):
             # stride-2 transposed conv = four stride-1 convs (one per output parity) on the slab kernel
             cf = w.convT_class_frags(self.fmt)
@@ -502,6 +511,10 @@ class Ctx:
         """One launch per layer for all maps of a BMap (the frame's encoder passes): the single-product 16-bit modes on the slab kernel."""
         return self.batched_kernels() and self.x1_bf16 and self.bf16_storage and not self.fuse_apply and self.batch_enc
 
+    def conv32_ws_available(self) -> bool:
+        """The weight-stationary kernel for 32 -> 32 channel 5x5 layers (single-product 16-bit modes)."""
+        return self.lp16 and self.use_slab and self.conv32_ws
+
     def batched_kernels(self) -> bool:
         """`igemm_batched` can run (what the batched Swin calls need; `batch_enc` only decides about the encoder passes)."""
         return self.lp16 and self.use_slab
@@ -522,6 +535,11 @@ class Ctx:
             assert (residual.B, residual.H, residual.W, residual.C) == (a.B, ho, wo, N) and residual.t.dtype == torch.float32
             assert residual.t.data_ptr() != a.t.data_ptr()
         tp = self._tp
+        if (self.conv32_ws_available() and ksize == 5 and stride == 1 and a.C == 32 and N == 32 and residual is None
+                and act in (ACT_NONE, ACT_RELU)):
+            _lib.check(_lib.lib().spei_conv32_ws16(self.fmt, tp(a.t), a.fmt, tp(w.frag(self.fmt)), tp(bias), tp(out.t), out.fmt, a.B, a.H, a.W,
+                                                   act, self._stream()), "spei_conv32_ws16")
+            return out
         _lib.check(_lib.lib().spei_conv_slab16_batched(self.fmt, tp(a.t), a.C, a.fmt, tp(w.frag(self.fmt)), _vp(0), tp(bias), tp(out.t), out.fmt,
                                                        tp(residual.t) if residual is not None else _vp(0), a.B, a.H, a.W, ho, wo, N, ksize,
                                                        stride, pad, act, self._stream()),

@@ -65,6 +65,42 @@ def test_igemm_conv(mode, cin, cout, k, stride, h, w):
     assert e < TOL[mode], f"{mode}: rel err {e:.2e}"
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("h,w,batch", [(16, 32, 1), (20, 36, 1), (37, 50, 3), (5, 7, 2), (48, 160, 2), (180, 320, 1)])
+def test_conv32_weight_stationary(mode, h, w, batch):
+    """The weight-stationary 32 -> 32 channel 5x5 kernel (csrc/conv32_ws16.hip: the ResBlock convs at full resolution) against the
+    float64 convolution and against the slab kernel it replaces (same operand rounding, other summation order): whole and ragged
+    tiles, maps smaller than a tile, several maps per launch (each as it comes out alone), fp32 and 16-bit inputs and outputs, ReLU."""
+    from speinet_amd.ops import BMap
+    ops, slab = Ctx(mode, device=DEV), Ctx(mode, device=DEV, conv32_ws=False)
+    lp = LPD[mode]
+    x = rnd(70 + h, batch, 32, h, w)
+    wt = rnd(71, 32, 32, 5, 5, scale=1.0 / np.sqrt(32 * 25))
+    b = rnd(72, 32, scale=0.1)
+    pw = pack.PackedW(pack.conv_w(wt), DEV)
+    rows = x.permute(0, 2, 3, 1).reshape(batch * h * w, 32).contiguous().to(DEV)
+    for in16 in (False, True):
+        xin = rows.to(lp) if in16 else rows
+        xr = xin.float().view(batch, h, w, 32).permute(0, 3, 1, 2).cpu()               # what the kernel sees
+        for relu in (False, True):
+            ref = F.conv2d(xr.double(), wt.double(), b.double(), padding=2)
+            ref = (F.relu(ref) if relu else ref).float()
+            act = ops.ACT_RELU if relu else ops.ACT_NONE
+            for o16 in (True, False):
+                odt = lp if o16 else torch.float32
+                out = ops.igemm_batched(BMap(xin, batch, h, w, 32), pw, b.to(DEV), 32, 5, act=act, out_dtype=odt)
+                got = out.t.float().view(batch, h, w, 32).permute(0, 3, 1, 2)
+                e = relerr(got, ref)
+                assert e < TOL[mode], f"{mode} in16={in16} relu={relu} o16={o16}: rel err {e:.2e}"
+                old = slab.igemm_batched(BMap(xin, batch, h, w, 32), pw, b.to(DEV), 32, 5, act=act, out_dtype=odt)
+                assert relerr(out.t.float(), old.t.float()) < TOL[mode]
+                one = ops.igemm(FMap(xin[:h * w], h, w, 32), pw, b.to(DEV), 32, ksize=5, act=act, out_dtype=odt)   # map 0 alone
+                assert torch.equal(one.t, out.t[:h * w])
+                if batch > 1:
+                    last = ops.igemm(FMap(xin[-h * w:].contiguous(), h, w, 32), pw, b.to(DEV), 32, ksize=5, act=act, out_dtype=odt)
+                    assert torch.equal(last.t, out.t[-h * w:])
+
+
 @pytest.mark.parametrize("mode", ["bf16x3", "bf16", "f16"])
 def test_igemm_concat_transpose_epilogue(mode):
     ops = Ctx(mode, device=DEV)
@@ -594,6 +630,7 @@ def test_fused_apply_matches_separate_apply(synth_sd, mode):
     for prefix, h, w, c in (("recons_net.inBlock.", 44, 70, 32), ("recons_net.encoder_first.", 37, 33, 64), ("recons_net.encoder_second.", 20, 45, 128)):
         blocks = [pack._to_device(pack.resblock(synth_sd, f"{prefix}{i}."), DEV) for i in (1, 2, 3)]
         x = FMap(torch.randn(h * w, c, generator=gen).to(DEV), h, w, c)
-        a = engine._resblocks(Ctx(mode, device=DEV, fuse_apply=True), x, blocks)
-        b = engine._resblocks(Ctx(mode, device=DEV, fuse_apply=False), x, blocks)
+        # (both on the slab kernel: the fused staging is a form of it; the 32-channel default, the weight-stationary kernel, sums in another order)
+        a = engine._resblocks(Ctx(mode, device=DEV, fuse_apply=True, conv32_ws=False), x, blocks)
+        b = engine._resblocks(Ctx(mode, device=DEV, fuse_apply=False, conv32_ws=False), x, blocks)
         assert torch.equal(a.t, b.t), (prefix, h, w, (a.t - b.t).abs().max().item())

@@ -37,6 +37,13 @@ x2, yhat2 = torch.randn(2 * H * W, 256, device=dev), torch.randn(2 * H * W, 256,
 out2 = torch.empty_like(x2)
 
 
+if which.startswith("ws"):            # the weight-stationary 32-channel kernel on 7 stacked 720p maps: ws32 (fp32 in) / ws16 (16-bit in)
+    from speinet_amd.ops import BMap                                   # noqa: E402
+    wx = torch.randn(7 * 720 * 1280, 32, device=dev)
+    wx = wx.half() if which == "ws16" else wx
+    wbm = BMap(wx, 7, 720, 1280, 32)
+    wpw = pack.PackedW(torch.randn(25, 32, 32) * 0.03, dev)
+    wb = torch.randn(32, device=dev)
 if which.startswith("conv"):
     from speinet_amd.ops import FMap                                   # noqa: E402
     ch, hh, ww = {"conv1": (32, 720, 1280), "conv2": (64, 360, 640), "conv3": (128, 180, 320)}[which]
@@ -47,7 +54,9 @@ if which.startswith("conv"):
 
 
 def run():
-    if which.startswith("conv"):
+    if which.startswith("ws"):
+        ops.igemm_batched(wbm, wpw, wb, 32, 5, act=1, out_dtype=torch.float16)
+    elif which.startswith("conv"):
         ops.igemm(cx, cw, cb, ch, ksize=5, out=cout)
     elif which == "attn":
         ops.replace(attn_win4=False).attn_fused(x, yhat, bk, H, W, 2, out)
