@@ -334,6 +334,28 @@ int spei_resblock_apply_bwd_batched(const float* dout, const float* x1, const fl
                                     const float* d_colmax, const float* d_colmean, const float* d_mean, float* dx1, int batch, int H,
                                     int W, int C, spei_stream_t stream);
 
+/* The gate maps of a ResBlock from its plane statistics, forward and backward, for the training step (model/block.py:8-24 SEBlock,
+ * :49-68 BasicConv1 = 2->1 conv + BatchNorm2d(1), :75-96 AttentionGate1/2, :116-119 TripletAttention) — BatchNorm on batch statistics
+ * with its running buffers moved (momentum 0.01, unbiased variance) when bn_train, on the running statistics otherwise:
+ *   s [N][C] = sigmoid(W2 relu(W1 mean + b1) + b2);  g1 [N][H][C] = BN(conv7x7([rowmax, rowmean]));  g2 [N][W][C] = BN(conv5x5([colmax^T,
+ *   colmean^T]))^T.   N = groups x B samples, BatchNorm statistics per group of B consecutive samples, running buffers moved once per
+ * group in group order.  prm: HOST array of 10 device pointers se_w1 [C/4][C], se_b1, se_w2 [C][C/4], se_b2, cw_w [2][7][7], cw_g, cw_b,
+ * hc_w [2][5][5], hc_g, hc_b; run: HOST array of 4 device pointers cw_rm, cw_rv, hc_rm, hc_rv (scalars).  saved
+ * (spei_gate_train_saved_floats): what the backward needs (conv outputs, SE hidden layer, the statistics used); ws
+ * (spei_gate_train_ws_floats floats, 8-byte aligned).  The backward returns the gradients of the five statistics and of the ten
+ * parameters packed in prm order (spei_gate_train_nparams floats).  float64 sums in a fixed order: bitwise reproducible. */
+int64_t spei_gate_train_saved_floats(int N, int groups, int H, int W, int C);
+int64_t spei_gate_train_ws_floats(int N, int groups, int H, int W, int C);
+int spei_gate_train_nparams(int C);
+int spei_gate_maps_fwd(const float* rowmax, const float* rowmean, const float* colmax, const float* colmean, const float* mean,
+                       const float* const* prm, float* const* run, int N, int groups, int H, int W, int C, int bn_train,
+                       int update_running, float* s, float* g1, float* g2, float* saved, float* ws, spei_stream_t stream);
+int spei_gate_maps_bwd(const float* rowmax, const float* rowmean, const float* colmax, const float* colmean, const float* mean,
+                       const float* const* prm, float* const* run, int N, int groups, int H, int W, int C, int bn_train,
+                       const float* s, const float* saved, const float* ds, const float* dg1, const float* dg2, float* d_rowmax,
+                       float* d_rowmean, float* d_colmax, float* d_colmean, float* d_mean, float* dprm, float* ws,
+                       spei_stream_t stream);
+
 /* ---- backward of the cross-window-attention SwinIR blocks (model/swinir.py:238-281 under loss.backward(), the training step of
  * trainer/trainer_swint.py:34-44).  fp32; fixed-order reductions. ---- */
 

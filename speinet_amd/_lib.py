@@ -73,6 +73,11 @@ SIGNATURES = {
     "spei_plane_stats_batched": (I, [P, P, I, I, I, I, P, P, P, P, P, P, I, P]),
     "spei_resblock_apply_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
     "spei_resblock_apply_bwd_batched": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "spei_gate_train_saved_floats": (L, [I, I, I, I, I]),
+    "spei_gate_train_ws_floats": (L, [I, I, I, I, I]),
+    "spei_gate_train_nparams": (I, [I]),
+    "spei_gate_maps_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P, P, P, P]),
+    "spei_gate_maps_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "spei_ln_bwd_blocks": (L, [L]),
     "spei_layernorm256_bwd": (I, [P, P, P, P, P, L, P]),
     "spei_gelu_fwd": (I, [P, P, L, P]),

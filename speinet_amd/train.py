@@ -555,54 +555,27 @@ class _SearchTransfer(torch.autograd.Function):
 
 
 # ---- the ResBlock's gated residual sum, batch form, BatchNorm(1) in either mode -------------------------------------------------
-def _gate_maps(rowmax, rowmean, colmax, colmean, mean, prm, bn_train: bool, update_running: bool):
-    """s [B,C], g1 [B,H,C], g2 [B,W,C] from the plane statistics (model/block.py:8-24 SE, :75-96 the two gates without their
-    sigmoid, :49-68 BasicConv1 = 2->1 conv + BatchNorm2d(1); TripletAttention sums the gates, :116-119).  prm: se_w1, se_b1, se_w2,
-    se_b2, cw_w, cw_bn_w, cw_bn_b, cw_rm, cw_rv, hc_w, hc_bn_w, hc_bn_b, hc_rm, hc_rv.  bn_train: normalise with the batch
-    statistics; update_running: also move the running buffers (momentum 0.01), as nn.BatchNorm2d.forward does in train()."""
-    se_w1, se_b1, se_w2, se_b2, cw_w, cw_g, cw_b, cw_rm, cw_rv, hc_w, hc_g, hc_b, hc_rm, hc_rv = prm
-    s = torch.sigmoid(F.linear(F.relu(F.linear(mean, se_w1, se_b1)), se_w2, se_b2))
-
-    def bn(t, g, b, rm, rv):
-        # nn.BatchNorm2d(1, eps 1e-5, momentum 0.01) written out (plain tensor arithmetic: no library batch-norm kernels to
-        # compile per shape): train() normalises with the biased batch variance and moves the buffers with the unbiased one
-        if not bn_train:
-            return (t - rm) / torch.sqrt(rv + 1e-5) * g + b
-        mean = t.mean()
-        var = ((t - mean) ** 2).mean()
-        if update_running:
-            with torch.no_grad():
-                n = t.numel()
-                rm.mul_(1.0 - 0.01).add_(0.01 * mean)
-                rv.mul_(1.0 - 0.01).add_(0.01 * var * (n / max(n - 1, 1)))
-        return (t - mean) / torch.sqrt(var + 1e-5) * g + b
-
-    def conv21(z, w, k):
-        # the 2 -> 1 channel k x k convolution as unfold + one matrix product: the library convolution's weight gradient is not
-        # bitwise reproducible for these shapes (atomics), this form is
-        # torch's im2col runs one launch per batch element (60 maps per ResBlock at batch 20: 2 900 launches per step): the batch is laid out
-        # as ONE tall map, each sample between its own zero rows, so the whole batch is one unfold and one product
-        bsz, _, a, b = z.shape
-        pd = k // 2
-        tall = F.pad(z, (0, 0, pd, pd)).permute(1, 0, 2, 3).reshape(1, 2, bsz * (a + 2 * pd), b)
-        cols = F.unfold(tall, k, padding=(0, pd))                              # [1, 2 k k, (bsz (a + 2 pd) - k + 1) * b]
-        out = (w.reshape(1, -1) @ cols).view(bsz * (a + 2 * pd) - 2 * pd, b)
-        out = F.pad(out, (0, 0, 0, 2 * pd)).view(bsz, a + 2 * pd, b)[:, :a]     # row r of sample i sits at i (a + 2 pd) + r
-        return out.reshape(bsz, 1, a, b)
-
-    z1 = torch.stack((rowmax, rowmean), dim=1)                              # [B, 2, H, C]: conv "height" = H, "width" = C
-    g1 = bn(conv21(z1, cw_w, 7), cw_g, cw_b, cw_rm, cw_rv)[:, 0]            # [B, H, C]
-    z2 = torch.stack((colmax.transpose(1, 2), colmean.transpose(1, 2)), dim=1)   # [B, 2, C, W]: conv "height" = C, "width" = W
-    g2 = bn(conv21(z2, hc_w, 5), hc_g, hc_b, hc_rm, hc_rv)[:, 0].transpose(1, 2)  # [B, W, C]
-    return s.contiguous(), g1.contiguous(), g2.contiguous()
+def _gate_ptrs(ctx: Ctx, params):
+    """(prm, run) pointer arrays of spei_gate_maps_fwd / _bwd from the 14 gate parameters of a ResBlock, and the tensors they point to
+    (kept alive by the caller): se_w1, se_b1, se_w2, se_b2, cw_w, cw_g, cw_b, cw_rm, cw_rv, hc_w, hc_g, hc_b, hc_rm, hc_rv."""
+    t = [q.detach() for q in params]
+    t = [q if q.is_contiguous() else q.contiguous() for q in t]
+    assert all(q.dtype == torch.float32 and q.device == ctx.device for q in t)
+    order = (0, 1, 2, 3, 4, 5, 6, 9, 10, 11)
+    prm = (C.c_void_p * 10)(*[q.data_ptr() for q in (t[i] for i in order)])
+    run = (C.c_void_p * 4)(*[t[i].data_ptr() for i in (7, 8, 12, 13)])
+    return prm, run, t
 
 
 class _GatedSum(torch.autograd.Function):
     """out = x + x1 * (s + g1[y] + g2[x]) per sample, the gates built from x1's plane statistics (the tail of model/block.py:136-140).
-    x, x1 [B*H*W, C]."""
+    x, x1 [B*H*W, C].  Statistics, gate maps (SE MLP, the two 2 -> 1 channel convolutions, BatchNorm2d(1) on batch statistics in
+    train() mode with its running buffers moved) and the gated sum are HIP kernels forward and backward (csrc/resblock.hip,
+    backward.hip, gates_train.hip); `groups`: BatchNorm statistics per group of B / groups consecutive samples (one group per encoder
+    pass when several passes share a launch)."""
 
     @staticmethod
-    def forward(fctx, x, x1, B, H, W, bn_train, *params):
+    def forward(fctx, x, x1, B, H, W, bn_train, groups, *params):
         ctx = _ctx(x.device)
         lib = _lib.lib()
         c = x.shape[1]
@@ -612,60 +585,70 @@ class _GatedSum(torch.autograd.Function):
         colmax, colmean = torch.empty(B, W, c, device=dev), torch.empty(B, W, c, device=dev)
         mean = torch.empty(B, c, device=dev)
         ws = torch.empty(B * lib.spei_plane_ws_floats(H, W, c), device=dev)
-        hw = H * W
         _lib.check(lib.spei_plane_stats_batched(_p(ctx, x1), _NULL, 0, H, W, c, _p(ctx, rowmax), _p(ctx, rowmean), _p(ctx, colmax),
                                                 _p(ctx, colmean), _p(ctx, mean), _p(ctx, ws), B, ctx._stream()), "spei_plane_stats_batched")
-        prm = [t.detach() for t in params]
-        with torch.no_grad():
-            s, g1, g2 = _gate_maps(rowmax, rowmean, colmax, colmean, mean, prm, bn_train, update_running=bn_train)
+        prm, run, keep_alive = _gate_ptrs(ctx, params)
+        s, g1, g2 = torch.empty(B, c, device=dev), torch.empty(B, H, c, device=dev), torch.empty(B, W, c, device=dev)
+        saved = torch.empty(lib.spei_gate_train_saved_floats(B, groups, H, W, c), device=dev)
+        gws = torch.empty(lib.spei_gate_train_ws_floats(B, groups, H, W, c) // 2 + 1, device=dev, dtype=torch.float64)
+        _lib.check(lib.spei_gate_maps_fwd(_p(ctx, rowmax), _p(ctx, rowmean), _p(ctx, colmax), _p(ctx, colmean), _p(ctx, mean), prm, run, B, groups,
+                                          H, W, c, int(bn_train), int(bn_train), _p(ctx, s), _p(ctx, g1), _p(ctx, g2), _p(ctx, saved),
+                                          C.c_void_p(gws.data_ptr()), ctx._stream()), "spei_gate_maps_fwd")
         out = torch.empty_like(x)
-        s, g1, g2 = s.contiguous(), g1.contiguous(), g2.contiguous()
-        assert s.shape == (B, c) and g1.shape == (B, H, c) and g2.shape == (B, W, c)
         _lib.check(lib.spei_resblock_apply_batched(_p(ctx, x), _p(ctx, x1), 0, _p(ctx, s), _p(ctx, g1), _p(ctx, g2), _p(ctx, out), B, H, W, c,
                                                    ctx._stream()), "spei_resblock_apply_batched")
-        # the running buffers move again when the same block runs on the next frame (the encoder is applied to every frame of the
-        # window): the backward of a train-mode call does not read them, so it keeps detached copies
-        keep = [t.detach().clone() if i in (7, 8, 12, 13) else t for i, t in enumerate(params)]
-        fctx.save_for_backward(x1, rowmax, rowmean, colmax, colmean, mean, s, g1, g2, *keep)
-        fctx.meta = (B, H, W, bn_train)
+        # the backward reads the SAVED batch statistics (train) / the running statistics as they were (eval: copied into `saved` by the
+        # forward), never the running buffers, which move again when the same block runs on the next frame
+        fctx.save_for_backward(x1, rowmax, rowmean, colmax, colmean, mean, s, g1, g2, saved, *params)
+        fctx.meta = (B, H, W, bn_train, groups)
         return out
 
     @staticmethod
     def backward(fctx, dout):
-        x1, rowmax, rowmean, colmax, colmean, mean, s, g1, g2, *params = fctx.saved_tensors
-        B, H, W, bn_train = fctx.meta
+        x1, rowmax, rowmean, colmax, colmean, mean, s, g1, g2, saved, *params = fctx.saved_tensors
+        B, H, W, bn_train, groups = fctx.meta
         ctx = _ctx(dout.device)
         lib = _lib.lib()
         c = x1.shape[1]
         dev = dout.device
         dout = dout.contiguous()
-        hw = H * W
         # gradients of the gates: sums of dOut * x1 over x, over y, over the map
         dg1, dg2, ds = torch.empty(B, H, c, device=dev), torch.empty(B, W, c, device=dev), torch.empty(B, c, device=dev)
         ws = torch.empty(B * lib.spei_plane_ws_floats(H, W, c), device=dev)
         _lib.check(lib.spei_plane_stats_batched(_p(ctx, dout), _p(ctx, x1), 1, H, W, c, _NULL, _p(ctx, dg1), _NULL, _p(ctx, dg2), _p(ctx, ds),
                                                 _p(ctx, ws), B, ctx._stream()), "spei_plane_stats_batched")
-        # through the (tiny) gate maps with torch.autograd: statistics and parameters are the leaves
-        with torch.enable_grad():
-            stats = [t.detach().requires_grad_(True) for t in (rowmax, rowmean, colmax, colmean, mean)]
-            prm = [t.detach().requires_grad_(t.is_floating_point() and i not in (7, 8, 12, 13)) for i, t in enumerate(params)]
-            s2, g1b, g2b = _gate_maps(*stats, prm, bn_train, update_running=False)
-            leaves = stats + [t for t in prm if t.requires_grad]
-            grads = torch.autograd.grad([s2, g1b, g2b], leaves, [ds, dg1, dg2], allow_unused=True)
-        d_stats = [g.contiguous() if g is not None else torch.zeros_like(t) for g, t in zip(grads[:5], stats)]
+        # ... through the gate maps: statistics and parameters are the leaves
+        prm, run, keep_alive = _gate_ptrs(ctx, params)
+        d_stats = [torch.empty_like(t) for t in (rowmax, rowmean, colmax, colmean, mean)]
+        npar = lib.spei_gate_train_nparams(c)
+        dprm = torch.empty(npar, device=dev)
+        gws = torch.empty(lib.spei_gate_train_ws_floats(B, groups, H, W, c) // 2 + 1, device=dev, dtype=torch.float64)
+        _lib.check(lib.spei_gate_maps_bwd(_p(ctx, rowmax), _p(ctx, rowmean), _p(ctx, colmax), _p(ctx, colmean), _p(ctx, mean), prm, run, B, groups,
+                                          H, W, c, int(bn_train), _p(ctx, s), _p(ctx, saved), _p(ctx, ds), _p(ctx, dg1), _p(ctx, dg2),
+                                          *[_p(ctx, t) for t in d_stats], _p(ctx, dprm), C.c_void_p(gws.data_ptr()), ctx._stream()),
+                   "spei_gate_maps_bwd")
         dx1 = torch.empty_like(x1)
-        assert d_stats[0].shape == (B, H, c) and d_stats[2].shape == (B, W, c) and d_stats[4].shape == (B, c)
         _lib.check(lib.spei_resblock_apply_bwd_batched(_p(ctx, dout), _p(ctx, x1), _p(ctx, s), _p(ctx, g1), _p(ctx, g2), _p(ctx, rowmax),
                                                        _p(ctx, colmax), _p(ctx, d_stats[0]), _p(ctx, d_stats[1]), _p(ctx, d_stats[2]),
                                                        _p(ctx, d_stats[3]), _p(ctx, d_stats[4]), _p(ctx, dx1), B, H, W, c, ctx._stream()),
                    "spei_resblock_apply_bwd_batched")
-        pg = iter(grads[5:])
-        dparams = [next(pg) if t.requires_grad else None for t in prm]
-        return (dout, dx1, None, None, None, None) + tuple(dparams)
+        # dprm: se_w1 | se_b1 | se_w2 | se_b2 | cw_w | cw_g | cw_b | hc_w | hc_g | hc_b  -> the parameters' shapes (views of one buffer)
+        r = c // 4
+        sizes = (r * c, r, c * r, c, 98, 1, 1, 50, 1, 1)
+        parts = torch.split(dprm, sizes)
+        gi = iter(parts)
+        dparams = []
+        for i, t in enumerate(params):
+            if i in (7, 8, 12, 13):
+                dparams.append(None)                       # running buffers
+            else:
+                g = next(gi)
+                dparams.append(g.view(t.shape) if fctx.needs_input_grad[7 + i] else None)
+        return (dout, dx1, None, None, None, None, None) + tuple(dparams)
 
 
 # ---- the model, train-mode graph ----------------------------------------------------------------------------------------------
-def resblock(x: torch.Tensor, blk, B: int, H: int, W: int, bn_train: bool) -> torch.Tensor:
+def resblock(x: torch.Tensor, blk, B: int, H: int, W: int, bn_train: bool, groups: int = 1) -> torch.Tensor:
     """x + SE(x1) + TE(x1), x1 = conv5(relu(conv5(x)))   (model/block.py:127-140); `blk`: a speinet._ResBlock."""
     c0, c1 = blk.main[0].main[0], blk.main[1].main[0]
     t = _Conv2d.apply(x, c0.weight, c0.bias, None, B, H, W, 5, 1, True)
@@ -674,7 +657,7 @@ def resblock(x: torch.Tensor, blk, B: int, H: int, W: int, bn_train: bool) -> to
     if bn_train:
         for bn in (cw.bn, hc.bn):
             bn.num_batches_tracked += 1
-    return _GatedSum.apply(x, x1, B, H, W, bn_train, blk.se.fc[0].weight, blk.se.fc[0].bias, blk.se.fc[2].weight, blk.se.fc[2].bias,
+    return _GatedSum.apply(x, x1, B, H, W, bn_train, groups, blk.se.fc[0].weight, blk.se.fc[0].bias, blk.se.fc[2].weight, blk.se.fc[2].bias,
                            cw.conv.weight, cw.bn.weight, cw.bn.bias, cw.bn.running_mean, cw.bn.running_var,
                            hc.conv.weight, hc.bn.weight, hc.bn.bias, hc.bn.running_mean, hc.bn.running_var)
 

@@ -162,6 +162,108 @@ def test_resblock_backward_vs_torch(synth_sd, c, h, w, prec):
         assert rel(p.grad, refp[k].grad.float()) < 1e-4 * fp, k
 
 
+# ---- the gate maps of a ResBlock (csrc/gates_train.hip) against their torch statement in float64 -------------------------------------
+def gate_maps_torch(rowmax, rowmean, colmax, colmean, mean, prm, bn_train: bool, update_running: bool):
+    """s [B,C], g1 [B,H,C], g2 [B,W,C] from the plane statistics (model/block.py:8-24 SE, :75-96 the two gates without their
+    sigmoid, :49-68 BasicConv1 = 2->1 conv + BatchNorm2d(1); TripletAttention sums the gates, :116-119).  prm: se_w1, se_b1, se_w2,
+    se_b2, cw_w, cw_bn_w, cw_bn_b, cw_rm, cw_rv, hc_w, hc_bn_w, hc_bn_b, hc_rm, hc_rv.  bn_train: normalise with the batch
+    statistics; update_running: also move the running buffers (momentum 0.01), as nn.BatchNorm2d.forward does in train()."""
+    se_w1, se_b1, se_w2, se_b2, cw_w, cw_g, cw_b, cw_rm, cw_rv, hc_w, hc_g, hc_b, hc_rm, hc_rv = prm
+    s = torch.sigmoid(F.linear(F.relu(F.linear(mean, se_w1, se_b1)), se_w2, se_b2))
+
+    def bn(t, g, b, rm, rv):
+        # nn.BatchNorm2d(1, eps 1e-5, momentum 0.01) written out (plain tensor arithmetic: no library batch-norm kernels to
+        # compile per shape): train() normalises with the biased batch variance and moves the buffers with the unbiased one
+        if not bn_train:
+            return (t - rm) / torch.sqrt(rv + 1e-5) * g + b
+        mean = t.mean()
+        var = ((t - mean) ** 2).mean()
+        if update_running:
+            with torch.no_grad():
+                n = t.numel()
+                rm.mul_(1.0 - 0.01).add_(0.01 * mean)
+                rv.mul_(1.0 - 0.01).add_(0.01 * var * (n / max(n - 1, 1)))
+        return (t - mean) / torch.sqrt(var + 1e-5) * g + b
+
+    def conv21(z, w, k):
+        # the 2 -> 1 channel k x k convolution as unfold + one matrix product: the library convolution's weight gradient is not
+        # bitwise reproducible for these shapes (atomics), this form is
+        # torch's im2col runs one launch per batch element (60 maps per ResBlock at batch 20: 2 900 launches per step): the batch is laid out
+        # as ONE tall map, each sample between its own zero rows, so the whole batch is one unfold and one product
+        bsz, _, a, b = z.shape
+        pd = k // 2
+        tall = F.pad(z, (0, 0, pd, pd)).permute(1, 0, 2, 3).reshape(1, 2, bsz * (a + 2 * pd), b)
+        cols = F.unfold(tall, k, padding=(0, pd))                              # [1, 2 k k, (bsz (a + 2 pd) - k + 1) * b]
+        out = (w.reshape(1, -1) @ cols).view(bsz * (a + 2 * pd) - 2 * pd, b)
+        out = F.pad(out, (0, 0, 0, 2 * pd)).view(bsz, a + 2 * pd, b)[:, :a]     # row r of sample i sits at i (a + 2 pd) + r
+        return out.reshape(bsz, 1, a, b)
+
+    z1 = torch.stack((rowmax, rowmean), dim=1)                              # [B, 2, H, C]: conv "height" = H, "width" = C
+    g1 = bn(conv21(z1, cw_w, 7), cw_g, cw_b, cw_rm, cw_rv)[:, 0]            # [B, H, C]
+    z2 = torch.stack((colmax.transpose(1, 2), colmean.transpose(1, 2)), dim=1)   # [B, 2, C, W]: conv "height" = C, "width" = W
+    g2 = bn(conv21(z2, hc_w, 5), hc_g, hc_b, hc_rm, hc_rv)[:, 0].transpose(1, 2)  # [B, W, C]
+    return s.contiguous(), g1.contiguous(), g2.contiguous()
+
+
+@pytest.mark.parametrize("bn_train", [True, False])
+@pytest.mark.parametrize("c,h,w,b,groups", [(32, 20, 24, 2, 1), (64, 13, 17, 3, 1), (128, 10, 15, 1, 1), (32, 9, 31, 6, 3), (64, 12, 8, 4, 2),
+                                            (32, 60, 40, 3, 1), (64, 30, 20, 3, 1), (128, 15, 10, 3, 1), (32, 200, 200, 4, 2)])
+def test_gate_maps_fwd_bwd_vs_torch(c, h, w, b, groups, bn_train):
+    """spei_gate_maps_fwd / _bwd (SE MLP, the two 2 -> 1 channel convolutions, BatchNorm2d(1) on batch or running statistics; per
+    group of samples) against torch.autograd of the same formulas in float64 — round 3's implementation of this glue, kept here as
+    the oracle: outputs, the gradients of the five statistics and of the ten parameters, and the running buffers after the call."""
+    import ctypes as C
+    from speinet_amd import _lib
+    g = torch.Generator().manual_seed(c * 100 + h)
+    rn = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    stats = [rn(b, h, c), rn(b, h, c), rn(b, w, c), rn(b, w, c), rn(b, c)]
+    r = c // 4
+    prm = [rn(r, c, sc=0.2), rn(r, sc=0.1), rn(c, r, sc=0.3), rn(c, sc=0.1), rn(1, 2, 7, 7, sc=0.15), rn(1).abs() + 0.5, rn(1, sc=0.1),
+           rn(1, sc=0.1), rn(1).abs() + 0.7, rn(1, 2, 5, 5, sc=0.2), rn(1).abs() + 0.5, rn(1, sc=0.1), rn(1, sc=0.1), rn(1).abs() + 0.6]
+    douts = [rn(b, c), rn(b, h, c), rn(b, w, c)]
+    # float64 oracle, group by group (the statistics of BatchNorm are per group; the running buffers move once per group, in order)
+    st64 = [t.double().requires_grad_(True) for t in stats]
+    p64 = [t.double().requires_grad_(t.is_floating_point() and i not in (7, 8, 12, 13)) for i, t in enumerate(prm)]
+    bs = b // groups
+    outs = [[], [], []]
+    for gi in range(groups):
+        sl = slice(gi * bs, (gi + 1) * bs)
+        o = gate_maps_torch(*[t[sl] for t in st64], p64, bn_train, update_running=bn_train)
+        for k in range(3):
+            outs[k].append(o[k])
+    outs = [torch.cat(o) for o in outs]
+    leaves = st64 + [t for t in p64 if t.requires_grad]
+    grads = torch.autograd.grad(outs, leaves, [t.double() for t in douts])
+    # HIP
+    ctx = T._ctx(torch.device(DEV))
+    lib = _lib.lib()
+    dv = lambda t: t.float().contiguous().to(DEV)
+    sd, pd, dd = [dv(t) for t in stats], [dv(t) for t in prm], [dv(t) for t in douts]
+    prm_p, run_p, keep = T._gate_ptrs(ctx, pd)
+    s_, g1, g2 = torch.empty(b, c, device=DEV), torch.empty(b, h, c, device=DEV), torch.empty(b, w, c, device=DEV)
+    saved = torch.empty(lib.spei_gate_train_saved_floats(b, groups, h, w, c), device=DEV)
+    ws = torch.empty(lib.spei_gate_train_ws_floats(b, groups, h, w, c) // 2 + 1, device=DEV, dtype=torch.float64)
+    P = lambda t: T._p(ctx, t)
+    with torch.cuda.device(DEV):
+        _lib.check(lib.spei_gate_maps_fwd(*[P(t) for t in sd], prm_p, run_p, b, groups, h, w, c, int(bn_train), int(bn_train), P(s_), P(g1), P(g2),
+                                          P(saved), C.c_void_p(ws.data_ptr()), ctx._stream()), "fwd")
+        for got, ref, nm in zip((s_, g1, g2), outs, ("s", "g1", "g2")):
+            assert rel(got, ref.detach().float()) < 2e-6, nm
+        for i in (7, 8, 12, 13):                                     # running buffers: moved (train) or untouched (eval)
+            assert (keep[i].cpu() - p64[i].detach().float()).abs().max().item() < 1e-6, i
+        d_stats = [torch.empty_like(t) for t in sd]
+        dprm = torch.empty(lib.spei_gate_train_nparams(c), device=DEV)
+        _lib.check(lib.spei_gate_maps_bwd(*[P(t) for t in sd], prm_p, run_p, b, groups, h, w, c, int(bn_train), P(s_), P(saved), *[P(t) for t in dd],
+                                          *[P(t) for t in d_stats], P(dprm), C.c_void_p(ws.data_ptr()), ctx._stream()), "bwd")
+    for got, ref, nm in zip(d_stats, grads[:5], ("d_rowmax", "d_rowmean", "d_colmax", "d_colmean", "d_mean")):
+        assert rel(got, ref.float()) < 5e-6, nm
+    sizes = (r * c, r, c * r, c, 98, 1, 1, 50, 1, 1)
+    names = ("se_w1", "se_b1", "se_w2", "se_b2", "cw_w", "cw_g", "cw_b", "hc_w", "hc_g", "hc_b")
+    for got, ref, nm in zip(torch.split(dprm, sizes), grads[5:], names):
+        scale = max(ref.norm().item(), 1e-3 * max(gq.norm().item() for gq in grads[5:]))
+        assert (got.cpu().double() - ref.reshape(-1)).norm().item() / scale < 2e-5, nm
+
+
 @pytest.mark.parametrize("name,h,w", [("g19_enc_grad_40x60", 40, 60), ("g19_enc_grad_100x100", 100, 100)])
 def test_encoder_gradients_vs_reference(golden_dir, synth_sd, name, h, w):
     """Every parameter gradient of the three encoder stages against the reference's own autograd (G19): L2 norm and a strided
