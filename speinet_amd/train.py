@@ -656,26 +656,30 @@ def resblock(x: torch.Tensor, blk, B: int, H: int, W: int, bn_train: bool, group
     cw, hc = blk.te.cw.conv, blk.te.hc.conv
     if bn_train:
         for bn in (cw.bn, hc.bn):
-            bn.num_batches_tracked += 1
+            bn.num_batches_tracked += groups
     return _GatedSum.apply(x, x1, B, H, W, bn_train, groups, blk.se.fc[0].weight, blk.se.fc[0].bias, blk.se.fc[2].weight, blk.se.fc[2].bias,
                            cw.conv.weight, cw.bn.weight, cw.bn.bias, cw.bn.running_mean, cw.bn.running_var,
                            hc.conv.weight, hc.bn.weight, hc.bn.bias, hc.bn.running_mean, hc.bn.running_var)
 
 
-def encoder(frames: torch.Tensor, rn, bn_train: bool, pyramid: bool = False):
+def encoder(frames: torch.Tensor, rn, bn_train: bool, pyramid: bool = False, groups: int = 1):
     """encoder_second(encoder_first(inBlock(frames)))  (model/swint.py:53,58): [B,3,H,W] -> [B*(H/4)*(W/4), 128]; pyramid: all three
-    levels (lv1 [B*H*W, 32], lv2, lv3), the sharp-reference features of model/speinet.py:124-126."""
+    levels (lv1 [B*H*W, 32], lv2, lv3), the sharp-reference features of model/speinet.py:124-126.  groups: `frames` holds that many
+    encoder passes of the reference one after the other (B / groups samples each, in the reference's call order): one set of
+    launches, every parameter used once per step, the BatchNorm(1) statistics of the gates taken and their running buffers moved pass
+    by pass as the separate calls would."""
     B, _, H, W = frames.shape
+    assert B % groups == 0
     f = _ConvIn.apply(frames, rn.inBlock[0][0].weight, rn.inBlock[0][0].bias)
     for blk in list(rn.inBlock)[1:]:
-        f = resblock(f, blk, B, H, W, bn_train)
+        f = resblock(f, blk, B, H, W, bn_train, groups)
     levels = [f]
     h, w = H, W
     for stage in (rn.encoder_first, rn.encoder_second):
         f = _Conv2d.apply(f, stage[0][0].weight, stage[0][0].bias, None, B, h, w, 5, 2, True)
         h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         for blk in list(stage)[1:]:
-            f = resblock(f, blk, B, h, w, bn_train)
+            f = resblock(f, blk, B, h, w, bn_train, groups)
         levels.append(f)
     return tuple(levels) if pyramid else f
 
@@ -802,21 +806,36 @@ def _train_precision(model) -> str:
     return p
 
 
+def merge_scales(calls: Optional[list]) -> Optional[list]:
+    """The DropPath factors of several Swin calls (`drop_path_scales`: [call][block] -> None or (attn [B], mlp [B])) as those of ONE call
+    on the calls' samples stacked: [block] -> None or (attn [calls*B], mlp [calls*B])."""
+    if not calls:
+        return None
+    out = []
+    for per_block in zip(*calls):
+        if per_block[0] is None:
+            out.append(None)
+        else:
+            out.append(tuple(torch.cat([c[j] for c in per_block]) for j in range(2)))
+    return out
+
+
 def _forward_swint_graph(model, x, n, B, h3, w3, training, scales):
+    """The n encoder passes as one (groups = n, the centre frame first: the reference's call order, model/swint.py:53,58) and the
+    n - 1 Swin calls as one call on the neighbours' samples stacked (the same weights; keys / values from the centre frame's
+    features repeated): every parameter enters the graph once, so autograd has no per-parameter sums left to take."""
     with torch.cuda.device(x.device):
         rn = model.recons_net
-        f_mid = encoder(x[:, n // 2], rn, training)
-        feats = [f_mid]
-        call = 0
-        for i in range(n):
-            if i == n // 2:
-                continue
-            feats.append(swin(model.swin, f_mid, encoder(x[:, i], rn, training), B, h3, w3, scales[call] if scales else None))
-            call += 1
+        hw = B * h3 * w3
+        order = [n // 2] + [i for i in range(n) if i != n // 2]
+        enc = encoder(torch.cat([x[:, i] for i in order]), rn, training, groups=n)
+        f_mid = enc[:hw]
         if n == 1:
             fused = f_mid + swin(model.swin, f_mid, f_mid, B, h3, w3, scales[0] if scales else None)
         else:
-            fused = torch.cat(feats, dim=1)
+            calls = n - 1
+            sw = swin(model.swin, f_mid.repeat(calls, 1), enc[hw:], calls * B, h3, w3, merge_scales(scales))
+            fused = torch.cat([f_mid] + [sw[j * hw:(j + 1) * hw] for j in range(calls)], dim=1)
         cv = model.conv
         ff = _Linear.apply(fused, cv.weight.view(cv.weight.shape[0], -1), cv.bias, None, None)
         return decoder(ff, rn, B, h3, w3, training)
@@ -875,19 +894,27 @@ def _branch_speinet(m, x: torch.Tensor, has_ref: bool, scales: Optional[list], b
     B, _, _, H, W = x.shape
     h3, w3 = H // 4, W // 4
     rn = m.recons_net
-    lv = encoder(x[:, n + 1], rn, bn_train, pyramid=True) if has_ref else None          # sharp_lv1, sharp_lv2, sharp_lv3
+    # every encoder pass of the branch as ONE pass, in the reference's call order (model/speinet.py:124-131 / :141-147): the sharp
+    # reference (all three levels), the centre frame and its 5-step prior, then each neighbour and its 1-step prior
     mid = x[:, n // 2]
-    f_mid = encoder(mid, rn, bn_train) + encoder(rl_prior(mid, 5), rn, bn_train)
-    feats = [f_mid]
-    call = 0
-    for i in range(n):
-        if i == n // 2:
-            continue
-        deb = rl_prior(x[:, i], 1)
-        feat = encoder(x[:, i], rn, bn_train)
-        feat = feat + encoder(deb, rn, bn_train)
-        feats.append(swin(m.swin, f_mid, feat, B, h3, w3, scales[call] if scales else None))
-        call += 1
+    nb = [i for i in range(n) if i != n // 2]
+    passes = ([x[:, n + 1]] if has_ref else []) + [mid, rl_prior(mid, 5)]
+    for i in nb:
+        passes += [x[:, i], rl_prior(x[:, i], 1)]
+    g = len(passes)
+    lv1, lv2, lv3 = encoder(torch.cat(passes), rn, bn_train, pyramid=True, groups=g)
+    hw = B * h3 * w3
+    part = lambda t, j: t[j * (t.shape[0] // g):(j + 1) * (t.shape[0] // g)]
+    lv = (part(lv1, 0), part(lv2, 0), part(lv3, 0)) if has_ref else None                 # sharp_lv1, sharp_lv2, sharp_lv3
+    o = 1 if has_ref else 0
+    f_mid = part(lv3, o) + part(lv3, o + 1)
+    if nb:
+        calls = len(nb)
+        feat = torch.cat([part(lv3, o + 2 + 2 * j) + part(lv3, o + 3 + 2 * j) for j in range(calls)])
+        sw = swin(m.swin, f_mid.repeat(calls, 1), feat, calls * B, h3, w3, merge_scales(scales))
+        feats = [f_mid] + [sw[j * hw:(j + 1) * hw] for j in range(calls)]
+    else:
+        feats = [f_mid]
     fu = m.fusion
     ff = _Linear.apply(torch.cat(feats, dim=1), fu.weight.view(fu.weight.shape[0], -1), fu.bias, None, None)
     if has_ref:
