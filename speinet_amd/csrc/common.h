@@ -39,6 +39,11 @@ static inline long long* spei_stamp_buffer() { const char* v = getenv("SPEI_STAM
     do {                                                                                              \
         if ((buf) && threadIdx.x == 0) (buf)[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
+// the shader clock (s_memtime: core cycles, per XCD) into slot i: with SPEI_STAMP at the same point it gives the clock a phase ran at
+#define SPEI_STAMP_CLK(buf, i)                                                                        \
+    do {                                                                                              \
+        if ((buf) && threadIdx.x == 0) (buf)[(size_t)blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); \
+    } while (0)
 // the same from lane 0 of another wave (thread t): kernels whose waves take different roles
 #define SPEI_STAMP_AT(buf, i, t)                                                                      \
     do {                                                                                              \
@@ -48,6 +53,7 @@ static inline long long* spei_stamp_buffer() { const char* v = getenv("SPEI_STAM
 static constexpr int spei_knob(const char*, int dflt) { return dflt; }
 static inline long long* spei_stamp_buffer() { return nullptr; }
 #define SPEI_STAMP(buf, i) do { } while (0)
+#define SPEI_STAMP_CLK(buf, i) do { } while (0)
 #define SPEI_STAMP_AT(buf, i, t) do { } while (0)
 #endif
 

@@ -4,7 +4,7 @@ every workgroup stamps s_memtime (100 MHz-independent shader clock ticks) at pha
 passed through SPEI_STAMP_PTR.  Prints the median per-phase durations in microseconds (at the measured clock) and the spread
 of workgroup start / end times across the launch.
 
-    python tools/stamp_phases.py attn|attn4|mlp      (attn: round 2's two-window kernel; attn4: the four-window kernel on two stacked maps)
+    python tools/stamp_phases.py attn|attn4|mlp|mlp2    (attn: round 2's two-window kernel; attn4: the four-window kernel on two stacked maps)
     python tools/stamp_phases.py conv1|conv2|conv3   (conv_slab: the 5x5 ResBlock conv at 720p level 1 / 2 / 3, f16 in and out;
                                                       stamps: 0 start, 1 slab staged, 2 barrier passed, 3 main loop done, 4 stored)
 """
@@ -62,6 +62,8 @@ def run():
         ops.replace(attn_win4=False).attn_fused(x, yhat, bk, H, W, 2, out)
     elif which == "attn4":
         ops.attn_fused(x2, yhat2, bk, H, W, 2, out2)
+    elif which == "mlp2":
+        ops.mlp_fused(x2, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out2)
     else:
         ops.mlp_fused(x, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out)
 
@@ -84,7 +86,15 @@ t0 = s[:, 0].min()
 span = (s.max() - t0).item()
 tick_us = 0.01               # s_memrealtime: 100 MHz reference clock, common to all XCDs
 print(f"{which}: {us:.1f} us by HIP events, {n} workgroups, first-start..last-end {span * tick_us:.1f} us")
-last = max(i for i in range(16) if (s[:, i] > 0).any())
+if which.startswith("mlp") and (s[:, 8] > 0).any():         # the persistent MLP kernel also stamps the shader clock (slots 8..15)
+    clk = s[:, 8:].clone()
+    s = s[:, :8]
+    for i in range(1, 8):
+        if (s[:, i] > 0).any() and (clk[:, i] > 0).any():
+            j = max(k for k in range(i) if (s[:, k] > 0).any())
+            f = (clk[:, i] - clk[:, j]).float() / ((s[:, i] - s[:, j]).float() * tick_us)
+            print(f"  shader clock over phase {j}->{i}: median {f.median():.0f} MHz")
+last = max(i for i in range(s.shape[1]) if (s[:, i] > 0).any())
 for i in range(1, last + 1):
     if not (s[:, i] > 0).any():
         continue
