@@ -759,6 +759,447 @@ __global__ __launch_bounds__(512, 2) void attn_win4_kernel(const Attn4Params<LP>
     }
 }
 
+
+// ---- round 4, second half: the four-window kernel as a PERSISTENT, software-pipelined kernel -----------------------------------------------
+// Stamps of `attn_win4_kernel` on the two stacked maps of a frame (1152 workgroups x 29.9 us on 256 CUs = 4.5 rounds): y-hat staging
+// 6.6 us, Q pass 3.6, LayerNorm 3.4, K pass + softmax 4.3, V pass 3.4, output exchange 4.0, projection 2.1, stores 2.2 — every wave of
+// the CU's one workgroup in the same phase, each phase waiting for its own loads.  Here a workgroup walks tiles of four windows
+// (tile = blockIdx.x + k gridDim.x) and a tile's loads, LayerNorm and stores ride inside the GEMM passes of its neighbours (the
+// structure of mlp_pipe_kernel, mlp_fused16.hip):
+//     Q pass   (y-hat: slab Yc)        + the NEXT tile's y-hat rows -> slab Yn
+//     K pass   (LN(x): slab X)         + relative-position bias, shift mask
+//     S^T + bias + mask;  V pass (slab X) + softmax;  this tile's residual rows requested INTO the projection's accumulators;  O^T -> slab Yc
+//     projection (slab Yc)             + the next tile's x rows -> LayerNorm -> slab X;  the token table of the tile after next
+//     results stored
+// Three 100-row slabs (Yc / Yn swap roles per tile), three barriers per tile, the weight ring runs on from pass to pass and tile to tile
+// (buffer loads: descriptor + fragment offset in scalar registers).  Results and residual move one dword per lane in the accumulators'
+// own layout, a row's byte offset looked up in the tile's token table (entry = pixel, or -1: an offset beyond the
+// descriptor's range, so absent rows read 0 and are never written).  The arithmetic — K order, accumulator starts, softmax — is
+// `attn_win4_kernel`'s; the two agree to the last bit except where the compiler contracts a LayerNorm product differently.
+constexpr int TABN = 128;             // token-table entries per tile (rows 100..127 are absent)
+
+template <typename LP>
+__global__ __launch_bounds__(512) void attn_pipe_kernel(const Attn4Params<LP> p, const int ntiles, const int stagger) {
+    typedef typename lpv<LP>::x8 lp8;
+    typedef typename lpv<LP>::x4 lp4;
+    constexpr int TPP = 32;                           // tokens per staging pass (16 lanes per token, 512 threads)
+    constexpr int NPASS = (TOK + TPP - 1) / TPP;      // 4
+    constexpr int RG = 8;                             // weight fragments in flight per wave
+    constexpr int SLAB = TOK * PA;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const sX = smem + SLAB;                                // LayerNorm(x) of the current tile
+    int* const tabs = reinterpret_cast<int*>(smem + 3 * SLAB);           // [3][TABN] token tables: previous, current, next tile
+    float* const sbias = reinterpret_cast<float*>(tabs + 3 * TABN);      // [768] bq | bk | bv
+    unsigned char* const sdummy = reinterpret_cast<unsigned char*>(sbias + 768);      // one row that takes the writes of absent rows / idle lanes
+    unsigned char* const tregs = sdummy + PA;                             // [2][128] shift-mask region of token t of window wd at [32 wd + t]
+
+    int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int fr = lane & 31, fk = lane >> 5;               // (not const: laundered at the top of every tile, see the loop)
+    int l16 = tid & 15, rsub = tid >> 4;
+    const int nwx = p.W / WS, HW = p.H * p.W;
+    const int h = wave;                               // the wave's head (Q, K, V passes) and its 32 output channels (projection)
+    const int G = gridDim.x;
+
+    SPEI_STAMP(p.stamps, 0);
+    spei_stagger_start(ntiles, stagger);
+    // token table of tile t: entry r = pixel of slab row r within its map, or -1; its shift-mask regions (swinir.py:215-236) as bytes
+    auto fill_table = [&](int* tab, unsigned char* treg, int t) {
+        {                                             // every thread writes entry tid & 127 (four identical writes: no divergent branch inside a pass)
+            const int te = tid & (TABN - 1);
+            int ent = -1;
+            if (te < TOK && t < ntiles) {
+                const int grp = t % p.groups;
+                const int wd = te / NT, tt = te - wd * NT;
+                const int win = grp * WPG + wd;
+                if (win < p.nwin) {
+                    const int wy = win / nwx, wx = win - wy * nwx;
+                    const int ysf = wy * WS + tt / WS, xsf = wx * WS + tt % WS;      // shifted-frame coordinates
+                    int yo = ysf + p.shift, xo = xsf + p.shift;                      // roll(-shift): shifted[y] = x[(y+shift) % H]
+                    if (yo >= p.H) yo -= p.H;
+                    if (xo >= p.W) xo -= p.W;
+                    const int reg = p.shift > 0 ? 3 * mask_region(ysf, p.H, p.shift) + mask_region(xsf, p.W, p.shift) : 0;
+                    ent = yo * p.W + xo;
+                    treg[wd * 32 + tt] = (unsigned char)reg;
+                }
+            }
+            tab[te] = ent;
+        }
+    };
+    int tile = blockIdx.x;
+    int* tcur = tabs;                                 // tables of this tile, of the next one, and the buffer the one after next is written to
+    int* tnext = tabs + TABN;
+    int* tspare = tabs + 2 * TABN;
+    if (tid < 64) reinterpret_cast<int*>(tregs)[tid] = 0;
+    lds_barrier();
+    fill_table(tcur, tregs, tile);
+    fill_table(tnext, tregs + TABN, tile + G);
+    for (int i = tid; i < 768; i += 512) sbias[i] = i < D ? p.bq[i] : p.bkv[i - D];
+    float bias_p = p.bproj[wave * HD + fr];
+    lds_barrier();
+
+    const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<LP*>(p.wq), 0, D * D * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rskv = __builtin_amdgcn_make_buffer_rsrc(const_cast<LP*>(p.wkv), 0, 2 * D * D * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<LP*>(p.wproj), 0, D * D * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrel = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.relbias), 0, 8 * NT * NT * 4, 0x00020000);
+    int lane16 = lane * 16;
+    // fragment of pass ph (0 Q, 1 K, 2 V, 3 projection), k-step ks
+    auto wload = [&](int ph, int ks) -> lp8 {
+        const int base = ph == 2 ? (8 + h) * 16 : h * 16;
+        return __builtin_bit_cast(lp8, __builtin_amdgcn_raw_buffer_load_b128(ph == 0 ? rsq : ph == 3 ? rsp : rskv, lane16, (base + ks) * 1024, 0));
+    };
+
+    // staging helpers: 16 lanes per token, 32 tokens per pass
+    auto row_entry = [&](const int* tab, int ps) { return tab[min(ps * TPP + rsub, TOK - 1)]; };
+    f32x4 xr[NPASS][4];
+    float lnm[NPASS], lns[NPASS];
+    auto x_load = [&](const float* xg, const int* tab, int ps) {
+        const int pix = max(row_entry(tab, ps), 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xr[ps][j] = reinterpret_cast<const f32x4*>(xg + (size_t)pix * D)[l16 + 16 * j];
+    };
+    // (inlined at two places — prologue and projection pass: the products and sums are spelled out and contraction is off, so that a
+    // tile's LayerNorm does not depend on which of the two computed it)
+    auto ln_slice = [&](const int* tab, int ps, int sub, unsigned char* dst, int rb_) {
+#pragma clang fp contract(off)
+        if (sub == 0) {
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sm += (xr[ps][j][0] + xr[ps][j][1]) + (xr[ps][j][2] + xr[ps][j][3]);
+            lnm[ps] = sum16(sm) * (1.0f / 256.0f);
+        } else if (sub == 1) {
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xr[ps][j] -= lnm[ps];
+                ss += __builtin_fmaf(xr[ps][j][1], xr[ps][j][1], xr[ps][j][0] * xr[ps][j][0]) +
+                      __builtin_fmaf(xr[ps][j][3], xr[ps][j][3], xr[ps][j][2] * xr[ps][j][2]);
+            }
+            lns[ps] = ss;
+        } else if (sub == 2) {
+            const int r = ps * TPP + rsub;
+            const bool ok = r < TOK && row_entry(tab, ps) >= 0;
+            lns[ps] = ok ? 1.0f / sqrtf(__builtin_fmaf(sum16(lns[ps]), 1.0f / 256.0f, 1e-5f)) : 0.f;     // empty rows stage zeros
+        } else {
+            const int r = ps * TPP + rsub;
+            unsigned char* const row = r < TOK ? dst + r * PA : sdummy;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lp4 hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hv[e] = to_lp<LP>(xr[ps][j][e] * lns[ps]);
+                *reinterpret_cast<lp4*>(row + (((l16 + 16 * j) * 8 - rb_) & 511)) = hv;
+            }
+        }
+    };
+    u32x4 yr[NPASS][2];
+    auto y_load = [&](const LP* yg, const int* tab, int ps) {
+        const int pix = max(row_entry(tab, ps), 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) yr[ps][j] = reinterpret_cast<const u32x4*>(yg + (size_t)pix * D)[l16 + 16 * j];
+    };
+    auto y_write = [&](const int* tab, int ps, unsigned char* dst, int rb_) {
+        const int r = ps * TPP + rsub;
+        unsigned char* const row = r < TOK ? dst + r * PA : sdummy;
+        const bool ok = row_entry(tab, ps) >= 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            *reinterpret_cast<u32x4*>(row + (((l16 + 16 * j) * 16 - rb_) & 511)) = ok ? yr[ps][j] : u32x4{0u, 0u, 0u, 0u};
+    };
+
+    // ---- prologue: the first tile's y-hat rows -> slab 0, x rows -> LayerNorm -> slab X; the ring's first fragments ---------------------
+    // (integer division runs on the vector unit: without readfirstlane the map's buffer descriptors count as divergent and every
+    // buffer access becomes a waterfall loop)
+    int bmap = __builtin_amdgcn_readfirstlane(tile / p.groups), grp = tile - bmap * p.groups;
+    int rot = grp & 15, rot4 = (grp * 3) & 15;
+    {
+        const size_t moff = (size_t)bmap * HW * D;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) y_load(p.yhat + moff, tcur, ps);
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) x_load(p.x + moff, tcur, ps);
+    }
+    lp8 ring[RG];
+#pragma unroll
+    for (int d = 0; d < RG; ++d) ring[d] = wload(0, (rot + d) & 15);
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) y_write(tcur, ps, smem, rot * 32);
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) ln_slice(tcur, ps, sub, sX, rot * 32);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+    SPEI_STAMP(p.stamps, 1);
+
+    int voff_ch = fr * 4;
+    const int soff_w = __builtin_amdgcn_readfirstlane(wave * 128);      // the wave's 128-byte channel block (scalar offset of every row access)
+    int cur = 0;
+    bool first = true;
+    for (; tile < ntiles; tile += G) {
+        // Everything derived from the lane's position is loop-invariant, and the compiler computes ALL of it ahead of the loop (table
+        // arithmetic, slab addresses, bias splats for packed adds: ~50 registers) and spills what does not fit; every reload is a
+        // scratch load in the middle of a pass, in the same in-order queue as the weight ring.  Opaque per tile, they are recomputed
+        // where they are used.
+        asm volatile("" : "+v"(tid), "+v"(fr), "+v"(fk), "+v"(l16), "+v"(rsub), "+v"(lane16), "+v"(voff_ch), "+v"(bias_p));
+        unsigned char* const sYc = smem + (cur ? 2 * SLAB : 0);           // y-hat of this tile, later its attention output
+        unsigned char* const sYn = smem + (cur ? 0 : 2 * SLAB);           // y-hat of the next tile
+        const int tnx = tile + G;
+        const int bq_ = __builtin_amdgcn_readfirstlane(tnx / p.groups);
+        const int grpn = tnx - bq_ * p.groups, bmapn = tnx < ntiles ? bq_ : bmap;
+        const int rotn = grpn & 15, rot4n = (grpn * 3) & 15;
+        const size_t moff = (size_t)__builtin_amdgcn_readfirstlane(bmap) * HW * D, moffn = (size_t)__builtin_amdgcn_readfirstlane(bmapn) * HW * D;
+        const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + moff), 0, HW * (D * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out + moff, 0, HW * (D * 4), 0x00020000);
+        // fragment q of the tile's weight stream (q = 16 pass + step; q >= 64: the next tile's Q pass)
+        auto wfrag = [&](int q) -> lp8 {
+            const int ph = (q >> 4) & 3;
+            const int r = q >= 64 ? rotn : ph == 3 ? rot4 : rot;
+            return wload(ph, (r + (q & 15)) & 15);
+        };
+        // One pass of 16 k-steps: 4 MFMAs per step on the fragment the ring delivers, token fragments from the slab one step ahead;
+        // filler(s): the vector / memory work that rides in this pass.  Pinned with full scheduling barriers; the empty asm on each
+        // accumulator keeps an IR pass from moving MFMAs whose results are needed late to the end of the pass (mlp_fused16.hip).
+        auto pass = [&](auto phc, const unsigned char* src, const int (&roff)[4], f32x16 (&acc)[4], auto tokens_on_columns, auto&& filler) {
+            constexpr int ph = decltype(phc)::value;
+            lp8 tn[4];
+#pragma unroll
+            for (int wd = 0; wd < 4; ++wd) tn[wd] = *reinterpret_cast<const lp8*>(src + roff[wd]);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                lp8 tc[4];
+#pragma unroll
+                for (int wd = 0; wd < 4; ++wd) tc[wd] = tn[wd];
+                if (i + 1 < 16) {
+#pragma unroll
+                    for (int wd = 0; wd < 4; ++wd) tn[wd] = *reinterpret_cast<const lp8*>(src + roff[wd] + (i + 1) * 32);
+                }
+                const lp8 wc = ring[(ph * 16 + i) % RG];
+                ring[(ph * 16 + i) % RG] = wfrag(ph * 16 + i + RG);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int wd = 0; wd < 4; ++wd) {
+                    if constexpr (decltype(tokens_on_columns)::value) acc[wd] = mfma16(wc, tc[wd], acc[wd]);
+                    else acc[wd] = mfma16(tc[wd], wc, acc[wd]);
+                }
+                filler(i);
+#pragma unroll
+                for (int wd = 0; wd < 4; ++wd) asm volatile("" : "+v"(acc[wd]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto init_rows = [&](f32x16 (&acc)[4], const float* b) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(b + h * HD + 8 * g + 4 * fk);
+#pragma unroll
+                for (int wd = 0; wd < 4; ++wd)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[wd][4 * g + e] = bv[e];
+            }
+        };
+        int rowoff[4], aoff[4];
+#pragma unroll
+        for (int wd = 0; wd < 4; ++wd) {
+            rowoff[wd] = min(wd * NT + fr, TOK - 1) * PA + fk * 16;       // window wd's 32-row tile (rows past its 25 tokens: the next window's)
+            aoff[wd] = min(wd * 32 + fr, TOK - 1) * PA + fk * 16;         // row tile wd of the 100 rows
+        }
+
+        // ---- Q^T of the wave's head  + the previous tile's results stored + the next tile's table ------------------------------------------
+        lp8 qp[4][2];
+        unsigned mbits[4] = {0u, 0u, 0u, 0u};
+        {
+            f32x16 acc[4];
+            init_rows(acc, sbias);
+            pass(std::integral_constant<int, 0>{}, sYc, rowoff, acc, std::true_type{}, [&](int s) {
+                // The next tile's y-hat rows: ALL loads now, as one burst.  The vector-memory queue is in order, so an access that takes
+                // longer than the ring's eight steps holds up every weight fragment requested behind it: spread over a pass (one group
+                // per step) each step waited for the group before it and the pass ran at (memory latency / 8) per step — 5.0 us instead
+                // of 2.5.  A burst costs that wait once.
+                if (s == 0) {
+#pragma unroll
+                    for (int ps = 0; ps < NPASS; ++ps) y_load(p.yhat + moffn, tnext, ps);
+                }
+                if (s >= 12) y_write(tnext, s - 12, sYn, rotn * 32);
+            });
+#pragma unroll
+            for (int wd = 0; wd < 4; ++wd) {
+                qp[wd][0] = cvt8<0, LP>(acc[wd]);
+                qp[wd][1] = cvt8<1, LP>(acc[wd]);
+                asm volatile("" : "+v"(qp[wd][0]), "+v"(qp[wd][1]));      // packed NOW: left alone the conversion sinks to its use after the
+            }                                                             // K pass and the 64 accumulator registers stay live through it
+        }
+        lds_barrier();                                // every wave is done with the y-hat rows (slab Yc); the next tile's table is complete
+        if (first) SPEI_STAMP(p.stamps, 2);
+
+        // ---- K^T -> S^T -> softmax ---------------------------------------------------------------------------------------------------------------
+        lp8 pp[4][2];                                 // P^T packed
+        f32x16 st[4];                                 // S^T, then the probabilities, of the four windows
+        {
+            float rb[16];
+            f32x16 acc[4];
+            init_rows(acc, sbias + D);
+            pass(std::integral_constant<int, 1>{}, sX, rowoff, acc, std::true_type{}, [&](int s) {
+                if (s == 0) {                         // relative-position bias of (query = lane column, key = register row): 16 L1-resident loads per
+                    // tile cost less than 16 registers held through every pass; one per-lane offset, the key in the immediate (keys >= 25 read the
+                    // next row or, past the table's end, the descriptor's 0: they are masked below)
+                    const int vb = ((h * NT + (fr < NT ? fr : 0)) * NT + 4 * fk) * 4;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        rb[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrel, vb + ((r & 3) + 8 * (r >> 2)) * 4, 0, 0));
+                }
+                if (s >= 12) {                        // shift mask of window s - 12: bit r of mbits = key (register row r) lies in another region
+                    const int wd = s - 12;            // than the lane's query; four key regions per 32-bit read, compared bytewise
+                    const unsigned char* tr = tregs + (cur ? TABN : 0) + wd * 32;
+                    const unsigned qs = tr[fr < NT ? fr : 0] * 0x01010101u;
+                    unsigned m = 0u;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const unsigned x = *reinterpret_cast<const unsigned*>(tr + 8 * g + 4 * fk) ^ qs;
+                        const unsigned nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) >> 7 & 0x01010101u;      // byte b = (region differs)
+                        m |= ((nz * 0x01020408u) >> 24) << (4 * g);
+                    }
+                    mbits[wd] = m;
+                }
+            });
+#pragma unroll
+            for (int wd = 0; wd < 4; ++wd) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[wd][r] = 0.f;
+                // S^T[key][query] = sum_d K^T[d][key] Q^T[d][query]:  A = (K^T)^T from the accumulator, B = Q^T (packed)
+                st[wd] = mfma16(cvt8<0, LP>(acc[wd]), qp[wd][0], st[wd]);
+                st[wd] = mfma16(cvt8<1, LP>(acc[wd]), qp[wd][1], st[wd]);
+            }
+            // + relative-position bias, shift mask, -inf on the 7 pad keys: here, so that bias and mask registers die before the V pass;
+            // the rest of the softmax (max, exp, sum, scale, pack: 3/4 of its instructions) rides in the V pass
+#pragma unroll
+            for (int wd = 0; wd < 4; ++wd)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    float v = -INFINITY;
+                    if (key < NT) {
+                        v = st[wd][r] + rb[r];
+                        if (mbits[wd] >> r & 1) v += -100.0f;
+                    }
+                    st[wd][r] = v;
+                }
+        }
+        if (first) SPEI_STAMP(p.stamps, 3);
+        // ---- V;  the residual rows requested;  O^T -----------------------------------------------------------------------------------------------
+        lp4 opk[4][4];
+        f32x16 accp[4];                               // the projection's accumulators
+        {
+            f32x16 acc[4];                            // V[token][d]: tokens on the accumulator rows, head dim on the columns
+            float bv = sbias[512 + h * HD + fr];
+            asm volatile("" : "+v"(bv));              // per tile: as a loop invariant the 16-register splat stays live through every pass
+#pragma unroll
+            for (int wd = 0; wd < 4; ++wd)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[wd][r] = bv;
+            float smx = 0.f, ssum = 0.f;
+            pass(std::integral_constant<int, 2>{}, sX, rowoff, acc, std::false_type{}, [&](int s) {
+                const int wd = s >> 2, part = s & 3;  // softmax of window wd in four slices (steps 4 wd .. 4 wd + 3)
+                if (part == 0) {
+                    float mx = st[wd][0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[wd][r]);
+                    smx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                } else if (part == 1) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float e = __expf(st[wd][r] - smx);
+                        st[wd][r] = e;
+                        sum += e;
+                    }
+                    ssum = sum;
+                } else if (part == 2) {
+                    const float inv = 1.0f / (ssum + __shfl_xor(ssum, 32, 64));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[wd][r] *= inv;
+                } else {
+                    pp[wd][0] = cvt8<0, LP>(st[wd]);
+                    pp[wd][1] = cvt8<1, LP>(st[wd]);
+                    asm volatile("" : "+v"(pp[wd][0]), "+v"(pp[wd][1]));
+                }
+            });
+            // the residual rows, straight into the projection's accumulators: one burst (see the Q pass) behind the pass: beside the V
+            // accumulators, P^T and the ring there is no room for them earlier; O^T, its exchange and the barrier cover part of their latency
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int4 ent = *reinterpret_cast<const int4*>(tcur + i * 32 + 8 * k + 4 * fk);
+                    const int en[4] = {ent.x, ent.y, ent.z, ent.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        accp[i][4 * k + e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsx, (en[e] << 10) + voff_ch, soff_w, 0));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+            for (int wd = 0; wd < 4; ++wd) {
+                // O^T[d][query] = sum_key V[key][d] P^T[key][query]:  A = V^T from the accumulator (X^T.B form), B = P^T (packed)
+                f32x16 ot;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[r] = 0.f;
+                ot = mfma16(cvt8<0, LP>(acc[wd]), pp[wd][0], ot);
+                ot = mfma16(cvt8<1, LP>(acc[wd]), pp[wd][1], ot);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) opk[wd][g][e] = to_lp<LP>(ot[4 * g + e]);
+            }
+        }
+        // rows d = 8 g + 4 fk + e of head h, column = query token fr (< 25)  ->  slab Yc[wd * 25 + fr][h * 32 + d]  (B1: nobody reads y-hat any more)
+#pragma unroll
+        for (int wd = 0; wd < 4; ++wd) {
+            unsigned char* const row = fr < NT ? sYc + (wd * NT + fr) * PA : sdummy;      // lanes 25..31 hold the next window's queries
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<lp4*>(row + (((h * HD + 8 * g + 4 * fk) * 2 - rot4 * 32) & 511)) = opk[wd][g];
+        }
+        lds_barrier();                                // the attention output is in slab Yc; every wave is done reading slab X
+        if (first) SPEI_STAMP(p.stamps, 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accp[i][r] += bias_p;
+        // ---- projection: the wave's 32 output channels of the 100 rows  + the next tile's x rows -> LayerNorm -> slab X ------------------------------
+        pass(std::integral_constant<int, 3>{}, sYc, aoff, accp, std::false_type{}, [&](int s) {
+            if (s == 0) {                             // the next tile's rows: one burst (see the Q pass), consumed in the second half of the pass
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) x_load(p.x + moffn, tnext, ps);
+                fill_table(tspare, tregs + (cur ? TABN : 0), tnx + G);      // the table of the tile after next (this tile's regions are used up)
+            }
+            if (s >= 8) {                             // 16 LayerNorm slices
+                ln_slice(tnext, (2 * s - 16) >> 2, (2 * s - 16) & 3, sX, rotn * 32);
+                ln_slice(tnext, (2 * s - 15) >> 2, (2 * s - 15) & 3, sX, rotn * 32);
+            }
+        });
+        if (first) SPEI_STAMP(p.stamps, 5);
+        // results: register 4 k + e of row tile i <-> slab row 32 i + 8 k + 4 fk + e, channel 32 wave + fr; one burst (the weight fragments
+        // of the next Q pass's first eight steps are already on their way)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int4 ent = *reinterpret_cast<const int4*>(tcur + i * 32 + 8 * k + 4 * fk);
+                const int en[4] = {ent.x, ent.y, ent.z, ent.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(accp[i][4 * k + e]), rso, (en[e] << 10) + voff_ch, soff_w, 0);
+                __builtin_amdgcn_sched_barrier(0);    // group by group: 16 table reads in flight at once are 64 more live registers
+            }
+        lds_barrier();                                // slab X holds the next tile; slab Yc is free; the table after next is complete
+        if (first) SPEI_STAMP(p.stamps, 6);
+        first = false;
+        int* const tt = tcur; tcur = tnext; tnext = tspare; tspare = tt;
+        cur ^= 1;
+        grp = grpn; bmap = bmapn; rot = rotn; rot4 = rot4n;
+    }
+    SPEI_STAMP(p.stamps, 7);
+}
+
 }  // namespace
 
 template <typename LP>
@@ -790,6 +1231,16 @@ static int attn4_launch(const float* x, float* out, const void* yhat, const void
     p.bkv = bkv; p.wproj = (const LP*)wproj; p.bproj = bproj; p.relbias = relbias;
     p.H = H; p.W = W; p.shift = shift; p.nwin = (H / WS) * (W / WS); p.groups = (p.nwin + WPG - 1) / WPG; p.batch = batch;
     p.stamps = spei_stamp_buffer();
+    static const int pipe = spei_knob("SPEI_ATTN_PIPE", 1);              // tuning build: 0 = one tile per workgroup (attn_win4_kernel)
+    if (pipe && (int64_t)H * W <= (1ll << 21)) {                         // 32-bit byte offsets into a map, 24-bit pixel indices in the table
+        const int ntiles = p.groups * batch;
+        const size_t lds = (size_t)3 * TOK * PA + 3 * TABN * sizeof(int) + 768 * sizeof(float) + PA + 2 * TABN;
+        ensure_dyn_lds<&attn_pipe_kernel<LP>>(lds);
+        static const int stagger = spei_knob("SPEI_PIPE_STAGGER", 2);
+        hipLaunchKernelGGL((attn_pipe_kernel<LP>), dim3(ntiles < spei_num_cus() ? ntiles : spei_num_cus()), dim3(512), lds, st, p, ntiles, stagger);
+        SPEI_CHECK_LAUNCH("spei_attn_win4_16");
+        return 0;
+    }
     const size_t lds = (size_t)TOK * PA + 2 * TOK * sizeof(int) + 1024 * sizeof(float);
     ensure_dyn_lds<&attn_win4_kernel<LP>>(lds);
     hipLaunchKernelGGL((attn_win4_kernel<LP>), dim3(p.groups * batch), dim3(512), lds, st, p);

@@ -87,6 +87,18 @@ inline int spei_num_cus() {
     return have[dev];
 }
 
+// Persistent kernels (one workgroup per CU, tile = blockIdx.x + k gridDim.x): the workgroups of a launch start together and do the
+// same work per tile, so chip-wide they issue every burst of loads at the same instant — 256 x 100 KB at once takes HBM 5 us to deliver,
+// whatever the average rate.  Each workgroup therefore starts `unit` x phase microseconds late, phase 0..3 by its place inside its XCD
+// (blockIdx / 8), + 4 for the workgroups that have one tile fewer than the others (they finish early anyway): the bursts of different
+// CUs then fall at different times for the whole launch.
+__device__ __forceinline__ void spei_stagger_start(int ntiles, int unit) {
+    const int G = gridDim.x, b = blockIdx.x;
+    const int mine = (ntiles - b + G - 1) / G, most = (ntiles + G - 1) / G;
+    const int phase = (mine < most ? 4 : 0) + ((b >> 3) & 3);
+    for (int i = 0; i < phase * unit; ++i) __builtin_amdgcn_s_sleep(32);      // 32 x 64 cycles ~ 1 us
+}
+
 // ---- cross-lane reductions on the VALU (DPP + gfx950 permlane swaps): no LDS-pipe traffic, unlike __shfl_xor -------
 // (ds_bpermute; 12 of them per wave_sum made the LayerNorm / gate-statistics kernels LDS-instruction-bound)
 template <int CTRL>

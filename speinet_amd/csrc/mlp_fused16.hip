@@ -334,7 +334,7 @@ constexpr int RP3 = MP / 32;                        // 32-token row tiles per ti
 constexpr int SLABP = MP * PA;                      // one slab (bytes)
 
 template <typename LP>
-__global__ __launch_bounds__(512) void mlp_pipe_kernel(const MlpParams<LP> p, const int ntiles) {
+__global__ __launch_bounds__(512) void mlp_pipe_kernel(const MlpParams<LP> p, const int ntiles, const int stagger) {
     typedef typename lpv<LP>::x8 lp8;
     typedef typename lpv<LP>::x4 lp4;
     constexpr int RG = 8;                                   // weight fragments in flight per wave
@@ -347,6 +347,7 @@ __global__ __launch_bounds__(512) void mlp_pipe_kernel(const MlpParams<LP> p, co
     const int l16 = tid & 15, rsub = tid >> 4;              // LayerNorm staging: 16 lanes per token, 32 tokens per pass
 
     SPEI_STAMP(p.stamps, 0); SPEI_STAMP_CLK(p.stamps, 8 + 0);
+    spei_stagger_start(ntiles, stagger);
     bias1[tid] = p.b1[tid];
     const float bias2 = p.b2[wave * 32 + fr];
     // The weight stream through buffer loads: descriptor and fragment offset in scalar registers, one vector register (lane x 16) for
@@ -370,7 +371,10 @@ __global__ __launch_bounds__(512) void mlp_pipe_kernel(const MlpParams<LP> p, co
         xr[b][j] = reinterpret_cast<const f32x4*>(p.x + (size_t)m * D)[l16 + 16 * j];
     };
     // LayerNorm of pass b (32 tokens) in four slices: sum | centre, squares | rstd | scale, convert, write (rotated by rb bytes)
+    // (inlined in the prologue and in P4: products and sums spelled out, contraction off — a tile's LayerNorm must not depend on which of
+    // the two computed it)
     auto ln_slice = [&](int b, int sub, unsigned char* dst, int rb) {
+#pragma clang fp contract(off)
         if (sub == 0) {
             float s = 0.f;
 #pragma unroll
@@ -381,11 +385,11 @@ __global__ __launch_bounds__(512) void mlp_pipe_kernel(const MlpParams<LP> p, co
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 xr[b][j] -= lnm[b];
-                ss += (xr[b][j][0] * xr[b][j][0] + xr[b][j][1] * xr[b][j][1]) + (xr[b][j][2] * xr[b][j][2] + xr[b][j][3] * xr[b][j][3]);
+                ss += __builtin_fmaf(xr[b][j][1], xr[b][j][1], xr[b][j][0] * xr[b][j][0]) + __builtin_fmaf(xr[b][j][3], xr[b][j][3], xr[b][j][2] * xr[b][j][2]);
             }
             lns[b] = ss;
         } else if (sub == 2) {
-            lns[b] = 1.0f / sqrtf(sum16(lns[b]) * (1.0f / 256.0f) + 1e-5f);
+            lns[b] = 1.0f / sqrtf(__builtin_fmaf(sum16(lns[b]), 1.0f / 256.0f, 1e-5f));
         } else {
             const int r = b * 32 + rsub;
 #pragma unroll
@@ -570,7 +574,8 @@ static int mlp_launch(const float* x, float* out, const void* w1, const float* b
         const int ntiles = cdiv(M, MP);
         const size_t lds = (size_t)3 * SLABP + HID * sizeof(float);
         ensure_dyn_lds<&mlp_pipe_kernel<LP>>(lds);
-        hipLaunchKernelGGL(mlp_pipe_kernel<LP>, dim3(ntiles < spei_num_cus() ? ntiles : spei_num_cus()), dim3(512), lds, st, p, ntiles);
+        static const int stagger = spei_knob("SPEI_PIPE_STAGGER", 2);
+        hipLaunchKernelGGL(mlp_pipe_kernel<LP>, dim3(ntiles < spei_num_cus() ? ntiles : spei_num_cus()), dim3(512), lds, st, p, ntiles, stagger);
         SPEI_CHECK_LAUNCH("spei_mlp_fused16");
         return 0;
     }
