@@ -1124,10 +1124,12 @@ __global__ __launch_bounds__(512) void attn_pipe_kernel(const Attn4Params<LP> p,
                     asm volatile("" : "+v"(pp[wd][0]), "+v"(pp[wd][1]));
                 }
             });
-            // the residual rows, straight into the projection's accumulators: one burst (see the Q pass) behind the pass: beside the V
-            // accumulators, P^T and the ring there is no room for them earlier; O^T, its exchange and the barrier cover part of their latency
+            // The residual rows, straight into the projection's accumulators, behind the pass (beside the V accumulators, P^T and the ring
+            // there is no room for them earlier) and in two halves around the O^T computation: a wave can have 63 vector-memory accesses
+            // outstanding, and 64 loads on top of the ring's 8 would stop at the queue.  Each half is a burst (see the Q pass); O^T, its
+            // exchange and the barrier cover part of their latency.
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int4 ent = *reinterpret_cast<const int4*>(tcur + i * 32 + 8 * k + 4 * fk);
@@ -1150,6 +1152,17 @@ __global__ __launch_bounds__(512) void attn_pipe_kernel(const Attn4Params<LP> p,
 #pragma unroll
                     for (int e = 0; e < 4; ++e) opk[wd][g][e] = to_lp<LP>(ot[4 * g + e]);
             }
+#pragma unroll
+            for (int i = 2; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int4 ent = *reinterpret_cast<const int4*>(tcur + i * 32 + 8 * k + 4 * fk);
+                    const int en[4] = {ent.x, ent.y, ent.z, ent.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        accp[i][4 * k + e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsx, (en[e] << 10) + voff_ch, soff_w, 0));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
         }
         // rows d = 8 g + 4 fk + e of head h, column = query token fr (< 25)  ->  slab Yc[wd * 25 + fr][h * 32 + d]  (B1: nobody reads y-hat any more)
 #pragma unroll
@@ -1177,10 +1190,10 @@ __global__ __launch_bounds__(512) void attn_pipe_kernel(const Attn4Params<LP> p,
             }
         });
         if (first) SPEI_STAMP(p.stamps, 5);
-        // results: register 4 k + e of row tile i <-> slab row 32 i + 8 k + 4 fk + e, channel 32 wave + fr; one burst (the weight fragments
-        // of the next Q pass's first eight steps are already on their way)
+        // results: register 4 k + e of row tile i <-> slab row 32 i + 8 k + 4 fk + e, channel 32 wave + fr; two bursts of 32 (the queue
+        // holds 63), the barrier between them (the weight fragments of the next Q pass's first eight steps are already on their way)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int4 ent = *reinterpret_cast<const int4*>(tcur + i * 32 + 8 * k + 4 * fk);
@@ -1191,6 +1204,17 @@ __global__ __launch_bounds__(512) void attn_pipe_kernel(const Attn4Params<LP> p,
                 __builtin_amdgcn_sched_barrier(0);    // group by group: 16 table reads in flight at once are 64 more live registers
             }
         lds_barrier();                                // slab X holds the next tile; slab Yc is free; the table after next is complete
+#pragma unroll
+        for (int i = 2; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int4 ent = *reinterpret_cast<const int4*>(tcur + i * 32 + 8 * k + 4 * fk);
+                const int en[4] = {ent.x, ent.y, ent.z, ent.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(accp[i][4 * k + e]), rso, (en[e] << 10) + voff_ch, soff_w, 0);
+                __builtin_amdgcn_sched_barrier(0);    // group by group: 16 table reads in flight at once are 64 more live registers
+            }
         if (first) SPEI_STAMP(p.stamps, 6);
         first = false;
         int* const tt = tcur; tcur = tnext; tnext = tspare; tspare = tt;
@@ -1236,7 +1260,7 @@ static int attn4_launch(const float* x, float* out, const void* yhat, const void
         const int ntiles = p.groups * batch;
         const size_t lds = (size_t)3 * TOK * PA + 3 * TABN * sizeof(int) + 768 * sizeof(float) + PA + 2 * TABN;
         ensure_dyn_lds<&attn_pipe_kernel<LP>>(lds);
-        static const int stagger = spei_knob("SPEI_PIPE_STAGGER", 2);
+        static const int stagger = spei_knob("SPEI_PIPE_STAGGER", 0);
         hipLaunchKernelGGL((attn_pipe_kernel<LP>), dim3(ntiles < spei_num_cus() ? ntiles : spei_num_cus()), dim3(512), lds, st, p, ntiles, stagger);
         SPEI_CHECK_LAUNCH("spei_attn_win4_16");
         return 0;

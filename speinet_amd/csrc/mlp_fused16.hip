@@ -574,7 +574,7 @@ static int mlp_launch(const float* x, float* out, const void* w1, const float* b
         const int ntiles = cdiv(M, MP);
         const size_t lds = (size_t)3 * SLABP + HID * sizeof(float);
         ensure_dyn_lds<&mlp_pipe_kernel<LP>>(lds);
-        static const int stagger = spei_knob("SPEI_PIPE_STAGGER", 2);
+        static const int stagger = spei_knob("SPEI_PIPE_STAGGER", 0);
         hipLaunchKernelGGL(mlp_pipe_kernel<LP>, dim3(ntiles < spei_num_cus() ? ntiles : spei_num_cus()), dim3(512), lds, st, p, ntiles, stagger);
         SPEI_CHECK_LAUNCH("spei_mlp_fused16");
         return 0;
