@@ -169,6 +169,9 @@ def frame_post(out_chw: torch.Tensor, gt_hwc: torch.Tensor, border: int = 4):
     return u8, res
 
 
+CORR_DIAG_WS_MAX = 8 << 30      # bytes of candidate pairs the diagonal correlation kernel may use before the slab kernel takes over
+
+
 class CorrPlan:
     """A prepared K11 launch (see Ctx.corr_plan): `launch()` runs the arg-max kernel — bracketed by the profile events — and
     whatever must follow it on the same stream (the exact re-score of the "top2" form)."""
@@ -658,14 +661,20 @@ class Ctx:
         n = lr.H * lr.W
         s = torch.empty(n, device=dev)
         arg = torch.empty(n, device=dev, dtype=torch.int32)
-        ws = torch.empty(lib.spei_corr_ws_floats(n), device=dev)
         dims = (lr.H, lr.W, ref.H, ref.W, lr.C)
+        rescore = self.precision != "f32" and self.corr_precision == "top2" and self.use_slab and lr.C == 128
+        # the diagonal kernel keeps one candidate pair per (query, diagonal, reference tile): 415 MB at 720p, ~34 GB at 4K — beyond the
+        # budget (a quarter of the device's free memory, at most 8 GiB) the slab kernel takes over (its workspace is per query only)
+        diag, diag_floats = False, 0
+        if rescore and self.corr_diag and ref.H >= lr.H:
+            diag_floats = lib.spei_corr_diag_ws_floats(lr.H, lr.W, ref.H, ref.W)
+            diag = 4 * diag_floats <= min(torch.cuda.mem_get_info(dev)[0] // 4, CORR_DIAG_WS_MAX)
+        ws = torch.empty(diag_floats if diag else lib.spei_corr_ws_floats(n), device=dev)
         if self.precision == "f32":
             args = (fp(lr), lr.ld, fp(ref), ref.ld, tp(inv_lr), tp(inv_ref), *dims, tp(s), tp(arg), tp(ws))
             return CorrPlan(self, s, arg, "corr_argmax_kernel (f32 MFMA)", [(lib.spei_corr_argmax, "spei_corr_argmax", args)], [],
                             (lr, ref, inv_lr, inv_ref, ws))
         split = self.corr_precision == "bf16x3"
-        rescore = self.corr_precision == "top2" and self.use_slab and lr.C == 128
         f16 = BF16 if (rescore and self.corr_bf16) else self.fmt
         assert f16 == BF16 or (not split and self.use_slab and lr.C == 128), "f16 correlation: slab kernel, single / top2"
         parts = []
@@ -678,9 +687,7 @@ class Ctx:
         if rescore:
             arg2 = torch.empty(n, device=dev, dtype=torch.int32)
             s2 = torch.empty(n, device=dev)
-            diag = self.corr_diag and ref.H >= lr.H
             if diag:
-                ws = torch.empty(lib.spei_corr_diag_ws_floats(lr.H, lr.W, ref.H, ref.W), device=dev)
                 main = (lib.spei_corr_diag_top2_16, "spei_corr_diag_top2_16",
                         (f16, tp(parts[0]), tp(parts[2]), tp(inv_ref), *dims, tp(s), tp(arg), tp(s2), tp(arg2), tp(ws)))
             else:

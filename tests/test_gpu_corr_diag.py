@@ -128,6 +128,21 @@ def test_corr_diag_lower_reference_map_takes_the_slab_kernel():
     assert rc != 0 and b"Hr" in _lib.lib().spei_last_error()
 
 
+def test_corr_diag_workspace_budget_falls_back_to_the_slab_kernel(monkeypatch):
+    """The diagonal kernel's candidate workspace grows with Hr * Wr / 64 * Hl * Wl (34 GB at 4K): beyond `ops.CORR_DIAG_WS_MAX` the
+    slab kernel (workspace per query only) takes the call, with the same decision."""
+    from speinet_amd import ops as ops_mod
+    lr3, rf3 = rnd(71, 1, 128, 24, 40), rnd(72, 1, 128, 24, 40)
+    ops = Ctx("f16", "top2", device=DEV)
+    inv_l, inv_r = ops.patch_invnorm(fm(lr3)), ops.patch_invnorm(fm(rf3))
+    s, arg = ops.corr_argmax(fm(lr3), fm(rf3), inv_l, inv_r)
+    monkeypatch.setattr(ops_mod, "CORR_DIAG_WS_MAX", 1 << 10)
+    plan = ops.corr_plan(fm(lr3), fm(rf3), inv_l, inv_r)
+    assert plan.kernel.startswith("corr_slab_kernel")
+    plan.launch()
+    assert torch.equal(plan.arg, arg) and (plan.s - s).abs().max().item() < 1e-6
+
+
 def test_corr_diag_random_shapes():
     """A seeded sweep of 24 ragged shape pairs (query hl x wl, reference hr x wr with hr >= hl): segment boundaries, wraps of the cyclic
     diagonals inside a segment, partial tiles on either map, groups of diagonals that are not full — against the float64 oracle."""
