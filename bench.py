@@ -195,7 +195,7 @@ def family_records(fam_events: dict, n_frames: int, h: int, w: int, has_ref: boo
     scale = hw / float(H * W)
     blocks_per_level = (7 if has_ref else 6) * 3 + 3                  # encoder passes x 3 ResBlocks + the decoder's 3, per level
     work = {"conv": ("mfma", 8.536e12 * scale, "conv_slab / igemm / conv5 (every Conv2d, ConvTranspose2d; Swin's 3x3 convs)"),
-            "swin": ("mfma", 4.455e12 * scale, "attn_win4 + mlp_fused (72 Swin blocks: LayerNorm, q/kv/proj, W-MSA, MLP)"),
+            "swin": ("mfma", 4.455e12 * scale, "attn_pipe + mlp_pipe, both Swin calls of a frame per launch (72 Swin blocks: LayerNorm, q/kv/proj, W-MSA, MLP)"),
             "correlation": ("mfma", corr_flops(h, w), "corr_diag / corr_slab + reduce + re-score (SearchTransfer's bmm + max)"),
             "streaming": ("hbm", blocks_per_level * 56.0 * hw * 12.0, "gate_stats / gate_maps / resblock_apply (SE + triplet gates, gated residual sum)")}
     out = {}

@@ -42,7 +42,7 @@ for r in seg:
 print("kernel time per stream: " + ", ".join(f"{k}: {v / 1e6:.2f} ms" for k, v in per.items()))
 # coarse phases: 1 ms buckets, kernels per bucket by family
 def fam(n):
-    for k in ("corr_slab", "corr_diag", "corr_rescore", "attn_fused", "attn_win4", "mlp_fused", "conv_slab", "conv5", "gate_", "resblock_apply", "layernorm", "bicubic", "gather_fold", "rl_", "patch_invnorm"):
+    for k in ("corr_slab", "corr_diag", "corr_rescore", "attn_fused", "attn_win4", "attn_pipe", "mlp_fused", "mlp_pipe", "conv32_ws", "conv_slab", "conv5", "gate_", "resblock_apply", "layernorm", "bicubic", "gather_fold", "rl_", "patch_invnorm"):
         if k in n:
             return k
     return "other"

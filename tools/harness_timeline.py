@@ -52,7 +52,7 @@ print(f"{nwin} windows, {(t1 - t0) / 1e6 / nwin:.2f} ms per window, {len(seg) / 
 
 
 def fam(name):
-    for k in ("corr_diag_kernel", "corr_diag_reduce", "corr_diag_final", "corr_slab", "corr_rescore", "attn_fused", "attn_win4", "mlp_fused", "conv_slab", "igemm_bf16",
+    for k in ("corr_diag_kernel", "corr_diag_reduce", "corr_diag_final", "corr_slab", "corr_rescore", "attn_fused", "attn_win4", "attn_pipe", "mlp_fused", "mlp_pipe", "conv32_ws", "conv_slab", "igemm_bf16",
               "igemm_f32", "conv5_in", "conv5_out", "gate_", "resblock_apply", "layernorm", "bicubic", "gather_fold", "rl_iter", "patch_invnorm",
               "add_kernel", "split16", "rot90", "any_nonzero"):
         if k in name:

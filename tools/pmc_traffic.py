@@ -41,7 +41,7 @@ out = {"commit": sys.argv[6] if len(sys.argv) > 6 else "n/a", KEY: {"kernel": kn
                              "HBM section); algorithmic compulsory bytes = 2 maps x 14.7 MB (16-bit) + 0.9 MB outputs; the diagonal kernel also writes one "
                              "key pair per (query, diagonal, reference tile): 415 MB at 720p, read back once by its reduce kernel"}}
 # per kernel family (bench.py's roofline.families): the same sums restricted to the family's kernels
-FAMILIES = {"swin": r"attn_fused_kernel|attn_win4_kernel|mlp_fused_kernel",
+FAMILIES = {"swin": r"attn_fused_kernel|attn_win4_kernel|attn_pipe_kernel|mlp_fused_kernel|mlp_pipe_kernel",
             "conv": r"conv_slab_kernel|igemm_bf16_kernel|igemm_f32_kernel|conv5_in_kernel|conv5_out_kernel",
             "correlation": r"corr_(slab|diag)_kernel|corr_diag_reduce|corr_diag_final|corr_rescore|corr_argmax",
             "streaming": r"resblock_apply|gate_stats|gate_maps"}
