@@ -143,6 +143,12 @@ int spei_convt2_slab16(int fmt, const void* a0, int lda0, int k0, int a_fmt, con
                        const void* wfrag10, const void* wfrag11, const float* bias, void* out, int ldo, int out_fmt,
                        int Hin, int Win, int N, int act, spei_stream_t stream);
 
+/* The same transposed conv in split (bf16x3, f32-grade) arithmetic: fp32 in, fp32 out; whi4 / wlo4: the four class weights (order (0,0),
+ * (0,1), (1,0), (1,1)) as bf16 high halves and low halves (= bf16(w - hi)) in fragment order.  Replaces the round-1 igemm path for the
+ * ConvTranspose2d that ends decoder_second inside an f16 frame's split stages (model/recons_video_ori.py:59-70, model/speinet.py:99). */
+int spei_convt2_slab16x3(const float* a0, int lda0, int k0, const void* const* whi4, const void* const* wlo4, const float* bias,
+                         float* out, int ldo, int Hin, int Win, int N, int act, spei_stream_t stream);
+
 /* Last conv (model/recons_video_ori.py:75-77: 5x5, 32 -> 3 channels, NHWC in, three NCHW fp32 planes out) on the
  * slab kernel: wfrag = fragment-ordered weights zero-padded to 32 output channels, bias32 = bias padded to 32. */
 int spei_conv5_out_slab16(int fmt, const void* in, int ldi, int in_fmt, const void* wfrag, const float* bias32, float* out_chw,

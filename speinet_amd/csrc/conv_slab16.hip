@@ -676,22 +676,14 @@ extern "C" int spei_conv_slab16_fa(int fmt, const float* x, int K, const void* x
                            ksize, 1, ksize / 2, act, 0, x1, s, g1, g2, x_out, stream);
 }
 
-extern "C" int spei_convt2_slab16(int fmt, const void* a0, int lda0, int k0, int a_fmt, const void* wfrag00, const void* wfrag01,
-                                  const void* wfrag10, const void* wfrag11, const float* bias, void* out, int ldo, int out_fmt,
-                                  int Hin, int Win, int N, int act, spei_stream_t stream) {
-    SPEI_REQUIRE(a0 && wfrag00 && wfrag01 && wfrag10 && wfrag11 && out, "spei_convt2_slab16: null pointer");
-    SPEI_REQUIRE_FMT("spei_convt2_slab16", fmt, a_fmt, out_fmt);
-    const bool a16 = a_fmt != SPEI_F32, o16 = out_fmt != SPEI_F32;
-    SPEI_REQUIRE(k0 > 0 && k0 % 32 == 0 && N > 0 && N % 32 == 0, "spei_convt2_slab16: K=%d N=%d must be multiples of 32", k0, N);
-    SPEI_REQUIRE(lda0 % (a16 ? 8 : 4) == 0 && lda0 >= k0 && ldo >= N && ldo % 4 == 0, "spei_convt2_slab16: bad row strides");
-    SPEI_REQUIRE(Hin > 0 && Win > 0 && (int64_t)Hin * Win * 4 * ldo < (1ll << 32), "spei_convt2_slab16: bad map size");
-    SPEI_REQUIRE(((uintptr_t)a0 | (uintptr_t)out | (uintptr_t)wfrag00 | (uintptr_t)wfrag01 | (uintptr_t)wfrag10 | (uintptr_t)wfrag11) % 16 == 0,
-                 "spei_convt2_slab16: operands must be 16-byte aligned");
-    const void* wf[2][2] = {{wfrag00, wfrag01}, {wfrag10, wfrag11}};
+// the four output-parity classes of a 3x3 stride-2 transposed conv as tap-list launches of the slab kernel; wl: the bf16 low halves of the
+// class weights (split = bf16x3 arithmetic), else NULL
+static int convt2_launch(int fmt, const void* a0, int lda0, int k0, bool a16, const void* const (&wf)[2][2], const void* const (*wl)[2],
+                         const float* bias, void* out, int ldo, bool o16, int Hin, int Win, int N, int act, hipStream_t stream) {
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
             SlabParams p = {};
-            p.a0 = a0; p.a1 = nullptr; p.wh = wf[py][px]; p.wl = nullptr; p.bias = bias; p.out = out;
+            p.a0 = a0; p.a1 = nullptr; p.wh = wf[py][px]; p.wl = wl ? wl[py][px] : nullptr; p.bias = bias; p.out = out;
             p.res = nullptr; p.rowscale = nullptr;
             p.lda0 = lda0; p.lda1 = 0; p.k0 = k0; p.k1 = 0; p.ldo = ldo; p.ldr = 0;
             p.N = N; p.K = k0;
@@ -706,10 +698,39 @@ extern "C" int spei_convt2_slab16(int fmt, const void* a0, int lda0, int k0, int
                     ++p.ntap;
                 }
             p.o_mul = 2; p.o_row_add = py; p.o_col_add = px; p.Wfull = 2 * Win; p.planes = 0;
-            const int rc = dispatch_fmt(p, fmt, false, a16, o16, (hipStream_t)stream);
+            const int rc = dispatch_fmt(p, fmt, wl != nullptr, a16, o16, stream);
             if (rc) return rc;
         }
     return 0;
+}
+
+extern "C" int spei_convt2_slab16x3(const float* a0, int lda0, int k0, const void* const* whi4, const void* const* wlo4, const float* bias,
+                                    float* out, int ldo, int Hin, int Win, int N, int act, spei_stream_t stream) {
+    SPEI_REQUIRE(a0 && whi4 && wlo4 && out, "spei_convt2_slab16x3: null pointer");
+    for (int i = 0; i < 4; ++i)
+        SPEI_REQUIRE(whi4[i] && wlo4[i] && ((uintptr_t)whi4[i] | (uintptr_t)wlo4[i]) % 16 == 0, "spei_convt2_slab16x3: class %d weights missing or unaligned", i);
+    SPEI_REQUIRE(k0 > 0 && k0 % 32 == 0 && N > 0 && N % 32 == 0, "spei_convt2_slab16x3: K=%d N=%d must be multiples of 32", k0, N);
+    SPEI_REQUIRE(lda0 % 4 == 0 && lda0 >= k0 && ldo >= N && ldo % 4 == 0, "spei_convt2_slab16x3: bad row strides");
+    SPEI_REQUIRE(Hin > 0 && Win > 0 && (int64_t)Hin * Win * 4 * ldo < (1ll << 32), "spei_convt2_slab16x3: bad map size");
+    SPEI_REQUIRE(((uintptr_t)a0 | (uintptr_t)out) % 16 == 0, "spei_convt2_slab16x3: operands must be 16-byte aligned");
+    const void* const wf[2][2] = {{whi4[0], whi4[1]}, {whi4[2], whi4[3]}};
+    const void* const wl[2][2] = {{wlo4[0], wlo4[1]}, {wlo4[2], wlo4[3]}};
+    return convt2_launch(SPEI_BF16, a0, lda0, k0, false, wf, wl, bias, out, ldo, false, Hin, Win, N, act, (hipStream_t)stream);
+}
+
+extern "C" int spei_convt2_slab16(int fmt, const void* a0, int lda0, int k0, int a_fmt, const void* wfrag00, const void* wfrag01,
+                                  const void* wfrag10, const void* wfrag11, const float* bias, void* out, int ldo, int out_fmt,
+                                  int Hin, int Win, int N, int act, spei_stream_t stream) {
+    SPEI_REQUIRE(a0 && wfrag00 && wfrag01 && wfrag10 && wfrag11 && out, "spei_convt2_slab16: null pointer");
+    SPEI_REQUIRE_FMT("spei_convt2_slab16", fmt, a_fmt, out_fmt);
+    const bool a16 = a_fmt != SPEI_F32, o16 = out_fmt != SPEI_F32;
+    SPEI_REQUIRE(k0 > 0 && k0 % 32 == 0 && N > 0 && N % 32 == 0, "spei_convt2_slab16: K=%d N=%d must be multiples of 32", k0, N);
+    SPEI_REQUIRE(lda0 % (a16 ? 8 : 4) == 0 && lda0 >= k0 && ldo >= N && ldo % 4 == 0, "spei_convt2_slab16: bad row strides");
+    SPEI_REQUIRE(Hin > 0 && Win > 0 && (int64_t)Hin * Win * 4 * ldo < (1ll << 32), "spei_convt2_slab16: bad map size");
+    SPEI_REQUIRE(((uintptr_t)a0 | (uintptr_t)out | (uintptr_t)wfrag00 | (uintptr_t)wfrag01 | (uintptr_t)wfrag10 | (uintptr_t)wfrag11) % 16 == 0,
+                 "spei_convt2_slab16: operands must be 16-byte aligned");
+    const void* const wf[2][2] = {{wfrag00, wfrag01}, {wfrag10, wfrag11}};
+    return convt2_launch(fmt, a0, lda0, k0, a16, wf, nullptr, bias, out, ldo, o16, Hin, Win, N, act, (hipStream_t)stream);
 }
 
 extern "C" int spei_conv5_out_slab16(int fmt, const void* in, int ldi, int in_fmt, const void* wfrag, const float* bias32, float* out_chw,

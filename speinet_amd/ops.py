@@ -422,6 +422,13 @@ class Ctx:
             _lib.check(lib.spei_convt2_slab16(self.fmt, fp(a0), a0.ld, k0, a0.fmt, tp(cf[(0, 0)]), tp(cf[(0, 1)]), tp(cf[(1, 0)]),
                                               tp(cf[(1, 1)]), tp(bias), fp(out), out.ld, out.fmt, a0.H, a0.W, N, act,
                                               self._stream()), "spei_convt2_slab16")
+        elif (mode == CONV_T and prec == "bf16x3" and self.use_slab and ksize == 3 and stride == 2 and a1 is None and residual is None
+                and rowscale is None and N % 32 == 0 and k0 % 32 == 0 and not a0.lp and not out.lp):
+            # the same in split arithmetic (the transposed conv that ends decoder_second inside an f16 frame's split stages; round 1's igemm
+            # kernel took 327 us for it)
+            _hi, _lo, ph, pl = w.convT_class_frags_split()
+            _lib.check(lib.spei_convt2_slab16x3(fp(a0), a0.ld, k0, ph, pl, tp(bias), fp(out), out.ld, a0.H, a0.W, N, act, self._stream()),
+                       "spei_convt2_slab16x3")
         elif prec == "f32":
             _lib.check(lib.spei_igemm_f32(*srcs, tp(w.f32), tp(bias), *common), "spei_igemm_f32")
         elif slab and w.fhi is not None:

@@ -68,14 +68,29 @@ class PackedW:
         1 -> k = 0 (d = 1), k = 2 (d = 0) — the tap order spei_convt2_slab16 assumes."""
         if fmt not in self._ct:
             assert self.shape[0] == 9
-            src = self.f32.to(LP_DTYPE[fmt])
-            ct = {}
-            for py in (0, 1):
-                for px in (0, 1):
-                    kys, kxs = ([0, 2] if py else [1]), ([0, 2] if px else [1])
-                    ct[(py, px)] = _frag(torch.stack([src[ky * 3 + kx] for ky in kys for kx in kxs]))
-            self._ct[fmt] = ct
+            self._ct[fmt] = self._class_frags(self.f32.to(LP_DTYPE[fmt]))
         return self._ct[fmt]
+
+    @staticmethod
+    def _class_frags(src: torch.Tensor) -> dict:
+        ct = {}
+        for py in (0, 1):
+            for px in (0, 1):
+                kys, kxs = ([0, 2] if py else [1]), ([0, 2] if px else [1])
+                ct[(py, px)] = _frag(torch.stack([src[ky * 3 + kx] for ky in kys for kx in kxs]))
+        return ct
+
+    def convT_class_frags_split(self):
+        """(hi, lo) class fragments for the split (bf16x3) form, spei_convt2_slab16x3, + the two device arrays of four pointers it takes."""
+        if "split" not in self._ct:
+            assert self.shape[0] == 9
+            hi, lo = self._class_frags(self.hi), self._class_frags(self.lo)
+            order = [(0, 0), (0, 1), (1, 0), (1, 1)]
+            import ctypes as C
+            ph = (C.c_void_p * 4)(*[hi[k].data_ptr() for k in order])
+            pl = (C.c_void_p * 4)(*[lo[k].data_ptr() for k in order])
+            self._ct["split"] = (hi, lo, ph, pl)
+        return self._ct["split"]
 
 
 def conv_w(w: torch.Tensor) -> torch.Tensor:
