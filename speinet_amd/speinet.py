@@ -613,19 +613,20 @@ def _wants_autograd(model: nn.Module, x: torch.Tensor) -> bool:
     """Which graph a `forward` call builds.  train() mode: always the differentiable one (the reference trainer's step).  eval():
     only when the caller asks for gradients — the input requires grad, or `model.autograd = True` — and autograd is recording;
     a plain eval() call outside `torch.no_grad()` (the reference's trainers do evaluate under no_grad, trainer_swint_hsa_nsf.py:57)
-    stays on the inference path in the model's `precision`, with a one-time warning: saving every activation of a 720p frame for a
+    stays on the inference path in the model's `precision`, with a warning per call site unless `model.autograd = False` says it is meant: saving every activation of a 720p frame for a
     backward nobody asked for is what round 2 did there."""
     if model.training:
         return True
     if not torch.is_grad_enabled():
         return False
-    if x.requires_grad or getattr(model, "autograd", False):
+    want = getattr(model, "autograd", None)           # None: not stated; True / False: the caller's explicit choice
+    if x.requires_grad or want:
         return True
-    if any(p.requires_grad for p in model.parameters()) and not getattr(model, "_warned_eval_grad", False):
-        import warnings
-        model._warned_eval_grad = True
-        warnings.warn("speinet_amd: eval()-mode forward with autograd recording runs the INFERENCE kernels (no graph is built); "
-                      "set `model.autograd = True`, pass an input that requires grad, or call model.train() to differentiate")
+    if want is None and any(p.requires_grad for p in model.parameters()):
+        import warnings                               # once per call site (Python's default filter), not once per model
+        warnings.warn("speinet_amd: eval()-mode forward with autograd recording runs the INFERENCE kernels (no graph is built, unlike the "
+                      "reference nn.Module); set `model.autograd = True` to differentiate (or pass an input that requires grad, or call "
+                      "model.train()), `model.autograd = False` to silence this", stacklevel=4)
     return False
 
 

@@ -460,10 +460,16 @@ def test_trainer_steps_reduce_the_loss():
     ev2 = net(x)                                   # the differentiable graph reads the live parameters
     assert ev2.requires_grad
     assert (ev - ev2.detach()).abs().max().item() < 2e-5
-    net.autograd = False
+    del net.autograd                               # intent not stated: inference path, and a warning at the call site
     with pytest.warns(UserWarning, match="INFERENCE kernels"):
-        ev3 = net(x)                               # autograd recording, nobody asked for a graph: inference path, one warning
+        ev3 = net(x)
     assert not ev3.requires_grad and torch.equal(ev3, ev)
+    net.autograd = False                           # stated: inference path, silent
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        ev4 = net(x)
+    assert not ev4.requires_grad and torch.equal(ev4, ev)
 
 
 @pytest.mark.parametrize("which", ["swint", "speinet"])
