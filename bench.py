@@ -63,6 +63,7 @@ sys.path.insert(0, ROOT)
 H, W = 720, 1280
 # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters: dense matrix peaks (never the 2:1-sparsity figures)
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0, "f16": 2500.0}
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 TRAFFIC_FILES = ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
 
 
@@ -181,6 +182,31 @@ def cpu_baseline(seed: int, mode: str, budget_s: float) -> dict:
             "sample": f"EXTRAPOLATED: oracle, {host}: best of two timed {sw}x{sh} _forwardbs frames after a warm-up ({probes[0]:.2f} s, "
                       f"{probes[1]:.2f} s), scaled x{scale:.2f} to 720p by F(HW) of BASELINE.md (optimistic: the 57600^2 correlation does "
                       "not scale like FLOPs)"}
+
+
+def conv_sub_records(conv_sub: dict, n_frames: int, conv_flops: float, peak: float) -> dict:
+    """The conv family by what bounds it: `level1` = the 32-channel 5x5 layers at full resolution (+ the first / last conv), priced against
+    HBM on the activation bytes they must move (input + output of every launch, weights excluded); `rest` = every other conv (64 / 128 /
+    256 channels, 1x1 and 3x3 glue, stride-2 and transposed convs), priced against the matrix pipe on the family's remaining flops."""
+    out = {}
+    if not conv_sub or not n_frames:
+        return out
+    l1 = conv_sub.get("level1")
+    if l1 and l1["events"]:
+        ms = sum(s_.elapsed_time(e_) for s_, e_ in l1["events"]) / n_frames
+        by, fl = l1["bytes"] / n_frames, l1["flops"] / n_frames
+        out["level1"] = {"ms_per_frame": ms, "launches_per_frame": len(l1["events"]) / n_frames, "bound": "hbm",
+                         "algorithmic_bytes_per_frame": by, "algorithmic_flops_per_frame": fl, "achieved": by / (ms * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "mfma_frac": fl / (ms * 1e-3) / 1e12 / peak}
+    rest = conv_sub.get("rest")
+    if rest and rest["events"]:
+        ms = sum(s_.elapsed_time(e_) for s_, e_ in rest["events"]) / n_frames
+        fl = conv_flops - (l1["flops"] / n_frames if l1 else 0.0)
+        out["rest"] = {"ms_per_frame": ms, "launches_per_frame": len(rest["events"]) / n_frames, "bound": "mfma",
+                       "algorithmic_flops_per_frame": fl, "achieved": fl / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                       "frac": fl / (ms * 1e-3) / 1e12 / peak}
+    return out
 
 
 def family_records(fam_events: dict, n_frames: int, h: int, w: int, has_ref: bool, peak: float, fam_hbm: dict, diag: bool) -> dict:
@@ -506,6 +532,8 @@ def main():
         k_bytes, path_hbm, tsrc, fam_hbm = traffic_bytes(args.precision, args.corr_precision) if (h, w) == (H, W) else (None, None, None, {})
         qs = statistics.quantiles(step_ms, n=10) if len(step_ms) >= 2 else [step_ms[0]] * 9
         families = family_records(fam_prof["families"], fam_frames, h, w, args.branch == "bs", peak, fam_hbm, kname.startswith("corr_diag"))
+        if "conv" in families:
+            families["conv"]["by_bound"] = conv_sub_records(fam_prof.get("conv_sub"), fam_frames, families["conv"]["algorithmic_flops_per_frame"], peak)
         top = max(families, key=lambda k: families[k]["ms_per_frame"]) if families else None
         line = {
             "metric": "deblurred 720p frames/sec", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,

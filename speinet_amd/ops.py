@@ -127,9 +127,30 @@ class _timed:
         return False
 
 
+def _tensor_bytes(x) -> int:
+    t = x.t if hasattr(x, "t") else x
+    return t.numel() * t.element_size() if torch.is_tensor(t) else 0
+
+
+def _conv_sub(method: str, a, k, out):
+    """(sub-family, flops, activation bytes) of one conv-family launch: the 32-channel 5x5 layers at full resolution (the ResBlock convs of
+    level 1 and the first / last conv) move 0.4-1.6 GB per launch for 0.3 TFLOP — their roofline is HBM, not the matrix pipe."""
+    if method == "conv5_in":
+        return "level1", 2.0 * 25 * 3 * 32 * a[0].shape[-2] * a[0].shape[-1], _tensor_bytes(a[0]) + _tensor_bytes(out)
+    if method == "conv5_out":
+        return "level1", 2.0 * 25 * 32 * 3 * a[0].H * a[0].W, _tensor_bytes(a[0]) + 12 * a[0].H * a[0].W
+    src, n = a[0], a[3]
+    ks = a[4] if len(a) > 4 else k.get("ksize", 1)
+    if n == 32 and src.C == 32 and ks == 5 and k.get("stride", a[5] if len(a) > 5 else 1) == 1:
+        maps = getattr(src, "B", 1)
+        return "level1", 2.0 * 25 * 32 * 32 * maps * src.H * src.W, _tensor_bytes(src) + _tensor_bytes(out)
+    return "rest", 0.0, 0
+
+
 def _family(name: str):
     """Time every call of a leaf launch method when the caller asked for it: `profile["families"]` = {family: [(start, end), ...]} gets
-    one HIP event pair per call on the launch stream (eager, single-stream passes only: bench.py's per-family roofline record)."""
+    one HIP event pair per call on the launch stream (eager, single-stream passes only: bench.py's per-family roofline record); the
+    conv family also by sub-family (`profile["conv_sub"]`: events, flops, bytes)."""
     def deco(fn):
         def wrapper(self, *a, **k):
             pr = self.profile
@@ -141,6 +162,12 @@ def _family(name: str):
             out = fn(self, *a, **k)
             e_.record(st)
             pr["families"].setdefault(name, []).append((s_, e_))
+            if name == "conv":
+                sub, fl, by = _conv_sub(fn.__name__, a, k, out)
+                rec = pr.setdefault("conv_sub", {}).setdefault(sub, {"events": [], "flops": 0.0, "bytes": 0})
+                rec["events"].append((s_, e_))
+                rec["flops"] += fl
+                rec["bytes"] += by
             return out
         wrapper.__name__, wrapper.__doc__ = fn.__name__, fn.__doc__
         return wrapper
