@@ -149,6 +149,15 @@ int spei_convt2_slab16(int fmt, const void* a0, int lda0, int k0, int a_fmt, con
 int spei_convt2_slab16x3(const float* a0, int lda0, int k0, const void* const* whi4, const void* const* wlo4, const float* bias,
                          float* out, int ldo, int Hin, int Win, int N, int act, spei_stream_t stream);
 
+/* 3x3 convolution 256 -> 256 channels (stride 1, padding 1) on a batch of fp32 token maps: the `conv(blocks(x)) + x` tail of every
+ * residual Swin group and conv_after_body (reference model/swinir.py:467,483-484,742) as a persistent, software-pipelined kernel — one
+ * workgroup per CU walks 6 x 16 pixel tiles, every weight fragment feeds three MFMAs, the next tile's halo is staged inside the
+ * current tile's 144 k-steps (round 4; conv_slab_kernel took 190 us per launch for the frame's two maps).  x, out, residual (or NULL;
+ * may alias out): [batch][H*W][256] fp32, x != out; w_frag: fragment-ordered 16-bit weights [8][9][16][64][8] (pack.py); bias [256] or
+ * NULL.  H % 6 == 0, W % 16 == 0, H*W <= 2^21. */
+int spei_conv3x3_256_pipe16(int fmt, const float* x, const void* w_frag, const float* bias, const float* residual, float* out,
+                            int batch, int H, int W, spei_stream_t stream);
+
 /* Last conv (model/recons_video_ori.py:75-77: 5x5, 32 -> 3 channels, NHWC in, three NCHW fp32 planes out) on the
  * slab kernel: wfrag = fragment-ordered weights zero-padded to 32 output channels, bias32 = bias padded to 32. */
 int spei_conv5_out_slab16(int fmt, const void* in, int ldi, int in_fmt, const void* wfrag, const float* bias32, float* out_chw,

@@ -39,6 +39,7 @@ SIGNATURES = {
     "spei_conv5_out_slab16": (I, [I, P, I, I, P, P, P, I, I, P]),
     "spei_convt2_slab16": (I, [I, P, I, I, I, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "spei_convt2_slab16x3": (I, [P, I, I, P, P, P, P, I, I, I, I, I, P]),
+    "spei_conv3x3_256_pipe16": (I, [I, P, P, P, P, P, I, I, I, P]),
     "spei_mlp_fused16": (I, [I, P, P, P, P, P, P, L, P]),
     "spei_split16": (I, [I, P, I, P, P, L, I, P]),
     "spei_corr_slab16": (I, [I, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P]),

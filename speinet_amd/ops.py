@@ -254,6 +254,8 @@ class Ctx:
                       stages in ONE launch per layer (gridDim.y = pass; engine.enc_batched) instead of one launch per pass and layer:
                       bit-identical frames, ~1000 fewer launches per frame, and at H/4 a launch has 3150 workgroups instead of 450
                       (three resident rounds instead of half of one).  Off: round 2's per-pass launches on two streams
+      conv3_pipe      16-bit: the 256 -> 256 channel 3x3 convolutions of the Swin body (RSTB tail, conv_after_body) on fp32 token maps whose
+                      height is a multiple of 6 and width a multiple of 16 as a persistent pipelined kernel (spei_conv3x3_256_pipe16)
       attn_win4       16-bit, with fuse_attn: the fused attention branch with four windows per workgroup and a batch of maps per launch
                       (spei_attn_win4_16).  Off: round 2's two-window kernel, one map per launch (spei_attn_fused16)
       conv32_ws       16-bit: the 32 -> 32 channel 5x5 convolutions (the ResBlock convs at full resolution: inBlock, outBlock) on the
@@ -275,7 +277,7 @@ class Ctx:
     ACT_NONE, ACT_RELU, ACT_GELU = ACT_NONE, ACT_RELU, ACT_GELU
     CONV, CONV_T = CONV, CONV_T
     _FIELDS = ("precision", "corr_precision", "device", "use_slab", "bf16_storage", "x1_bf16", "fuse_mlp", "fuse_attn",
-               "commute_upconv", "commute_any", "corr_bf16", "corr_diag", "fuse_apply", "split_decode", "batch_enc", "attn_win4", "conv32_ws", "stage", "profile", "capture")
+               "commute_upconv", "commute_any", "corr_bf16", "corr_diag", "fuse_apply", "split_decode", "batch_enc", "attn_win4", "conv32_ws", "conv3_pipe", "stage", "profile", "capture")
     # stages of an f16 frame that run in split (bf16x3) arithmetic by default, see `split_decode`
     SPLIT_STAGES = ("glue", "dec2")
     __slots__ = _FIELDS
@@ -284,7 +286,7 @@ class Ctx:
                  bf16_storage: bool = True, x1_bf16: bool = True, fuse_mlp: bool = True, fuse_attn: bool = True,
                  commute_upconv: bool = True, commute_any: bool = False, corr_bf16: bool = True,
                  corr_diag: bool = True, fuse_apply: bool = False, split_decode: bool = True, batch_enc: bool = True,
-                 attn_win4: bool = True, conv32_ws: bool = True, stage: Optional[dict] = None,
+                 attn_win4: bool = True, conv32_ws: bool = True, conv3_pipe: bool = True, stage: Optional[dict] = None,
                  profile: Optional[dict] = None, capture: Optional[dict] = None):
         if precision not in PRECISIONS:
             raise ValueError(f"unknown precision {precision!r}")
@@ -304,7 +306,7 @@ class Ctx:
         object.__setattr__(self, "device", device)
         for k, v in (("use_slab", use_slab), ("bf16_storage", bf16_storage), ("x1_bf16", x1_bf16), ("fuse_mlp", fuse_mlp),
                      ("fuse_attn", fuse_attn), ("commute_upconv", commute_upconv), ("commute_any", commute_any),
-                     ("corr_bf16", corr_bf16), ("corr_diag", corr_diag), ("fuse_apply", fuse_apply), ("split_decode", split_decode), ("batch_enc", batch_enc), ("attn_win4", attn_win4), ("conv32_ws", conv32_ws)):
+                     ("corr_bf16", corr_bf16), ("corr_diag", corr_diag), ("fuse_apply", fuse_apply), ("split_decode", split_decode), ("batch_enc", batch_enc), ("attn_win4", attn_win4), ("conv32_ws", conv32_ws), ("conv3_pipe", conv3_pipe)):
             object.__setattr__(self, k, bool(v))
         object.__setattr__(self, "stage", dict(stage) if stage else {})
         object.__setattr__(self, "profile", profile)
@@ -400,6 +402,15 @@ class Ctx:
         return out
 
     # ---- the GEMM family ---------------------------------------------------------------------------------------
+    def _conv3_pipe_ok(self, a, w, N: int, ksize: int, stride: int, act: int, residual, out) -> bool:
+        """The persistent 3x3 / 256-channel kernel takes the call: dense fp32 maps, 6 x 16 pixel tiles cover the map, 16-bit single products."""
+        return (self.conv3_pipe and self.lp16 and self.use_slab and ksize == 3 and stride == 1 and N == 256 and a.C == 256 and act == ACT_NONE
+                and a.H % 6 == 0 and a.W % 16 == 0 and a.H * a.W <= (1 << 21) and a.t.dtype == torch.float32 and getattr(a, "ld", 256) == 256
+                and getattr(a, "off", 0) == 0 and getattr(w, "fhi", None) is not None and tuple(w.shape) == (9, 256, 256)
+                and (out is None or (out.t.dtype == torch.float32 and getattr(out, "ld", 256) == 256 and getattr(out, "off", 0) == 0
+                                     and out.t.data_ptr() != a.t.data_ptr()))
+                and (residual is None or (residual.t.dtype == torch.float32 and getattr(residual, "ld", 256) == 256 and getattr(residual, "off", 0) == 0)))
+
     @_family("conv")
     def igemm(self, a0: FMap, w, bias: Optional[torch.Tensor], N: int, ksize: int = 1, stride: int = 1,
               mode: int = CONV, act: int = ACT_NONE, a1: Optional[FMap] = None, residual: Optional[FMap] = None,
@@ -436,7 +447,11 @@ class Ctx:
                   ksize, stride, pad, mode, act, self._stream())
         srcs = (fp(a0), a0.ld, k0, fp(a1), a1.ld if a1 is not None else 0, k1)
         lib = _lib.lib()
-        if (self.conv32_ws_available() and mode == CONV and ksize == 5 and stride == 1 and k0 == 32 and N == 32 and a1 is None
+        if (mode == CONV and a1 is None and rowscale is None and not ln_input and out_dtype == torch.float32
+                and self._conv3_pipe_ok(a0, w, N, ksize, stride, act, residual, out)):
+            _lib.check(lib.spei_conv3x3_256_pipe16(self.fmt, fp(a0), tp(w.frag(self.fmt)), tp(bias), fp(residual), fp(out), 1, a0.H, a0.W,
+                                                   self._stream()), "spei_conv3x3_256_pipe16")
+        elif (self.conv32_ws_available() and mode == CONV and ksize == 5 and stride == 1 and k0 == 32 and N == 32 and a1 is None
                 and residual is None and rowscale is None and not ln_input and act in (ACT_NONE, ACT_RELU) and w.fhi is not None
                 and (a0.ld, a0.off, out.ld, out.off) == (32, 0, 32, 0) and a0.t.data_ptr() != out.t.data_ptr()):
             # the 32-channel 5x5 layers: weight-stationary persistent kernel (csrc/conv32_ws16.hip)
@@ -572,6 +587,11 @@ class Ctx:
             assert (residual.B, residual.H, residual.W, residual.C) == (a.B, ho, wo, N) and residual.t.dtype == torch.float32
             assert residual.t.data_ptr() != a.t.data_ptr()
         tp = self._tp
+        if out_dtype == torch.float32 and self._conv3_pipe_ok(a, w, N, ksize, stride, act, residual, out):
+            _lib.check(_lib.lib().spei_conv3x3_256_pipe16(self.fmt, tp(a.t), tp(w.frag(self.fmt)), tp(bias),
+                                                          tp(residual.t) if residual is not None else _vp(0), tp(out.t), a.B, a.H, a.W,
+                                                          self._stream()), "spei_conv3x3_256_pipe16")
+            return out
         if (self.conv32_ws_available() and ksize == 5 and stride == 1 and a.C == 32 and N == 32 and residual is None
                 and act in (ACT_NONE, ACT_RELU)):
             _lib.check(_lib.lib().spei_conv32_ws16(self.fmt, tp(a.t), a.fmt, tp(w.frag(self.fmt)), tp(bias), tp(out.t), out.fmt, a.B, a.H, a.W,

@@ -124,6 +124,38 @@ def test_igemm_concat_transpose_epilogue(mode):
     assert relerr(out.nchw(), ref) < TOL[mode]
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_conv3x3_256_pipe_vs_conv2d(mode):
+    """The persistent 3x3 / 256-channel kernel of the Swin body (spei_conv3x3_256_pipe16; RSTB tail and conv_after_body, reference
+    model/swinir.py:467,483-484,742) against F.conv2d in fp32: one tile, several tiles per workgroup's walk across map borders, two stacked
+    maps, the residual aliasing the output (as engine.swin_multi calls it), and the fall-back to the slab kernel where 6 x 16 tiles do not
+    cover the map."""
+    from speinet_amd.ops import BMap
+    ops = Ctx(mode, device=DEV)
+    slab = ops.replace(conv3_pipe=False)
+    wt, b = rnd(31, 256, 256, 3, 3, scale=0.03), rnd(32, 256, scale=0.1)
+    pw = pack.PackedW(pack.conv_w(wt), DEV)
+    for (batch, h, w) in ((1, 6, 16), (1, 12, 48), (3, 18, 32), (2, 180, 320), (1, 10, 16)):
+        x = rnd(33 + h, batch, 256, h, w)
+        r = rnd(34 + w, batch, 256, h, w)
+        ref = F.conv2d(x, wt, b, padding=1) + r
+        xin = x.permute(0, 2, 3, 1).reshape(batch * h * w, 256).contiguous().to(DEV)
+        rin = r.permute(0, 2, 3, 1).reshape(batch * h * w, 256).contiguous().to(DEV)
+        rb = BMap(rin.clone(), batch, h, w, 256)
+        out = ops.igemm_batched(BMap(xin, batch, h, w, 256), pw, b.to(DEV), 256, 3, residual=rb, out=rb)       # in place on the residual
+        got = out.t.view(batch, h, w, 256).permute(0, 3, 1, 2).cpu()
+        e = relerr(got, ref)
+        assert torch.isfinite(got).all() and e < TOL[mode], f"{mode} {batch}x{h}x{w}: rel err {e:.2e}"
+        old = slab.igemm_batched(BMap(xin, batch, h, w, 256), pw, b.to(DEV), 256, 3, residual=BMap(rin, batch, h, w, 256))
+        assert relerr(out.t, old.t) < TOL[mode]
+        # one map alone through igemm (the x-side call of a frame), no residual, fresh output
+        one = ops.igemm(FMap(xin[:h * w], h, w, 256), pw, b.to(DEV), 256, ksize=3)
+        assert relerr(one.nchw().cpu(), F.conv2d(x[:1], wt, b, padding=1)) < TOL[mode]
+        if h % 6 == 0 and batch > 1:                  # a map's result does not depend on its place in the batch
+            last = ops.igemm(FMap(xin[-h * w:].contiguous(), h, w, 256), pw, b.to(DEV), 256, ksize=3, residual=FMap(rin[-h * w:].contiguous(), h, w, 256))
+            assert torch.equal(last.t, out.t[-h * w:])
+
+
 @pytest.mark.parametrize("name", ["g07_search", "g07_search_tie"])
 def test_search_bf16x3_argmax_exact(golden_dir, name):
     """With split-bf16 scores the arg-max of the golden cases (incl. the exact-tie one) stays bit exact."""

@@ -49,3 +49,11 @@ out2 = torch.empty_like(x2)
 timeit("mlp_fused 2x tokens", lambda: ops.mlp_fused(x2, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out2))
 for shift in (0, 2):
     timeit(f"attn + mlp shift={shift}", lambda: a2.mlp_fused(a2.attn_fused(x, yhat, bk, H, W, shift, out), bk["w1"], bk["b1"], bk["w2"], bk["b2"], out))
+# the 256 -> 256 channel 3x3 convolution of the Swin body (RSTB tail) on the frame's two stacked maps: persistent kernel / slab kernel
+from speinet_amd.ops import BMap                     # noqa: E402
+cw = pack.PackedW(torch.randn(9, 256, 256) * 0.03, dev)
+cb = torch.randn(256, device=dev)
+cx, cr = BMap(xx, 2, H, W, 256), BMap(torch.randn_like(xx), 2, H, W, 256)
+timeit("conv3x3 256 pipe, 2 maps", lambda: ops.igemm_batched(cx, cw, cb, 256, 3, residual=cr, out=cr))
+slab3 = ops.replace(conv3_pipe=False)
+timeit("conv3x3 256 slab, 2 maps", lambda: slab3.igemm_batched(cx, cw, cb, 256, 3, residual=cr, out=cr))
