@@ -46,6 +46,7 @@ struct C3Params {
     const float* res;       // [batch][H*W][256] or null (may alias out)
     float* out;             // [batch][H*W][256]
     int H, W, batch, tiles_x, tiles_map, ntiles;
+    long long* stamps;      // tuning build: phase stamps of every workgroup's SECOND tile (steady state), else NULL
 };
 
 template <typename LP>
@@ -126,7 +127,9 @@ __global__ __launch_bounds__(512) void conv3_pipe_kernel(const C3Params<LP> p) {
     lds_barrier();
 
     int cur = 0;
-    for (; tile < p.ntiles; tile += G) {
+    int nth = 0;
+    for (; tile < p.ntiles; tile += G, ++nth) {
+        if (nth == 1) { SPEI_STAMP(p.stamps, 0); SPEI_STAMP_CLK(p.stamps, 8); }
         asm volatile("" : "+v"(tid), "+v"(fr), "+v"(fk), "+v"(l16), "+v"(rsub), "+v"(lane16), "+v"(bias));
         const unsigned char* const sa = smem + (cur ? SLAB : 0);          // this tile's halo
         unsigned char* const sn = smem + (cur ? 0 : SLAB);                // the next tile's
@@ -177,14 +180,15 @@ __global__ __launch_bounds__(512) void conv3_pipe_kernel(const C3Params<LP> p) {
             // ---- fillers: the next tile's halo in three chunks (loads as a burst, the conversion 40 steps later); this tile's residual
             // rows near the end (vector-memory accesses that outlast the ring's eight steps go in bursts: mlp_fused16.hip) ----
             if (q == 0) { stage_load(tnc, 0, 0); stage_load(tnc, 1, 1); }
-            if (q == 40) stage_write(tnc, 0, 0, sn, rotn * 32);
+            if (q == 40) { stage_write(tnc, 0, 0, sn, rotn * 32); if (nth == 1) { SPEI_STAMP(p.stamps, 1); SPEI_STAMP_CLK(p.stamps, 9); } }
             if (q == 41) stage_write(tnc, 1, 1, sn, rotn * 32);
             if (q == 44) { stage_load(tnc, 2, 0); stage_load(tnc, 3, 1); }
-            if (q == 84) stage_write(tnc, 2, 0, sn, rotn * 32);
+            if (q == 84) { stage_write(tnc, 2, 0, sn, rotn * 32); if (nth == 1) { SPEI_STAMP(p.stamps, 2); SPEI_STAMP_CLK(p.stamps, 10); } }
             if (q == 85) stage_write(tnc, 3, 1, sn, rotn * 32);
             if (q == 88) stage_load(tnc, 4, 0);
             if (q == 124) stage_write(tnc, 4, 0, sn, rotn * 32);
             if (q == 128) {
+                if (nth == 1) { SPEI_STAMP(p.stamps, 3); SPEI_STAMP_CLK(p.stamps, 11); }
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -196,13 +200,16 @@ __global__ __launch_bounds__(512) void conv3_pipe_kernel(const C3Params<LP> p) {
             for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(acc[i]));
             __builtin_amdgcn_sched_barrier(0);
         });
+        if (nth == 1) { SPEI_STAMP(p.stamps, 4); SPEI_STAMP_CLK(p.stamps, 12); }
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][r] + res[i][r]), rso, voff,
                                                       soff0 + ((2 * i + (r >> 3)) * p.W + 8 * ((r >> 2) & 1) + (r & 3)) * 1024, 0);
+        if (nth == 1) { SPEI_STAMP(p.stamps, 5); SPEI_STAMP_CLK(p.stamps, 13); }
         lds_barrier();                                // the next tile's halo is complete; this tile's slab is free
+        if (nth == 1) { SPEI_STAMP(p.stamps, 6); SPEI_STAMP_CLK(p.stamps, 14); }
         cur ^= 1;
         rot = rotn;
     }
@@ -216,6 +223,7 @@ static int conv3_launch(const float* x, const void* wfrag, const float* bias, co
     C3Params<LP> p;
     p.x = x; p.wfrag = (const LP*)wfrag; p.bias = bias; p.res = res; p.out = out;
     p.H = H; p.W = W; p.batch = batch;
+    p.stamps = spei_stamp_buffer();
     p.tiles_x = W / TW; p.tiles_map = p.tiles_x * (H / TH); p.ntiles = p.tiles_map * batch;
     const size_t lds = (size_t)2 * SLAB;
     ensure_dyn_lds<&conv3_pipe_kernel<LP>>(lds);

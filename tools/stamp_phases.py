@@ -4,7 +4,7 @@ every workgroup stamps s_memtime (100 MHz-independent shader clock ticks) at pha
 passed through SPEI_STAMP_PTR.  Prints the median per-phase durations in microseconds (at the measured clock) and the spread
 of workgroup start / end times across the launch.
 
-    python tools/stamp_phases.py attn|attn4|mlp|mlp2    (attn: round 2's two-window kernel; attn4: the four-window kernel on two stacked maps)
+    python tools/stamp_phases.py attn|attn4|mlp|mlp2|conv3    (attn: round 2's two-window kernel; attn4: the four-window kernel on two stacked maps)
     python tools/stamp_phases.py conv1|conv2|conv3   (conv_slab: the 5x5 ResBlock conv at 720p level 1 / 2 / 3, f16 in and out;
                                                       stamps: 0 start, 1 slab staged, 2 barrier passed, 3 main loop done, 4 stored)
 """
@@ -44,7 +44,12 @@ if which.startswith("ws"):            # the weight-stationary 32-channel kernel 
     wbm = BMap(wx, 7, 720, 1280, 32)
     wpw = pack.PackedW(torch.randn(25, 32, 32) * 0.03, dev)
     wb = torch.randn(32, device=dev)
-if which.startswith("conv"):
+if which == "conv3":
+    from speinet_amd.ops import BMap                                   # noqa: E402
+    c3w = pack.PackedW(torch.randn(9, 256, 256) * 0.03, dev)
+    c3b = torch.randn(256, device=dev)
+    c3x, c3r = BMap(x2, 2, H, W, 256), BMap(torch.randn_like(x2), 2, H, W, 256)
+elif which.startswith("conv"):
     from speinet_amd.ops import FMap                                   # noqa: E402
     ch, hh, ww = {"conv1": (32, 720, 1280), "conv2": (64, 360, 640), "conv3": (128, 180, 320)}[which]
     cx = FMap(torch.randn(hh * ww, ch, device=dev).half(), hh, ww, ch)
@@ -56,12 +61,14 @@ if which.startswith("conv"):
 def run():
     if which.startswith("ws"):
         ops.igemm_batched(wbm, wpw, wb, 32, 5, act=1, out_dtype=torch.float16)
-    elif which.startswith("conv"):
+    elif which.startswith("conv") and which != "conv3":
         ops.igemm(cx, cw, cb, ch, ksize=5, out=cout)
     elif which == "attn":
         ops.replace(attn_win4=False).attn_fused(x, yhat, bk, H, W, 2, out)
     elif which == "attn4":
         ops.attn_fused(x2, yhat2, bk, H, W, 2, out2)
+    elif which == "conv3":            # the persistent 3x3 / 256-channel kernel on two stacked token maps (stamps: the workgroup's second tile)
+        ops.igemm_batched(c3x, c3w, c3b, 256, 3, residual=c3r, out=c3r)
     elif which == "mlp2":
         ops.mlp_fused(x2, bk["w1"], bk["b1"], bk["w2"], bk["b2"], out2)
     else:
@@ -86,7 +93,7 @@ t0 = s[:, 0].min()
 span = (s.max() - t0).item()
 tick_us = 0.01               # s_memrealtime: 100 MHz reference clock, common to all XCDs
 print(f"{which}: {us:.1f} us by HIP events, {n} workgroups, first-start..last-end {span * tick_us:.1f} us")
-if which.startswith("mlp") and (s[:, 8] > 0).any():         # the persistent MLP kernel also stamps the shader clock (slots 8..15)
+if (which.startswith("mlp") or which == "conv3") and (s[:, 8] > 0).any():         # the persistent MLP kernel also stamps the shader clock (slots 8..15)
     clk = s[:, 8:].clone()
     s = s[:, :8]
     for i in range(1, 8):
