@@ -280,22 +280,31 @@ __global__ __launch_bounds__(256) void gather_fold_kernel(const float* __restric
         const int64_t pix = i / cg;
         const int x = (int)(pix % Wo), y = (int)(pix / Wo);
         const int by = y / s, bx = x / s;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        // fold accumulates in increasing in-patch offset (py, px) => decreasing patch index
-        for (int qy = by + 1; qy >= by - 1; --qy) {
-            if (qy < 0 || qy >= H3) continue;
-            const int py = y - qy * s + s;
-            for (int qx = bx + 1; qx >= bx - 1; --qx) {
-                if (qx < 0 || qx >= W3) continue;
-                const int px = x - qx * s + s;
-                const int a = arg[qy * W3 + qx];
-                const int ay = a / Wr3, ax = a - ay * Wr3;
-                const int sy = ay * s - s + py, sx = ax * s - s + px;
-                if (sy < 0 || sy >= Hs || sx < 0 || sx >= Wsrc) continue;
-                const float4 v = *reinterpret_cast<const float4*>(ref + ((size_t)sy * Wsrc + sx) * ldr + c);
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-            }
+        // fold accumulates in increasing in-patch offset (py, px) => decreasing patch index.  The nine (arg -> address -> row) chains are
+        // independent: all nine indices first, then all nine rows (clamped addresses, absent taps contribute +0: the sum and its
+        // order are those of the branchy loop, which ran the chains one after the other: 67 us at 720p)
+        int a9[9];
+        bool ok9[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int qy = by + 1 - t / 3, qx = bx + 1 - t % 3;
+            ok9[t] = qy >= 0 && qy < H3 && qx >= 0 && qx < W3;
+            a9[t] = arg[min(max(qy, 0), H3 - 1) * W3 + min(max(qx, 0), W3 - 1)];
         }
+        float4 v9[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int qy = by + 1 - t / 3, qx = bx + 1 - t % 3;
+            const int py = y - qy * s + s, px = x - qx * s + s;
+            const int ay = a9[t] / Wr3, ax = a9[t] - ay * Wr3;
+            const int sy = ay * s - s + py, sx = ax * s - s + px;
+            ok9[t] = ok9[t] && sy >= 0 && sy < Hs && sx >= 0 && sx < Wsrc;
+            v9[t] = *reinterpret_cast<const float4*>(ref + ((size_t)min(max(sy, 0), Hs - 1) * Wsrc + min(max(sx, 0), Wsrc - 1)) * ldr + c);
+        }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            if (ok9[t]) { acc.x += v9[t].x; acc.y += v9[t].y; acc.z += v9[t].z; acc.w += v9[t].w; }
         *reinterpret_cast<float4*>(out + pix * ldo + c) = make_float4(acc.x / 9.0f, acc.y / 9.0f, acc.z / 9.0f, acc.w / 9.0f);
     }
 }
